@@ -1,0 +1,113 @@
+"""ctypes loader of libart.so (the C ABI of include/art.h).  Fails loudly: there is no Python or CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libart.so")
+
+ART_OK, ART_E_INVALID, ART_E_STATE, ART_E_NO_DEVICE, ART_E_HIP, ART_E_NOMEM = 0, -1, -2, -3, -4, -5
+ART_FLAG_KEEP_DEBUG = 1
+
+
+class ArtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libart error {code}: {msg}")
+        self.code = code
+
+
+class ArtVertex(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("uv", C.c_float * 2), ("normal", C.c_float * 3), ("tangent", C.c_float * 4)]
+
+
+class ArtLight(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("type", C.c_uint32), ("dir", C.c_float * 3), ("casts_shadows", C.c_uint32),
+                ("color", C.c_float * 3), ("falloff_distance", C.c_float), ("area_pos2", C.c_float * 3), ("penumbra_angle", C.c_float),
+                ("area_pos3", C.c_float * 3), ("umbra_angle", C.c_float)]
+
+
+class ArtCamera(C.Structure):
+    _pack_ = 1
+    _fields_ = [("view", C.c_float * 16), ("view_inv", C.c_float * 16), ("proj", C.c_float * 16), ("proj_inv", C.c_float * 16),
+                ("camera_pos", C.c_float * 3)]
+
+
+class ArtConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("morton_bits", C.c_uint32),
+                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ArtStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("hit_pixels", C.c_uint64), ("ao_rays", C.c_uint64),
+                ("num_triangles", C.c_uint32), ("num_primitives", C.c_uint32), ("num_nodes", C.c_uint32), ("reserved", C.c_uint32),
+                ("build_ms", C.c_float), ("frame_ms", C.c_float), ("trace_primary_ms", C.c_float), ("shade_ms", C.c_float),
+                ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+assert C.sizeof(ArtVertex) == 48 and C.sizeof(ArtLight) == 80 and C.sizeof(ArtCamera) == 268
+
+# every symbol include/art.h declares: (name, restype, argtypes)
+_P, _U32, _I32, _F, _SZ = C.c_void_p, C.c_uint32, C.c_int32, C.c_float, C.c_size_t
+SYMBOLS = {
+    "art_last_error": (C.c_char_p, []),
+    "art_device_count": (_I32, []),
+    "art_create": (_I32, [_P, _P]),
+    "art_destroy": (_I32, [_P]),
+    "art_set_stream": (_I32, [_P, _P]),
+    "art_scene_add_primitive": (_I32, [_P, _P, _U32, _P, _U32, _U32, _P, _U32, _U32, _P, _P]),
+    "art_scene_clear": (_I32, [_P]),
+    "art_scene_build": (_I32, [_P]),
+    "art_set_camera": (_I32, [_P, _P]),
+    "art_camera_from_params": (_I32, [_P, _P, _F, _F, _F, _F, _P]),
+    "art_set_lights": (_I32, [_P, _P, _U32]),
+    "art_light_point": (_I32, [_P, _P, _F, _I32, _P]),
+    "art_light_spot": (_I32, [_P, _P, _P, _F, _F, _F, _I32, _P]),
+    "art_light_directional": (_I32, [_P, _P, _I32, _P]),
+    "art_light_area": (_I32, [_P, _P, _P, _I32, _P, _F, _F, _F, _I32, _P]),
+    "art_resize": (_I32, [_P, _U32, _U32]),
+    "art_trace": (_I32, [_P]),
+    "art_sync": (_I32, [_P]),
+    "art_read_color": (_I32, [_P, _P, _SZ]),
+    "art_read_depth": (_I32, [_P, _P, _SZ]),
+    "art_read_normal": (_I32, [_P, _P, _SZ]),
+    "art_device_color": (_I32, [_P, _P, _P]),
+    "art_device_depth": (_I32, [_P, _P, _P]),
+    "art_device_normal": (_I32, [_P, _P, _P]),
+    "art_shard_tile_count": (_I32, [_P, _P, _P]),
+    "art_device_color_tiles": (_I32, [_P, _P, _P]),
+    "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
+    "art_untile_gathered": (_I32, [_P, _P, _U32, _P]),
+    "art_get_stats": (_I32, [_P, _P]),
+    "art_read_hits": (_I32, [_P, _P, _P, _SZ]),
+    "art_read_shadow_bits": (_I32, [_P, _P, _SZ]),
+    "art_query_closest": (_I32, [_P, _P, _U32, _P, _P]),
+    "art_query_any": (_I32, [_P, _P, _U32, _P]),
+    "art_get_lbvh": (_I32, [_P] + [_P] * 7),
+}
+
+_lib = None
+
+
+def load():
+    """Load libart.so; raises if the HIP extension has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C araytracingjourney_amd/csrc` (libart has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != ART_OK:
+        raise ArtError(code, load().art_last_error().decode("utf-8", "replace"))

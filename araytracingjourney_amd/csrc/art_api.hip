@@ -1,0 +1,599 @@
+// art_api.hip -- the C ABI of include/art.h: context, scene tables, frame orchestration, host maths.
+// Product code; gfx950 only; there is no CPU fallback anywhere in this file.
+#include "art_internal.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+using namespace art;
+
+namespace {
+
+thread_local std::string g_err;
+int32_t fail(int32_t code, const std::string &msg) { g_err = msg; return code; }
+int32_t hipfail(hipError_t e, const char *what) { return fail(ART_E_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hipfail(e_, #x); } while (0)
+
+struct HostPrim {
+    std::vector<ArtVertex> verts;
+    std::vector<uint8_t> indices; // original width
+    uint32_t n_indices, idx_bytes;
+    std::vector<uint8_t> tex;
+    uint32_t tw, th;
+    float o2w[12], w2o[12];
+};
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count ? count : 1;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+} // namespace
+
+struct ArtContext {
+    ArtConfig cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint32_t W = 0, H = 0;
+    std::vector<HostPrim> prims;
+    bool built = false, have_camera = false, frame_ready = false;
+    // device scene
+    DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
+    Lbvh bvh{};
+    uint32_t T = 0;
+    ArtCamera camera{};
+    std::vector<ArtLight> lights;
+    DevBuf<ArtLight> d_lights;
+    // frame
+    std::vector<uint32_t> tile_list; uint32_t tiles_x = 0, tiles_y = 0, padded_tiles = 0, n_local = 0;
+    DevBuf<uint32_t> d_tile_list, d_counters, d_shadow_bits;
+    DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
+    DevBuf<float> d_depth;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool traced = false;
+    ArtStats stats{};
+};
+
+namespace {
+
+void affine_inverse(const float *m, float *o) { // row-major 3x4
+    float a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    float det = a * A + b * B + c * C;
+    float id = 1.0f / det;
+    o[0] = A * id;  o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+    o[4] = B * id;  o[5] = (a * i - c * g) * id;  o[6] = -(a * f - c * d) * id;
+    o[8] = C * id;  o[9] = -(a * h - b * g) * id; o[10] = (a * e - b * d) * id;
+    float tx = m[3], ty = m[7], tz = m[11];
+    o[3] = -((o[0] * tx + o[1] * ty) + o[2] * tz);
+    o[7] = -((o[4] * tx + o[5] * ty) + o[6] * tz);
+    o[11] = -((o[8] * tx + o[9] * ty) + o[10] * tz);
+}
+
+int32_t use_device(ArtContext *c) {
+    HIPC(hipSetDevice(c->device));
+    return ART_OK;
+}
+
+int32_t setup_frame(ArtContext *c) {
+    // tile ownership + per-frame buffers for the current extent / light count
+    c->tiles_x = (c->W + kTile - 1) / kTile; c->tiles_y = (c->H + kTile - 1) / kTile;
+    uint32_t count = c->cfg.shard_count > 1 ? c->cfg.shard_count : 1, rank = count > 1 ? c->cfg.shard_rank : 0;
+    c->tile_list.clear();
+    std::vector<uint32_t> per(count, 0);
+    for (uint32_t ty = 0; ty < c->tiles_y; ty++)
+        for (uint32_t tx = 0; tx < c->tiles_x; tx++) {
+            uint32_t o = tile_owner(tx, ty, count);
+            per[o]++;
+            if (o == rank) c->tile_list.push_back(ty * c->tiles_x + tx);
+        }
+    c->padded_tiles = 0;
+    for (uint32_t v : per) c->padded_tiles = v > c->padded_tiles ? v : c->padded_tiles;
+    c->n_local = (uint32_t)c->tile_list.size() * kTilePixels;
+    size_t npix = (size_t)c->W * c->H;
+    size_t nl = c->lights.size() ? c->lights.size() : 1;
+    HIPC(c->d_tile_list.ensure(c->tile_list.size()));
+    if (!c->tile_list.empty()) HIPC(hipMemcpy(c->d_tile_list.p, c->tile_list.data(), c->tile_list.size() * 4, hipMemcpyHostToDevice));
+    HIPC(c->d_counters.ensure(16));
+    HIPC(c->d_hits.ensure(c->n_local));
+    HIPC(c->d_contrib.ensure(nl * c->n_local));
+    HIPC(c->d_shadow_rays.ensure(2 * nl * c->n_local));
+    HIPC(c->d_color.ensure(npix)); HIPC(c->d_normal.ensure(npix)); HIPC(c->d_depth.ensure(npix));
+    HIPC(hipMemset(c->d_color.p, 0, npix * 16)); HIPC(hipMemset(c->d_normal.p, 0, npix * 16)); HIPC(hipMemset(c->d_depth.p, 0, npix * 4));
+    if (count > 1) { HIPC(c->d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(c->d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * 16)); }
+    if (c->cfg.flags & ART_FLAG_KEEP_DEBUG) HIPC(c->d_shadow_bits.ensure(c->n_local));
+    HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the context's stream is non-blocking
+    c->frame_ready = true;
+    return ART_OK;
+}
+
+void normalize3(const float *v, float *o) {
+    float l = std::sqrt(std::fmaf(v[2], v[2], std::fmaf(v[1], v[1], v[0] * v[0])));
+    float inv = 1.0f / l;
+    o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
+}
+void cross3h(const float *a, const float *b, float *o) {
+    o[0] = std::fmaf(a[1], b[2], -(a[2] * b[1])); o[1] = std::fmaf(a[2], b[0], -(a[0] * b[2])); o[2] = std::fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+float dot3h(const float *a, const float *b) { return std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])); }
+
+// general 4x4 inverse by cofactors, column-major (stands in for nalgebra's try_inverse, vk_camera.rs:111-113)
+bool mat4_inverse(const float *m, float *o) {
+    float inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0.0f) return false;
+    det = 1.0f / det;
+    for (int i = 0; i < 16; i++) o[i] = inv[i] * det;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *art_last_error(void) { return g_err.c_str(); }
+
+int32_t art_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
+    if (!cfg || !out) return fail(ART_E_INVALID, "art_create: null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ART_E_NO_DEVICE, "art_create: no HIP device (libart has no CPU fallback)");
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return fail(ART_E_NO_DEVICE, "art_create: hipGetDevice failed"); }
+    if (dev >= n) return fail(ART_E_INVALID, "art_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ART_E_NO_DEVICE, std::string("art_create: device is ") + prop.gcnArchName + ", libart is built for gfx950 only");
+    if (cfg->morton_bits != 0 && cfg->morton_bits != 30 && cfg->morton_bits != 63) return fail(ART_E_INVALID, "art_create: morton_bits must be 0, 30 or 63");
+    if (cfg->shard_count > 1 && cfg->shard_rank >= cfg->shard_count) return fail(ART_E_INVALID, "art_create: shard_rank >= shard_count");
+    ArtContext *c = new (std::nothrow) ArtContext();
+    if (!c) return fail(ART_E_NOMEM, "art_create: out of memory");
+    c->cfg = *cfg;
+    if (c->cfg.morton_bits == 0) c->cfg.morton_bits = 63;
+    c->device = dev;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
+    c->stream = c->own_stream;
+    c->W = cfg->width; c->H = cfg->height;
+    *out = c;
+    return ART_OK;
+}
+
+int32_t art_destroy(ArtContext *c) {
+    if (!c) return ART_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    lbvh_free(c->bvh);
+    c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release(); c->d_lights.release();
+    c->d_tile_list.release(); c->d_counters.release(); c->d_shadow_bits.release(); c->d_hits.release(); c->d_contrib.release();
+    c->d_shadow_rays.release(); c->d_color.release(); c->d_normal.release(); c->d_color_tiles.release(); c->d_depth.release();
+    for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return ART_OK;
+}
+
+int32_t art_set_stream(ArtContext *c, void *hip_stream) {
+    if (!c) return fail(ART_E_INVALID, "art_set_stream: null context");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return ART_OK;
+}
+
+int32_t art_scene_add_primitive(ArtContext *c, const ArtVertex *verts, uint32_t n_verts, const void *indices, uint32_t n_indices,
+                                uint32_t idx_bytes, const uint8_t *rgba8, uint32_t tw, uint32_t th, const float model3x4[12], uint32_t *out_id) {
+    if (!c || !verts || !indices || !rgba8 || !model3x4) return fail(ART_E_INVALID, "art_scene_add_primitive: null argument");
+    if (idx_bytes != 2 && idx_bytes != 4) return fail(ART_E_INVALID, "art_scene_add_primitive: idx_bytes must be 2 or 4");
+    if (n_indices == 0 || n_indices % 3 != 0) return fail(ART_E_INVALID, "art_scene_add_primitive: index count must be a positive multiple of 3");
+    if (n_verts == 0 || tw == 0 || th == 0) return fail(ART_E_INVALID, "art_scene_add_primitive: empty vertices or texture");
+    if (idx_bytes == 2 && n_verts > 65536) return fail(ART_E_INVALID, "art_scene_add_primitive: u16 indices cannot address the vertex count");
+    for (uint32_t i = 0; i < n_indices; i++) {
+        uint32_t v = idx_bytes == 2 ? ((const uint16_t *)indices)[i] : ((const uint32_t *)indices)[i];
+        if (v >= n_verts) return fail(ART_E_INVALID, "art_scene_add_primitive: index out of range");
+    }
+    HostPrim p;
+    p.verts.assign(verts, verts + n_verts);
+    p.indices.assign((const uint8_t *)indices, (const uint8_t *)indices + (size_t)n_indices * idx_bytes);
+    p.n_indices = n_indices; p.idx_bytes = idx_bytes;
+    p.tex.assign(rgba8, rgba8 + (size_t)3 * tw * th * 4);
+    p.tw = tw; p.th = th;
+    std::memcpy(p.o2w, model3x4, 48);
+    affine_inverse(p.o2w, p.w2o);
+    c->prims.push_back(std::move(p));
+    c->built = false;
+    if (out_id) *out_id = (uint32_t)c->prims.size() - 1;
+    return ART_OK;
+}
+
+int32_t art_scene_clear(ArtContext *c) {
+    if (!c) return fail(ART_E_INVALID, "art_scene_clear: null context");
+    c->prims.clear(); c->built = false;
+    return ART_OK;
+}
+
+int32_t art_scene_build(ArtContext *c) {
+    if (!c) return fail(ART_E_INVALID, "art_scene_build: null context");
+    if (c->prims.empty()) return fail(ART_E_STATE, "art_scene_build: no primitives");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    lbvh_free(c->bvh); c->built = false;
+    size_t nv = 0, ib = 0, nt = 0; uint32_t T = 0;
+    for (auto &p : c->prims) { nv += p.verts.size(); ib += (p.indices.size() + 15) & ~(size_t)15; nt += (size_t)3 * p.tw * p.th; }
+    HIPC(c->d_verts.ensure(nv * 12)); HIPC(c->d_indices.ensure(ib)); HIPC(c->d_tex.ensure(nt));
+    std::vector<DevPrim> dp(c->prims.size());
+    std::vector<uint32_t> first(c->prims.size());
+    size_t ov = 0, oi = 0, ot = 0;
+    for (size_t k = 0; k < c->prims.size(); k++) {
+        auto &p = c->prims[k];
+        HIPC(hipMemcpy(c->d_verts.p + ov * 12, p.verts.data(), p.verts.size() * 48, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(c->d_indices.p + oi, p.indices.data(), p.indices.size(), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(c->d_tex.p + ot, p.tex.data(), p.tex.size(), hipMemcpyHostToDevice));
+        DevPrim &d = dp[k];
+        d.vertices = c->d_verts.p + ov * 12; d.indices = c->d_indices.p + oi; d.texture_offset = (uint32_t)ot; d.single_index_size = p.idx_bytes;
+        d.tw = p.tw; d.th = p.th; d.first_tri = T; d.n_tri = p.n_indices / 3;
+        std::memcpy(d.o2w, p.o2w, 48); std::memcpy(d.w2o, p.w2o, 48);
+        first[k] = T;
+        T += d.n_tri;
+        ov += p.verts.size(); oi += (p.indices.size() + 15) & ~(size_t)15; ot += (size_t)3 * p.tw * p.th;
+    }
+    HIPC(c->d_prims.ensure(dp.size())); HIPC(c->d_first_tri.ensure(first.size()));
+    HIPC(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(c->d_first_tri.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    c->T = T;
+    BuildInputs in{c->d_prims.p, (uint32_t)dp.size(), c->d_first_tri.p, T, c->cfg.morton_bits};
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, c->stream));
+    hipError_t e = lbvh_build(in, c->bvh, c->stream);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "lbvh_build"); }
+    HIPC(hipEventRecord(e1, c->stream)); HIPC(hipEventSynchronize(e1));
+    float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    c->stats.build_ms = ms; c->stats.num_triangles = T; c->stats.num_primitives = (uint32_t)dp.size(); c->stats.num_nodes = T > 1 ? T - 1 : 1;
+    c->built = true;
+    return ART_OK;
+}
+
+int32_t art_set_camera(ArtContext *c, const ArtCamera *cam) {
+    if (!c || !cam) return fail(ART_E_INVALID, "art_set_camera: null argument");
+    c->camera = *cam; c->have_camera = true;
+    return ART_OK;
+}
+
+int32_t art_camera_from_params(const float pos[3], const float dir[3], float aspect, float fovy, float znear, float zfar, ArtCamera *out) {
+    if (!pos || !dir || !out) return fail(ART_E_INVALID, "art_camera_from_params: null argument");
+    // VkCamera::set_dir normalises (vk_camera.rs:133-136); view = look_at_rh(pos, pos + dir, up = (0,-1,0)) (:182-189)
+    float dn[3], tgt[3], f[3], s[3], u[3];
+    normalize3(dir, dn);
+    for (int k = 0; k < 3; k++) tgt[k] = (pos[k] + dn[k]) - pos[k];
+    normalize3(tgt, f);
+    const float up[3] = {0.0f, -1.0f, 0.0f};
+    float sx[3]; cross3h(f, up, sx); normalize3(sx, s);
+    cross3h(s, f, u);
+    float *V = out->view;
+    V[0] = s[0]; V[4] = s[1]; V[8] = s[2]; V[12] = -dot3h(s, pos);
+    V[1] = u[0]; V[5] = u[1]; V[9] = u[2]; V[13] = -dot3h(u, pos);
+    V[2] = -f[0]; V[6] = -f[1]; V[10] = -f[2]; V[14] = dot3h(f, pos);
+    V[3] = 0; V[7] = 0; V[11] = 0; V[15] = 1;
+    // proj = Perspective3::new(aspect, fovy, znear, zfar) (:191-193): OpenGL convention, z in [-1, 1]
+    float *P = out->proj;
+    std::memset(P, 0, 64);
+    float cc = 1.0f / std::tan(fovy * 0.5f);
+    P[0] = cc / aspect; P[5] = cc; P[10] = (zfar + znear) / (znear - zfar); P[14] = 2.0f * zfar * znear / (znear - zfar); P[11] = -1.0f;
+    if (!mat4_inverse(out->view, out->view_inv) || !mat4_inverse(out->proj, out->proj_inv)) return fail(ART_E_INVALID, "art_camera_from_params: singular matrix");
+    out->camera_pos[0] = pos[0]; out->camera_pos[1] = pos[1]; out->camera_pos[2] = pos[2];
+    return ART_OK;
+}
+
+int32_t art_set_lights(ArtContext *c, const ArtLight *lights, uint32_t n) {
+    if (!c || (n && !lights)) return fail(ART_E_INVALID, "art_set_lights: null argument");
+    if (n > (uint32_t)kMaxLights) return fail(ART_E_INVALID, "art_set_lights: more than 16 lights");
+    for (uint32_t i = 0; i < n; i++) if (lights[i].type > 3) return fail(ART_E_INVALID, "art_set_lights: unknown light type");
+    int32_t r = use_device(c); if (r) return r;
+    bool resized = n != c->lights.size();
+    c->lights.assign(lights, lights + n);
+    HIPC(c->d_lights.ensure(n));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (n) HIPC(hipMemcpy(c->d_lights.p, lights, (size_t)n * sizeof(ArtLight), hipMemcpyHostToDevice));
+    if (resized) c->frame_ready = false;
+    return ART_OK;
+}
+
+static void zero_light(ArtLight *l) { std::memset(l, 0, sizeof(*l)); }
+static void cp3(float *d, const float *s) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+
+int32_t art_light_point(const float pos[3], const float color[3], float falloff, int32_t casts, ArtLight *o) { // lights.rs:144-159
+    if (!pos || !color || !o) return fail(ART_E_INVALID, "art_light_point: null argument");
+    zero_light(o); cp3(o->pos, pos); o->type = 0; o->casts_shadows = casts ? 1u : 0u; cp3(o->color, color); o->falloff_distance = falloff;
+    return ART_OK;
+}
+int32_t art_light_spot(const float pos[3], const float dir[3], const float color[3], float falloff, float penumbra, float umbra, int32_t casts, ArtLight *o) { // lights.rs:228-243
+    if (!pos || !dir || !color || !o) return fail(ART_E_INVALID, "art_light_spot: null argument");
+    zero_light(o); cp3(o->pos, pos); o->type = 1; cp3(o->dir, dir); o->casts_shadows = casts ? 1u : 0u; cp3(o->color, color);
+    o->falloff_distance = falloff; o->penumbra_angle = penumbra; o->umbra_angle = umbra;
+    return ART_OK;
+}
+int32_t art_light_directional(const float dir[3], const float color[3], int32_t casts, ArtLight *o) { // lights.rs:281-296
+    if (!dir || !color || !o) return fail(ART_E_INVALID, "art_light_directional: null argument");
+    zero_light(o); o->type = 2; cp3(o->dir, dir); o->casts_shadows = casts ? 1u : 0u; cp3(o->color, color);
+    return ART_OK;
+}
+int32_t art_light_area(const float pos[3], const float pos2[3], const float pos3[3], int32_t invert_normal, const float color[3], float falloff,
+                       float penumbra, float umbra, int32_t casts, ArtLight *o) { // lights.rs:383-403
+    if (!pos || !pos2 || !pos3 || !color || !o) return fail(ART_E_INVALID, "art_light_area: null argument");
+    zero_light(o);
+    float a[3] = {pos[0] - pos2[0], pos[1] - pos2[1], pos[2] - pos2[2]}, b[3] = {pos3[0] - pos2[0], pos3[1] - pos2[1], pos3[2] - pos2[2]}, n[3];
+    cross3h(a, b, n);
+    if (invert_normal) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    normalize3(n, n);
+    cp3(o->pos, pos); o->type = 3; cp3(o->dir, n); o->casts_shadows = casts ? 1u : 0u; cp3(o->color, color); o->falloff_distance = falloff;
+    cp3(o->area_pos2, pos2); o->penumbra_angle = penumbra; cp3(o->area_pos3, pos3); o->umbra_angle = umbra;
+    return ART_OK;
+}
+
+int32_t art_resize(ArtContext *c, uint32_t w, uint32_t h) {
+    if (!c || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(ART_E_INVALID, "art_resize: bad extent");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    c->W = w; c->H = h; c->frame_ready = false; c->traced = false;
+    return ART_OK;
+}
+
+int32_t art_trace(ArtContext *c) {
+    if (!c) return fail(ART_E_INVALID, "art_trace: null context");
+    if (!c->built) return fail(ART_E_STATE, "art_trace: scene not built (art_scene_build)");
+    if (!c->have_camera) return fail(ART_E_STATE, "art_trace: no camera (art_set_camera)");
+    if (c->W == 0 || c->H == 0) return fail(ART_E_STATE, "art_trace: zero extent (art_resize)");
+    int32_t r = use_device(c); if (r) return r;
+    if (!c->frame_ready) { HIPC(hipStreamSynchronize(c->stream)); r = setup_frame(c); if (r) return r; }
+    FrameArgs a{};
+    static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
+    std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
+    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local;
+    a.nodes = c->bvh.nodes; a.tris = c->bvh.tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
+    a.lights = c->d_lights.p; a.n_lights = (uint32_t)c->lights.size();
+    a.hits = c->d_hits.p; a.contrib = c->d_contrib.p; a.shadow_rays = c->d_shadow_rays.p; a.counters = c->d_counters.p;
+    a.color = c->d_color.p; a.depth = c->d_depth.p; a.normal = c->d_normal.p;
+    a.color_tiles = c->cfg.shard_count > 1 ? c->d_color_tiles.p : nullptr;
+    a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? c->d_shadow_bits.p : nullptr;
+    hipStream_t s = c->stream;
+    HIPC(hipMemsetAsync(c->d_counters.p, 0, 16 * 4, s));
+    HIPC(hipEventRecord(c->ev[0], s));
+    if (a.n_local) launch_primary(a, s);
+    HIPC(hipEventRecord(c->ev[1], s));
+    if (a.n_local) launch_shade(a, s);
+    HIPC(hipEventRecord(c->ev[2], s));
+    if (a.n_local) launch_shadow(a, s);
+    HIPC(hipEventRecord(c->ev[3], s));
+    if (a.n_local) launch_accumulate(a, s);
+    HIPC(hipEventRecord(c->ev[4], s));
+    HIPC(hipGetLastError());
+    c->traced = true;
+    return ART_OK;
+}
+
+int32_t art_sync(ArtContext *c) {
+    if (!c) return fail(ART_E_INVALID, "art_sync: null context");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    return ART_OK;
+}
+
+static int32_t read_back(ArtContext *c, const void *src, size_t have, void *dst, size_t bytes, const char *who) {
+    if (!c || !dst) return fail(ART_E_INVALID, std::string(who) + ": null argument");
+    if (!c->traced) return fail(ART_E_STATE, std::string(who) + ": nothing traced yet");
+    if (bytes != have) return fail(ART_E_INVALID, std::string(who) + ": size mismatch");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return ART_OK;
+}
+int32_t art_read_color(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->d_color.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_color"); }
+int32_t art_read_depth(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->d_depth.p : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_depth"); }
+int32_t art_read_normal(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->d_normal.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_normal"); }
+
+static int32_t dev_ptr(ArtContext *c, void *p, size_t n, void **out, size_t *bytes, const char *who) {
+    if (!c || !out) return fail(ART_E_INVALID, std::string(who) + ": null argument");
+    if (!c->frame_ready) { int32_t r = use_device(c); if (r) return r; if (c->W == 0 || c->H == 0) return fail(ART_E_STATE, std::string(who) + ": zero extent"); r = setup_frame(c); if (r) return r; }
+    (void)p;
+    *out = nullptr; if (bytes) *bytes = n;
+    return ART_OK;
+}
+int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color"); if (r) return r; *p = c->d_color.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
+int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
+int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->d_normal.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
+
+int32_t art_shard_tile_count(ArtContext *c, uint32_t *owned, uint32_t *padded) {
+    if (!c) return fail(ART_E_INVALID, "art_shard_tile_count: null context");
+    void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_shard_tile_count"); if (r) return r;
+    if (owned) *owned = (uint32_t)c->tile_list.size();
+    if (padded) *padded = c->padded_tiles;
+    return ART_OK;
+}
+int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
+    int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color_tiles"); if (r) return r;
+    if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
+    *p = c->d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * 16;
+    return ART_OK;
+}
+int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
+    if (c && c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
+    return read_back(c, c ? c->d_color_tiles.p : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * 16 : 0, dst, bytes, "art_read_color_tiles");
+}
+int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev) {
+    if (!c || !gathered_dev) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
+    void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_untile_gathered"); if (r) return r;
+    if (shard_count != (c->cfg.shard_count > 1 ? c->cfg.shard_count : 1)) return fail(ART_E_INVALID, "art_untile_gathered: shard_count differs from the context's");
+    r = use_device(c); if (r) return r;
+    launch_untile((const float4 *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->d_color.p, c->stream);
+    HIPC(hipGetLastError());
+    c->traced = true;
+    return ART_OK;
+}
+
+int32_t art_get_stats(ArtContext *c, ArtStats *out) {
+    if (!c || !out) return fail(ART_E_INVALID, "art_get_stats: null argument");
+    if (c->traced && c->frame_ready) {
+        int32_t r = use_device(c); if (r) return r;
+        HIPC(hipStreamSynchronize(c->stream));
+        uint32_t cnt[2] = {0, 0};
+        HIPC(hipMemcpy(cnt, c->d_counters.p, 8, hipMemcpyDeviceToHost));
+        uint64_t owned = 0; // pixels of owned tiles that fall inside the frame
+        for (uint32_t t : c->tile_list) {
+            uint32_t tx = t % c->tiles_x, ty = t / c->tiles_x;
+            uint32_t w = (tx + 1) * kTile <= c->W ? kTile : c->W - tx * kTile, h = (ty + 1) * kTile <= c->H ? kTile : c->H - ty * kTile;
+            owned += (uint64_t)w * h;
+        }
+        c->stats.primary_rays = owned; c->stats.shadow_rays = cnt[0]; c->stats.hit_pixels = cnt[1];
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) c->stats.frame_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.trace_primary_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.shade_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.trace_shadow_ms = ms;
+        if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->stats.accumulate_ms = ms;
+    }
+    *out = c->stats;
+    return ART_OK;
+}
+
+// ---- parity / debug surface ------------------------------------------------------------------------------------
+int32_t art_read_hits(ArtContext *c, float *tuv, int32_t *ids, size_t n_pixels) {
+    if (!c || !tuv || !ids) return fail(ART_E_INVALID, "art_read_hits: null argument");
+    if (!c->traced) return fail(ART_E_STATE, "art_read_hits: nothing traced yet");
+    if (n_pixels != (size_t)c->W * c->H) return fail(ART_E_INVALID, "art_read_hits: size mismatch");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    std::vector<float4> h(c->n_local);
+    std::vector<DevTri> tris(c->T);
+    HIPC(hipMemcpy(h.data(), c->d_hits.p, (size_t)c->n_local * 16, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n_pixels; i++) { tuv[4 * i] = 0; tuv[4 * i + 1] = 0; tuv[4 * i + 2] = 0; tuv[4 * i + 3] = 0; ids[2 * i] = -2; ids[2 * i + 1] = -2; } // -2: not owned
+    for (uint32_t p = 0; p < c->n_local; p++) {
+        uint32_t tile = c->tile_list[p >> 10], q = p & 1023u, sub = q >> 6, l = q & 63u;
+        uint32_t x = (tile % c->tiles_x) * kTile + (sub & 3u) * 8u + (l & 7u), y = (tile / c->tiles_x) * kTile + (sub >> 2) * 8u + (l >> 3);
+        if (x >= c->W || y >= c->H) continue;
+        size_t i = (size_t)y * c->W + x;
+        uint32_t pos; std::memcpy(&pos, &h[p].w, 4);
+        tuv[4 * i] = h[p].x; tuv[4 * i + 1] = h[p].y; tuv[4 * i + 2] = h[p].z;
+        if (pos == kNoHit) { ids[2 * i] = -1; ids[2 * i + 1] = -1; }
+        else { uint32_t pr, tr; std::memcpy(&pr, &tris[pos].v[0].w, 4); std::memcpy(&tr, &tris[pos].v[1].w, 4); ids[2 * i] = (int32_t)pr; ids[2 * i + 1] = (int32_t)tr; }
+    }
+    return ART_OK;
+}
+
+int32_t art_read_shadow_bits(ArtContext *c, uint32_t *bits, size_t n_pixels) {
+    if (!c || !bits) return fail(ART_E_INVALID, "art_read_shadow_bits: null argument");
+    if (!(c->cfg.flags & ART_FLAG_KEEP_DEBUG)) return fail(ART_E_STATE, "art_read_shadow_bits: context created without ART_FLAG_KEEP_DEBUG");
+    if (!c->traced) return fail(ART_E_STATE, "art_read_shadow_bits: nothing traced yet");
+    if (n_pixels != (size_t)c->W * c->H) return fail(ART_E_INVALID, "art_read_shadow_bits: size mismatch");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> sb(c->n_local);
+    HIPC(hipMemcpy(sb.data(), c->d_shadow_bits.p, (size_t)c->n_local * 4, hipMemcpyDeviceToHost));
+    std::memset(bits, 0, n_pixels * 4);
+    for (uint32_t p = 0; p < c->n_local; p++) {
+        uint32_t tile = c->tile_list[p >> 10], q = p & 1023u, sub = q >> 6, l = q & 63u;
+        uint32_t x = (tile % c->tiles_x) * kTile + (sub & 3u) * 8u + (l & 7u), y = (tile / c->tiles_x) * kTile + (sub >> 2) * 8u + (l >> 3);
+        if (x >= c->W || y >= c->H) continue;
+        bits[(size_t)y * c->W + x] = sb[p];
+    }
+    return ART_OK;
+}
+
+int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *tuv, int32_t *ids) {
+    if (!c || (n && (!rays || !tuv || !ids))) return fail(ART_E_INVALID, "art_query_closest: null argument");
+    if (!c->built) return fail(ART_E_STATE, "art_query_closest: scene not built");
+    if (n == 0) return ART_OK;
+    int32_t r = use_device(c); if (r) return r;
+    float4 *d_r = nullptr, *d_h = nullptr;
+    HIPC(hipMalloc(&d_r, (size_t)n * 32));
+    hipError_t e = hipMalloc(&d_h, (size_t)n * 16);
+    if (e != hipSuccess) { (void)hipFree(d_r); return hipfail(e, "hipMalloc"); }
+    std::vector<float4> h(n);
+    std::vector<DevTri> tris(c->T);
+    e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { launch_query_closest(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);
+    (void)hipFree(d_r); (void)hipFree(d_h);
+    if (e != hipSuccess) return hipfail(e, "art_query_closest");
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t pos; std::memcpy(&pos, &h[i].w, 4);
+        tuv[4 * i] = h[i].x; tuv[4 * i + 1] = h[i].y; tuv[4 * i + 2] = h[i].z; tuv[4 * i + 3] = 0;
+        if (pos == kNoHit) { ids[2 * i] = -1; ids[2 * i + 1] = -1; }
+        else { uint32_t pr, tr; std::memcpy(&pr, &tris[pos].v[0].w, 4); std::memcpy(&tr, &tris[pos].v[1].w, 4); ids[2 * i] = (int32_t)pr; ids[2 * i + 1] = (int32_t)tr; }
+    }
+    return ART_OK;
+}
+
+int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit) {
+    if (!c || (n && (!rays || !hit))) return fail(ART_E_INVALID, "art_query_any: null argument");
+    if (!c->built) return fail(ART_E_STATE, "art_query_any: scene not built");
+    if (n == 0) return ART_OK;
+    int32_t r = use_device(c); if (r) return r;
+    float4 *d_r = nullptr; uint32_t *d_h = nullptr;
+    HIPC(hipMalloc(&d_r, (size_t)n * 32));
+    hipError_t e = hipMalloc(&d_h, (size_t)n * 4);
+    if (e != hipSuccess) { (void)hipFree(d_r); return hipfail(e, "hipMalloc"); }
+    std::vector<uint32_t> h(n);
+    e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { launch_query_any(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_r); (void)hipFree(d_h);
+    if (e != hipSuccess) return hipfail(e, "art_query_any");
+    for (uint32_t i = 0; i < n; i++) hit[i] = (uint8_t)h[i];
+    return ART_OK;
+}
+
+int32_t art_get_lbvh(ArtContext *c, uint32_t *leaf_gid, uint64_t *keys, int32_t *child, float *node_lo, float *node_hi, float *leaf_lo, float *leaf_hi) {
+    if (!c) return fail(ART_E_INVALID, "art_get_lbvh: null context");
+    if (!c->built) return fail(ART_E_STATE, "art_get_lbvh: scene not built");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    size_t T = c->T, NI = T > 1 ? T - 1 : 0;
+    if (leaf_gid) HIPC(hipMemcpy(leaf_gid, c->bvh.leaf_gid, T * 4, hipMemcpyDeviceToHost));
+    if (keys) HIPC(hipMemcpy(keys, c->bvh.keys, T * 8, hipMemcpyDeviceToHost));
+    if (child && NI) HIPC(hipMemcpy(child, c->bvh.child, NI * 8, hipMemcpyDeviceToHost));
+    if (node_lo && NI) HIPC(hipMemcpy(node_lo, c->bvh.node_lo, NI * 12, hipMemcpyDeviceToHost));
+    if (node_hi && NI) HIPC(hipMemcpy(node_hi, c->bvh.node_hi, NI * 12, hipMemcpyDeviceToHost));
+    if (leaf_lo) HIPC(hipMemcpy(leaf_lo, c->bvh.leaf_lo, T * 12, hipMemcpyDeviceToHost));
+    if (leaf_hi) HIPC(hipMemcpy(leaf_hi, c->bvh.leaf_hi, T * 12, hipMemcpyDeviceToHost));
+    return ART_OK;
+}
+
+} // extern "C"

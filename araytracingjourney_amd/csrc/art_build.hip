@@ -1,0 +1,250 @@
+// art_build.hip -- device LBVH builder over the world-space triangle soup (gfx950).
+//
+// Replaces the closed driver work behind VkBlasBuilder::build_blas_from_geometry (vk_blas_builder.rs:88-170,
+// vkCmdBuildAccelerationStructuresKHR, PREFER_FAST_TRACE) and VkTlasBuilder::recreate_tlas
+// (vk_tlas_builder.rs:38-233): instances are folded into the soup (one instance per model, renderer.rs:641-650).
+//
+// Pipeline: soup (index fetch + object->world) -> centroid bounds (ordered-int atomics) -> Morton keys ->
+// stable radix sort (rocPRIM) -> Karras 2012 radix tree -> bottom-up AABB refit (arrival counters) ->
+// 64-byte traversal nodes + 48-byte leaf-ordered triangles.
+#include "art_internal.h"
+#include <rocprim/rocprim.hpp>
+
+namespace art {
+
+#define HIPQ(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+__device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ inline float ord2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+__device__ inline float3 xform_point(const float *m, float x, float y, float z) {
+    return make_float3(((m[0] * x + m[1] * y) + m[2] * z) + m[3], ((m[4] * x + m[5] * y) + m[6] * z) + m[7],
+                       ((m[8] * x + m[9] * y) + m[10] * z) + m[11]);
+}
+
+// one thread per triangle: fetch indices + vertices, transform, write world triangle, its AABB, reduce centroid bounds
+__global__ __launch_bounds__(256) void k_soup(const DevPrim *__restrict__ prims, uint32_t n_prims, const uint32_t *__restrict__ first_tri,
+                                              uint32_t T, float *__restrict__ triw /*T*9*/, float *__restrict__ tlo, float *__restrict__ thi,
+                                              uint32_t *__restrict__ tri_prim, uint32_t *__restrict__ cbounds /*6 ordered ints*/) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    float cx = 0, cy = 0, cz = 0;
+    bool on = g < T;
+    if (on) {
+        uint32_t lo = 0, hi = n_prims; // last p with first_tri[p] <= g
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (first_tri[mid] <= g) lo = mid; else hi = mid; }
+        const DevPrim &P = prims[lo];
+        uint32_t t = g - P.first_tri;
+        uint32_t i0, i1, i2;
+        if (P.single_index_size == 2) { const uint16_t *ix = (const uint16_t *)P.indices + 3 * (size_t)t; i0 = ix[0]; i1 = ix[1]; i2 = ix[2]; }
+        else { const uint32_t *ix = (const uint32_t *)P.indices + 3 * (size_t)t; i0 = ix[0]; i1 = ix[1]; i2 = ix[2]; }
+        const float *a = P.vertices + (size_t)i0 * 12, *b = P.vertices + (size_t)i1 * 12, *c = P.vertices + (size_t)i2 * 12;
+        float3 w0 = xform_point(P.o2w, a[0], a[1], a[2]), w1 = xform_point(P.o2w, b[0], b[1], b[2]), w2 = xform_point(P.o2w, c[0], c[1], c[2]);
+        float *o = triw + (size_t)g * 9;
+        o[0] = w0.x; o[1] = w0.y; o[2] = w0.z; o[3] = w1.x; o[4] = w1.y; o[5] = w1.z; o[6] = w2.x; o[7] = w2.y; o[8] = w2.z;
+        float lx = fminf(fminf(w0.x, w1.x), w2.x), ly = fminf(fminf(w0.y, w1.y), w2.y), lz = fminf(fminf(w0.z, w1.z), w2.z);
+        float hx = fmaxf(fmaxf(w0.x, w1.x), w2.x), hy = fmaxf(fmaxf(w0.y, w1.y), w2.y), hz = fmaxf(fmaxf(w0.z, w1.z), w2.z);
+        tlo[3 * (size_t)g] = lx; tlo[3 * (size_t)g + 1] = ly; tlo[3 * (size_t)g + 2] = lz;
+        thi[3 * (size_t)g] = hx; thi[3 * (size_t)g + 1] = hy; thi[3 * (size_t)g + 2] = hz;
+        tri_prim[g] = lo;
+        cx = (lx + hx) * 0.5f; cy = (ly + hy) * 0.5f; cz = (lz + hz) * 0.5f;
+    }
+    // wave reduction of the ordered keys, then one atomic per wave
+    uint32_t kmin[3] = {on ? f2ord(cx) : 0xFFFFFFFFu, on ? f2ord(cy) : 0xFFFFFFFFu, on ? f2ord(cz) : 0xFFFFFFFFu};
+    uint32_t kmax[3] = {on ? f2ord(cx) : 0u, on ? f2ord(cy) : 0u, on ? f2ord(cz) : 0u};
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int k = 0; k < 3; k++) {
+            kmin[k] = min(kmin[k], (uint32_t)__shfl_xor((int)kmin[k], off));
+            kmax[k] = max(kmax[k], (uint32_t)__shfl_xor((int)kmax[k], off));
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; k++) { atomicMin(&cbounds[k], kmin[k]); atomicMax(&cbounds[3 + k], kmax[k]); }
+}
+
+__device__ inline uint32_t expand10(uint32_t v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ inline uint64_t expand21(uint64_t v) {
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull; v = (v | (v << 16)) & 0x1f0000ff0000ffull; v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull; v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton(uint32_t T, uint32_t bits, const float *__restrict__ tlo, const float *__restrict__ thi,
+                                                const uint32_t *__restrict__ cbounds, uint64_t *__restrict__ keys, uint32_t *__restrict__ gids) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= T) return;
+    float cmin[3], cmax[3];
+    for (int k = 0; k < 3; k++) { cmin[k] = ord2f(cbounds[k]); cmax[k] = ord2f(cbounds[3 + k]); }
+    float cells = bits == 30 ? 1024.0f : 2097152.0f;
+    float q[3];
+    for (int k = 0; k < 3; k++) {
+        float ext = cmax[k] - cmin[k];
+        float sc = ext > 0.0f ? cells / ext : 0.0f;
+        float c = (tlo[3 * (size_t)g + k] + thi[3 * (size_t)g + k]) * 0.5f;
+        q[k] = fminf(fmaxf((c - cmin[k]) * sc, 0.0f), cells - 1.0f);
+    }
+    uint64_t key;
+    if (bits == 30) key = ((uint64_t)expand10((uint32_t)q[0]) << 2) | ((uint64_t)expand10((uint32_t)q[1]) << 1) | (uint64_t)expand10((uint32_t)q[2]);
+    else key = (expand21((uint64_t)q[0]) << 2) | (expand21((uint64_t)q[1]) << 1) | expand21((uint64_t)q[2]);
+    keys[g] = key; gids[g] = g;
+}
+
+__device__ inline int delta_fn(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ gid, int T, int i, int j) {
+    if (j < 0 || j >= T) return -1;
+    uint64_t a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)(gid[i] ^ gid[j]));
+}
+
+// Karras 2012, one thread per internal node
+__global__ __launch_bounds__(256) void k_karras(int T, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ gid, int32_t *__restrict__ child,
+                                                int32_t *__restrict__ parent_int, int32_t *__restrict__ parent_leaf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T - 1) return;
+    if (i == 0) parent_int[0] = -1;
+    int d = delta_fn(keys, gid, T, i, i + 1) - delta_fn(keys, gid, T, i, i - 1) >= 0 ? 1 : -1;
+    int dmin = delta_fn(keys, gid, T, i, i - d);
+    int lmax = 2;
+    while (delta_fn(keys, gid, T, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta_fn(keys, gid, T, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta_fn(keys, gid, T, i, j);
+    int sp = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (delta_fn(keys, gid, T, i, i + (sp + t) * d) > dnode) sp += t;
+    } while (t > 1);
+    int gamma = i + sp * d + (d < 0 ? -1 : 0);
+    int lo = min(i, j), hi = max(i, j);
+    if (lo == gamma) { child[2 * i] = ~gamma; parent_leaf[gamma] = i; } else { child[2 * i] = gamma; parent_int[gamma] = i; }
+    if (hi == gamma + 1) { child[2 * i + 1] = ~(gamma + 1); parent_leaf[gamma + 1] = i; } else { child[2 * i + 1] = gamma + 1; parent_int[gamma + 1] = i; }
+}
+
+// leaf boxes + leaf-ordered triangle records
+__global__ __launch_bounds__(256) void k_leaves(uint32_t T, const uint32_t *__restrict__ leaf_gid, const float *__restrict__ triw, const float *__restrict__ tlo,
+                                                const float *__restrict__ thi, const uint32_t *__restrict__ tri_prim, const uint32_t *__restrict__ first_tri,
+                                                float *__restrict__ leaf_lo, float *__restrict__ leaf_hi, DevTri *__restrict__ tris) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= T) return;
+    uint32_t g = leaf_gid[p];
+    for (int k = 0; k < 3; k++) { leaf_lo[3 * (size_t)p + k] = tlo[3 * (size_t)g + k]; leaf_hi[3 * (size_t)p + k] = thi[3 * (size_t)g + k]; }
+    const float *w = triw + (size_t)g * 9;
+    uint32_t pr = tri_prim[g];
+    DevTri t;
+    t.v[0] = make_float4(w[0], w[1], w[2], __uint_as_float(pr));
+    t.v[1] = make_float4(w[3], w[4], w[5], __uint_as_float(g - first_tri[pr]));
+    t.v[2] = make_float4(w[6], w[7], w[8], __uint_as_float(g));
+    tris[p] = t;
+}
+
+// bottom-up refit: the second thread to arrive at a node owns it (its sibling's box is complete and visible)
+__global__ __launch_bounds__(256) void k_refit(uint32_t T, const int32_t *__restrict__ child, const int32_t *__restrict__ parent_int,
+                                               const int32_t *__restrict__ parent_leaf, const float *__restrict__ leaf_lo, const float *__restrict__ leaf_hi,
+                                               float *node_lo, float *node_hi, uint32_t *arrive) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= T) return;
+    int n = parent_leaf[p];
+    while (n >= 0) {
+        __threadfence();                       // release: this thread's boxes below n are written back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // keep the write-back ahead of the arrival (hipcc may drop the wait)
+        if (atomicAdd(&arrive[n], 1u) == 0u) return;
+        __threadfence();                       // acquire: see the sibling subtree's boxes
+        float lo[3], hi[3];
+        for (int c = 0; c < 2; c++) {
+            int ch = child[2 * n + c];
+            const float *cl = ch < 0 ? leaf_lo + 3 * (size_t)(~ch) : node_lo + 3 * (size_t)ch;
+            const float *chh = ch < 0 ? leaf_hi + 3 * (size_t)(~ch) : node_hi + 3 * (size_t)ch;
+            for (int k = 0; k < 3; k++) {
+                float l = __builtin_nontemporal_load(cl + k), h = __builtin_nontemporal_load(chh + k);
+                lo[k] = c == 0 ? l : fminf(lo[k], l);
+                hi[k] = c == 0 ? h : fmaxf(hi[k], h);
+            }
+        }
+        for (int k = 0; k < 3; k++) { node_lo[3 * (size_t)n + k] = lo[k]; node_hi[3 * (size_t)n + k] = hi[k]; }
+        n = parent_int[n];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_emit_nodes(uint32_t T, const int32_t *__restrict__ child, const float *__restrict__ node_lo, const float *__restrict__ node_hi,
+                                                    const float *__restrict__ leaf_lo, const float *__restrict__ leaf_hi, DevNode *__restrict__ nodes) {
+    uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T == 1) { // single triangle: a root whose second child can never be hit
+        if (n == 0) {
+            DevNode d;
+            d.q[0] = make_float4(leaf_lo[0], leaf_lo[1], leaf_lo[2], leaf_hi[0]);
+            d.q[1] = make_float4(leaf_hi[1], leaf_hi[2], 3.0e38f, 3.0e38f);
+            d.q[2] = make_float4(3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            d.q[3] = make_float4(__int_as_float(~0), __int_as_float(~0), 0.f, 0.f);
+            nodes[0] = d;
+        }
+        return;
+    }
+    if (n >= T - 1) return;
+    int c0 = child[2 * n], c1 = child[2 * n + 1];
+    const float *l0 = c0 < 0 ? leaf_lo + 3 * (size_t)(~c0) : node_lo + 3 * (size_t)c0, *h0 = c0 < 0 ? leaf_hi + 3 * (size_t)(~c0) : node_hi + 3 * (size_t)c0;
+    const float *l1 = c1 < 0 ? leaf_lo + 3 * (size_t)(~c1) : node_lo + 3 * (size_t)c1, *h1 = c1 < 0 ? leaf_hi + 3 * (size_t)(~c1) : node_hi + 3 * (size_t)c1;
+    DevNode d;
+    d.q[0] = make_float4(l0[0], l0[1], l0[2], h0[0]);
+    d.q[1] = make_float4(h0[1], h0[2], l1[0], l1[1]);
+    d.q[2] = make_float4(l1[2], h1[0], h1[1], h1[2]);
+    d.q[3] = make_float4(__int_as_float(c0), __int_as_float(c1), 0.f, 0.f);
+    nodes[n] = d;
+}
+
+void lbvh_free(Lbvh &l) {
+    hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
+    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim);
+    l = Lbvh{};
+}
+
+hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
+    const uint32_t T = in.T;
+    const uint32_t NI = T > 1 ? T - 1 : 1;
+    out = Lbvh{};
+    float *triw = nullptr, *tlo = nullptr, *thi = nullptr;
+    uint32_t *cb = nullptr, *gid_in = nullptr, *arrive = nullptr;
+    uint64_t *keys_in = nullptr;
+    int32_t *parent_int = nullptr, *parent_leaf = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipError_t err = hipSuccess;
+    auto body = [&]() -> hipError_t {
+        HIPQ(hipMalloc(&triw, (size_t)T * 36)); HIPQ(hipMalloc(&tlo, (size_t)T * 12)); HIPQ(hipMalloc(&thi, (size_t)T * 12));
+        HIPQ(hipMalloc(&cb, 24)); HIPQ(hipMalloc(&gid_in, (size_t)T * 4)); HIPQ(hipMalloc(&keys_in, (size_t)T * 8));
+        HIPQ(hipMalloc(&arrive, (size_t)NI * 4)); HIPQ(hipMalloc(&parent_int, (size_t)NI * 4)); HIPQ(hipMalloc(&parent_leaf, (size_t)T * 4));
+        HIPQ(hipMalloc(&out.leaf_gid, (size_t)T * 4)); HIPQ(hipMalloc(&out.keys, (size_t)T * 8)); HIPQ(hipMalloc(&out.child, (size_t)NI * 8));
+        HIPQ(hipMalloc(&out.node_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&out.node_hi, (size_t)NI * 12));
+        HIPQ(hipMalloc(&out.leaf_lo, (size_t)T * 12)); HIPQ(hipMalloc(&out.leaf_hi, (size_t)T * 12));
+        HIPQ(hipMalloc(&out.tris, (size_t)T * sizeof(DevTri))); HIPQ(hipMalloc(&out.nodes, (size_t)NI * sizeof(DevNode)));
+        HIPQ(hipMalloc(&out.tri_prim, (size_t)T * 4));
+        const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+        HIPQ(hipMemcpyAsync(cb, init, 24, hipMemcpyHostToDevice, s));
+        HIPQ(hipMemsetAsync(arrive, 0, (size_t)NI * 4, s));
+        const uint32_t B = 256, GT = (T + B - 1) / B;
+        k_soup<<<GT, B, 0, s>>>(in.prims, in.n_prims, in.prim_first_tri, T, triw, tlo, thi, out.tri_prim, cb);
+        k_morton<<<GT, B, 0, s>>>(T, in.morton_bits, tlo, thi, cb, keys_in, gid_in);
+        HIPQ(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
+        HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        HIPQ(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
+        k_leaves<<<GT, B, 0, s>>>(T, out.leaf_gid, triw, tlo, thi, out.tri_prim, in.prim_first_tri, out.leaf_lo, out.leaf_hi, out.tris);
+        if (T > 1) {
+            k_karras<<<(T - 1 + B - 1) / B, B, 0, s>>>((int)T, out.keys, out.leaf_gid, out.child, parent_int, parent_leaf);
+            k_refit<<<GT, B, 0, s>>>(T, out.child, parent_int, parent_leaf, out.leaf_lo, out.leaf_hi, out.node_lo, out.node_hi, arrive);
+        }
+        k_emit_nodes<<<(NI + B - 1) / B, B, 0, s>>>(T, out.child, out.node_lo, out.node_hi, out.leaf_lo, out.leaf_hi, out.nodes);
+        HIPQ(hipGetLastError());
+        HIPQ(hipStreamSynchronize(s));
+        return hipSuccess;
+    };
+    err = body();
+    hipFree(triw); hipFree(tlo); hipFree(thi); hipFree(cb); hipFree(gid_in); hipFree(keys_in); hipFree(arrive); hipFree(parent_int); hipFree(parent_leaf); hipFree(tmp);
+    if (err != hipSuccess) lbvh_free(out);
+    return err;
+}
+
+} // namespace art

@@ -1,0 +1,475 @@
+// art_trace.hip -- per-frame wavefront pipeline (gfx950): primary rays + closest hit, hit reconstruction + PBR
+// direct light + shadow-ray emission, shadow (any-hit) rays, accumulation.  Restates
+// /root/reference/src/vk_renderer/shaders/rt_lightning_shadows/raytrace.rgen.glsl:77-200 (+ light.glsl, brdfs.glsl)
+// split at its two traceRayEXT calls; the traversal replaces the driver/hardware behind traceRayEXT.
+//
+// Built with -ffp-contract=off: every fused multiply-add below is an explicit fmaf, so the geometry stages
+// (ray generation, slab test, Moller-Trumbore, hit reconstruction up to the shadow ray) follow one fixed
+// floating-point expression order.
+//
+// Geometry semantics (order- and structure-independent):
+//   accept(tri, ray) := slab(AABB(tri), ray) passes AND Moller-Trumbore hits with tmin < t < tmax
+//   t_eff := max(t_MT, t_entry(AABB(tri)));  closest := argmin (t_eff, gid);  any := exists accept
+#include "art_internal.h"
+
+namespace art {
+
+// ------------------------------------------------------------------------------------------------ vector helpers
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+    return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ float len3(V3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ V3 nrm3(V3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return a * inv; }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+__device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+// column-major mat4 times (x,y,z,w), rows 0..2: ((c0*x + c1*y) + c2*z) + c3*w
+__device__ __forceinline__ V3 mat4_mul(const float *m, float x, float y, float z, float w) {
+    return mk(((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w, ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w,
+              ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w);
+}
+__device__ __forceinline__ V3 xform_point(const float *m, V3 p) {
+    return mk(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+              ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]);
+}
+__device__ __forceinline__ V3 xform_vec(const float *m, V3 p) {
+    return mk((m[0] * p.x + m[1] * p.y) + m[2] * p.z, (m[4] * p.x + m[5] * p.y) + m[6] * p.z, (m[8] * p.x + m[9] * p.y) + m[10] * p.z);
+}
+
+// ------------------------------------------------------------------------------------------------ traversal
+struct Ray {
+    V3 o, d;
+    float tmin, tmax;
+    V3 inv, ood;
+};
+__device__ __forceinline__ float safe_dir(float d) { return fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d; }
+__device__ __forceinline__ void ray_init(Ray &r, V3 o, V3 d, float tmin, float tmax) {
+    r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax;
+    r.inv = mk(1.0f / safe_dir(d.x), 1.0f / safe_dir(d.y), 1.0f / safe_dir(d.z));
+    r.ood = mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+}
+// monotone slab test against [tmin, tlimit]; tn = un-clamped entry distance
+__device__ __forceinline__ bool slab(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float tlimit, float &tn) {
+    float t0x = fmaf(lx, r.inv.x, -r.ood.x), t1x = fmaf(hx, r.inv.x, -r.ood.x);
+    float t0y = fmaf(ly, r.inv.y, -r.ood.y), t1y = fmaf(hy, r.inv.y, -r.ood.y);
+    float t0z = fmaf(lz, r.inv.z, -r.ood.z), t1z = fmaf(hz, r.inv.z, -r.ood.z);
+    tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    return fmaxf(tn, r.tmin) <= fminf(tf, tlimit);
+}
+#define ART_BARY_EPS 1.0e-6f
+// Moller-Trumbore, two-sided (instance flags 0, vk_model.rs:374), edges fattened by ART_BARY_EPS, tmin < t < tmax
+__device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v2, float &t, float &u, float &v) {
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    V3 p = cross3(r.d, e2);
+    float det = dot3(e1, p);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    V3 tv = r.o - v0;
+    float uu = dot3(tv, p) * inv;
+    if (!(uu >= -ART_BARY_EPS && uu <= 1.0f + ART_BARY_EPS)) return false;
+    V3 q = cross3(tv, e1);
+    float vv = dot3(r.d, q) * inv;
+    if (!(vv >= -ART_BARY_EPS && uu + vv <= 1.0f + ART_BARY_EPS)) return false;
+    float tt = dot3(e2, q) * inv;
+    if (!(tt > r.tmin && tt < r.tmax)) return false;
+    t = tt; u = uu; v = vv;
+    return true;
+}
+
+constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], conflict-free); deeper entries spill to scratch
+constexpr int kOvfStack = 80;
+constexpr int kBlock = 256;
+
+struct Hit { float t, u, v; uint32_t pos; }; // pos = leaf-order triangle slot, kNoHit = none; gid compared for ties
+
+// Binary-LBVH traversal.  ANY: stop at the first accepted triangle.
+template <bool ANY>
+__device__ __forceinline__ void traverse(const DevNode *__restrict__ nodes, const DevTri *__restrict__ tris, const Ray &r, int *lds /* &stack[0][lane] */,
+                                         Hit &best, uint32_t &best_gid) {
+    int ovf[kOvfStack];
+    int sp = 0;
+    int node = 0;
+    float tbest = r.tmax;
+    best.t = r.tmax; best.u = 0.f; best.v = 0.f; best.pos = kNoHit; best_gid = kNoHit;
+    for (;;) {
+        const float4 *nq = reinterpret_cast<const float4 *>(nodes + node);
+        float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+        float te0, te1;
+        bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0);
+        bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            bool h = k == 0 ? h0 : h1;
+            int c = k == 0 ? c0 : c1;
+            float te = k == 0 ? te0 : te1;
+            if (h && c < 0 && fmaxf(te, r.tmin) <= tbest) {
+                uint32_t pos = (uint32_t)~c;
+                const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
+                float4 a = tq[0], b = tq[1], cc = tq[2];
+                float t, u, v;
+                if (moller_trumbore(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t, u, v)) {
+                    if (ANY) { best.pos = pos; best.t = t; return; }
+                    float teff = fmaxf(t, te);
+                    uint32_t gid = __float_as_uint(cc.w);
+                    if (teff < tbest || (teff == tbest && gid < best_gid)) {
+                        tbest = teff; best.t = teff; best.u = u; best.v = v; best.pos = pos; best_gid = gid;
+                    }
+                }
+            }
+        }
+        bool g0 = h0 && c0 >= 0, g1 = h1 && c1 >= 0;
+        if (!ANY) { // the leaf tests above may have shortened the ray
+            g0 = g0 && fmaxf(te0, r.tmin) <= tbest;
+            g1 = g1 && fmaxf(te1, r.tmin) <= tbest;
+        }
+        if (g0 && g1) {
+            bool first0 = te0 <= te1;
+            int far = first0 ? c1 : c0;
+            node = first0 ? c0 : c1;
+            if (sp < kLdsStack) lds[sp * kBlock] = far; else ovf[sp - kLdsStack] = far;
+            sp++;
+        } else if (g0) node = c0;
+        else if (g1) node = c1;
+        else {
+            if (sp == 0) return;
+            sp--;
+            node = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
+        }
+    }
+}
+
+// local pixel id -> frame coordinates.  p = tile*1024 + sub*64 + lane; a wave covers an 8x8 pixel block.
+__device__ __forceinline__ bool local_to_xy(uint32_t p, const uint32_t *__restrict__ tile_list, uint32_t tiles_x, uint32_t W, uint32_t H, uint32_t &x, uint32_t &y) {
+    uint32_t tile = tile_list[p >> 10];
+    uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
+    x = (tile % tiles_x) * kTile + (sub & 3u) * 8u + (l & 7u);
+    y = (tile / tiles_x) * kTile + (sub >> 2) * 8u + (l >> 3);
+    return x < W && y < H;
+}
+
+// XCD-aware block remap: blocks are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of work
+// (neighbouring screen tiles traverse the same BVH region and share that XCD's L2).  Speed only.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+    uint32_t per = nb >> 3;
+    if (per == 0 || b >= per * 8u) return b;
+    return (b & 7u) * per + (b >> 3);
+}
+
+// raytrace.rgen.glsl:78-101 + rchit/rmiss: primary ray, closest hit
+__global__ __launch_bounds__(kBlock) void k_primary(FrameArgs a) {
+    __shared__ int stack[kLdsStack * kBlock];
+    uint32_t p = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    if (p >= a.n_local) return;
+    uint32_t x, y;
+    float4 out = make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+    if (local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y)) {
+        float px = (float)x + 0.5f, py = (float)y + 0.5f;
+        float ux = px / (float)a.W, uy = py / (float)a.H;
+        float dx = ux * 2.0f - 1.0f, dy = uy * 2.0f - 1.0f;
+        V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
+        V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
+        V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
+        Ray r; ray_init(r, org, dir, 0.001f, 10000.0f);
+        Hit h; uint32_t gid;
+        traverse<false>(a.nodes, a.tris, r, &stack[threadIdx.x], h, gid);
+        if (h.pos != kNoHit) out = make_float4(h.t, h.u, h.v, __uint_as_float(h.pos));
+    }
+    a.hits[p] = out;
+}
+
+// ------------------------------------------------------------------------------------------------ lights (light.glsl)
+__device__ V3 compute_barycentric(V3 a, V3 b, V3 c, V3 p) { // light.glsl:50-68
+    V3 v0 = b - a, v1 = c - a, v2 = p - a;
+    float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+    float denom = d00 * d11 - d01 * d01;
+    V3 r;
+    r.x = (d11 * d20 - d01 * d21) / denom;
+    r.y = (d00 * d21 - d01 * d20) / denom;
+    r.z = 1.0f - r.x - r.y;
+    return r;
+}
+__device__ V3 closest_point_to_segment(V3 p0, V3 p1, V3 p) { // light.glsl:70-75
+    V3 v01 = p1 - p0;
+    float t = dot3(p - p0, v01) / dot3(v01, v01);
+    t = clampf(t, 0.0f, 1.0f);
+    return p0 + v01 * t;
+}
+__device__ V3 closest_point_to_triangle(V3 p0, V3 p1, V3 p2, V3 pt) { // light.glsl:77-91
+    V3 b = compute_barycentric(p0, p1, p2, pt);
+    if (b.x < 0.0f) return closest_point_to_segment(p2, p0, pt);
+    else if (b.z < 0.0f) return closest_point_to_segment(p1, p2, pt);
+    return pt;
+}
+__device__ V3 get_unnormalized_L_vec(const ArtLight &l, V3 pos) { // light.glsl:93-124
+    if (l.type == 0u || l.type == 1u) return ld3(l.pos) - pos;
+    if (l.type == 2u) return neg(ld3(l.dir)) * 10.0f;
+    if (l.type == 3u) {
+        V3 ldir = ld3(l.dir), lp = ld3(l.pos), p2 = ld3(l.area_pos2), p3 = ld3(l.area_pos3);
+        float distance = dot3(ldir, p2) - dot3(ldir, pos);
+        V3 cp = pos + ldir * distance;
+        V3 b = compute_barycentric(lp, p2, p3, cp);
+        V3 c;
+        if (b.x < 0.0f) { V3 p4 = (lp - p2) + p3; c = closest_point_to_triangle(lp, p3, p4, cp); }
+        else if (b.y < 0.0f) c = closest_point_to_segment(lp, p2, cp);
+        else if (b.z < 0.0f) c = closest_point_to_segment(p2, p3, cp);
+        else c = cp;
+        return c - pos;
+    }
+    return mk(1.0f, 1.0f, 1.0f);
+}
+__device__ V3 get_light_radiance(const ArtLight &l, V3 pos, V3 L) { // light.glsl:34-48
+    V3 rad = ld3(l.color);
+    if (l.type == 1u || l.type == 3u) {
+        float theta_s = acosf(clampf(dot3(ld3(l.dir), neg(L)), -1.0f, 1.0f));
+        float t = clampf((theta_s - l.umbra_angle) / (l.penumbra_angle - l.umbra_angle), 0.0f, 1.0f);
+        rad = rad * powf(t, 2.0f);
+    }
+    if (l.falloff_distance > 0.0f) {
+        float dist = len3(ld3(l.pos) - pos);
+        rad = rad * powf(fmaxf(1.0f - powf(dist / l.falloff_distance, 2.0f), 0.0f), 2.0f);
+    }
+    return rad;
+}
+
+// ------------------------------------------------------------------------------------------------ BRDFs (brdfs.glsl)
+#define ART_INV_PI (1.0f / 3.14159265359f)
+__device__ __forceinline__ float D_GGX(float a_, float NdotH) { // brdfs.glsl:6-14
+    float om = 1.0f - NdotH * NdotH;
+    float a = NdotH * a_;
+    float k = a_ / (om + a * a);
+    return k * k * ART_INV_PI;
+}
+__device__ __forceinline__ float V_SmithGGXCorrelated_fast(float a_, float NdotV, float NdotL) { // brdfs.glsl:25-29
+    return 0.5f / mixf(2.0f * NdotL * NdotV, NdotL + NdotV, a_);
+}
+__device__ __forceinline__ float pow5(float x) { return powf(x, 5.0f); }
+__device__ __forceinline__ float F_Schlick1(float F0, float F90, float x) { return F0 + (F90 - F0) * pow5(1.0f - x); } // brdfs.glsl:44-49
+__device__ float Burley_diffuse_local_sss(float a_, float NdotV, float nc_NdotV, float nc_NdotL, float LdotH, float ratio) { // brdfs.glsl:89-99
+    float F_SS90 = a_ * LdotH * LdotH;
+    float F_SS = F_Schlick1(1.0f, F_SS90, nc_NdotL) * F_Schlick1(1.0f, F_SS90, nc_NdotV);
+    float f_ss = (1.0f / (nc_NdotV * nc_NdotL) - 0.5f) * F_SS + 0.5f;
+    float local_sss = 1.25f * ratio * f_ss;
+    float f90 = 0.5f + 2.0f * F_SS90;
+    float diffuse = (1.0f - ratio) * F_Schlick1(1.0f, f90, nc_NdotL) * F_Schlick1(1.0f, f90, nc_NdotV);
+    return NdotV * (diffuse + local_sss) * ART_INV_PI;
+}
+
+// ------------------------------------------------------------------------------------------------ textures
+// sampler2DArray, linear / REPEAT, LOD 0 (no derivatives in a raygen stage): vk_rt_descriptor_set.rs:42-56
+__device__ __forceinline__ int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+__device__ float4 sample_tex(const uint32_t *__restrict__ pool, const DevPrim &P, int layer, float u, float v) {
+    int tw = (int)P.tw, th = (int)P.th;
+    float x = u * (float)tw - 0.5f, y = v * (float)th - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = wrapi((int)x0f, tw), y0 = wrapi((int)y0f, th);
+    int x1 = wrapi(x0 + 1, tw), y1 = wrapi(y0 + 1, th);
+    const uint32_t *base = pool + P.texture_offset + (size_t)layer * tw * th;
+    uint32_t t00 = base[(size_t)y0 * tw + x0], t10 = base[(size_t)y0 * tw + x1], t01 = base[(size_t)y1 * tw + x0], t11 = base[(size_t)y1 * tw + x1];
+    const float k = 1.0f / 255.0f;
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float A = (float)((t00 >> (8 * c)) & 255u) * k, B = (float)((t10 >> (8 * c)) & 255u) * k;
+        float Cc = (float)((t01 >> (8 * c)) & 255u) * k, D = (float)((t11 >> (8 * c)) & 255u) * k;
+        float top = A * (1.0f - fx) + B * fx, bot = Cc * (1.0f - fx) + D * fx;
+        o[c] = top * (1.0f - fy) + bot * fy;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// raytrace.rgen.glsl:103-199 without the shadow traceRayEXT: emits one shadow ray per (pixel, light) that needs it
+__global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.n_local) return;
+    uint32_t x, y;
+    if (!local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y)) return;
+    size_t pix = (size_t)y * a.W + x;
+    float4 h = a.hits[p];
+    uint32_t pos = __float_as_uint(h.w);
+    float out_depth = 10000.0f;
+    V3 out_normal = mk(0.5f, 0.5f, 0.5f);
+    uint32_t sbits = 0;
+    if (pos == kNoHit) {
+        for (uint32_t i = 0; i < a.n_lights; i++) a.contrib[(size_t)i * a.n_local + p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
+        uint32_t pi = __float_as_uint(tq[0].w), tri = __float_as_uint(tq[1].w);
+        const DevPrim &P = a.prims[pi];
+        uint32_t i0, i1, i2; // get_indices, raytrace.rgen.glsl:55-66
+        if (P.single_index_size == 2) { const uint16_t *ix = (const uint16_t *)P.indices + 3 * (size_t)tri; i0 = ix[0]; i1 = ix[1]; i2 = ix[2]; }
+        else { const uint32_t *ix = (const uint32_t *)P.indices + 3 * (size_t)tri; i0 = ix[0]; i1 = ix[1]; i2 = ix[2]; }
+        const float *a0 = P.vertices + (size_t)i0 * 12, *a1 = P.vertices + (size_t)i1 * 12, *a2 = P.vertices + (size_t)i2 * 12;
+        float bx = 1.0f - h.y - h.z, by = h.y, bz = h.z;
+        V3 posv = (ld3(a0) * bx + ld3(a1) * by) + ld3(a2) * bz;
+        V3 world_pos = xform_point(P.o2w, posv);
+        float tu = (a0[3] * bx + a1[3] * by) + a2[3] * bz, tv = (a0[4] * bx + a1[4] * by) + a2[4] * bz;
+        V3 nrm = nrm3((ld3(a0 + 5) * bx + ld3(a1 + 5) * by) + ld3(a2 + 5) * bz);
+        const float *Wm = P.w2o;
+        V3 world_normal = nrm3(mk(dot3(nrm, mk(Wm[0], Wm[4], Wm[8])), dot3(nrm, mk(Wm[1], Wm[5], Wm[9])), dot3(nrm, mk(Wm[2], Wm[6], Wm[10]))));
+        V3 tan = nrm3((ld3(a0 + 8) * bx + ld3(a1 + 8) * by) + ld3(a2 + 8) * bz);
+        V3 world_tangent = nrm3(xform_vec(P.o2w, tan));
+        world_tangent = nrm3(world_tangent - world_normal * dot3(world_tangent, world_normal));
+        V3 world_binormal = cross3(world_normal, world_tangent) * a0[11];
+        float4 tx = sample_tex(a.tex_pool, P, 2, tu, tv);
+        V3 N = nrm3(mk(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f));
+        N = nrm3((world_tangent * N.x + world_binormal * N.y) + world_normal * N.z);
+        tx = sample_tex(a.tex_pool, P, 0, tu, tv);
+        V3 albedo = mk(powf(tx.x, 2.2f), powf(tx.y, 2.2f), powf(tx.z, 2.2f));
+        tx = sample_tex(a.tex_pool, P, 1, tu, tv);
+        float roughness = tx.y, metallic = tx.z;
+        V3 Vv = nrm3(ld3(a.cam.camera_pos) - world_pos);
+        V3 F0 = mk(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
+        float alpha = roughness * roughness;
+        float nc_NdotV = dot3(N, Vv);
+        float NdotV = clampf(nc_NdotV, 1e-5f, 1.0f);
+        for (uint32_t i = 0; i < a.n_lights; i++) {
+            const ArtLight &l = a.lights[i];
+            V3 nn_L = get_unnormalized_L_vec(l, world_pos);
+            V3 L = nrm3(nn_L);
+            V3 Hh = nrm3(Vv + L);
+            float nc_NdotL = dot3(N, L);
+            float NdotL = clampf(nc_NdotL, 0.0f, 1.0f);
+            float NdotH = clampf(dot3(N, Hh), 0.0f, 1.0f);
+            float LdotH = clampf(dot3(L, Hh), 0.0f, 1.0f);
+            float sch = pow5(1.0f - LdotH);
+            V3 Ks = mk(F0.x + (1.0f - F0.x) * sch, F0.y + (1.0f - F0.y) * sch, F0.z + (1.0f - F0.z) * sch);
+            V3 Kd = albedo * (1.0f - metallic);
+            float DG = D_GGX(alpha, NdotH) * V_SmithGGXCorrelated_fast(alpha, NdotV, NdotL);
+            V3 rho_s = Ks * DG;
+            V3 rho_d = Kd * Burley_diffuse_local_sss(alpha, NdotV, nc_NdotV, nc_NdotL, LdotH, 0.4f);
+            V3 rad = get_light_radiance(l, world_pos, L);
+            V3 c = (rho_s + rho_d) * rad;
+            size_t slot = (size_t)i * a.n_local + p;
+            a.contrib[slot] = make_float4(c.x, c.y, c.z, NdotL);
+            if (l.casts_shadows && nc_NdotL > 0.0f) { // raytrace.rgen.glsl:165
+                uint32_t q = atomicAdd(&a.counters[0], 1u);
+                a.shadow_rays[2 * (size_t)q] = make_float4(world_pos.x, world_pos.y, world_pos.z, len3(nn_L));
+                a.shadow_rays[2 * (size_t)q + 1] = make_float4(L.x, L.y, L.z, __uint_as_float((uint32_t)slot));
+                if (i < 16) sbits |= 1u << (16 + i);
+            }
+        }
+        V3 vp = mat4_mul(a.cam.view, world_pos.x, world_pos.y, world_pos.z, 1.0f);
+        out_depth = -vp.z;
+        const float *VI = a.cam.view_inv;
+        V3 on = mk((VI[0] * N.x + VI[1] * N.y) + VI[2] * N.z, (VI[4] * N.x + VI[5] * N.y) + VI[6] * N.z, (VI[8] * N.x + VI[9] * N.y) + VI[10] * N.z);
+        on.y = -on.y; on.z = -on.z;
+        on = nrm3(on);
+        out_normal = mk(on.x * 0.5f + 0.5f, on.y * 0.5f + 0.5f, on.z * 0.5f + 0.5f);
+        atomicAdd(&a.counters[1], 1u);
+    }
+    a.depth[pix] = out_depth;
+    a.normal[pix] = make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f);
+    if (a.shadow_bits) a.shadow_bits[p] = sbits;
+}
+
+// shadow traceRayEXT (raytrace.rgen.glsl:167-181): TerminateOnFirstHit | Opaque | SkipClosestHit, tmin 0.01;
+// a shadowed light keeps 0.05 of its contribution
+__global__ __launch_bounds__(kBlock) void k_shadow(FrameArgs a) {
+    __shared__ int stack[kLdsStack * kBlock];
+    uint32_t n = a.counters[0];
+    uint32_t q = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    if (q >= n) return;
+    float4 r0 = a.shadow_rays[2 * (size_t)q], r1 = a.shadow_rays[2 * (size_t)q + 1];
+    Ray r; ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), 0.01f, r0.w);
+    Hit h; uint32_t gid;
+    traverse<true>(a.nodes, a.tris, r, &stack[threadIdx.x], h, gid);
+    if (h.pos != kNoHit) {
+        uint32_t slot = __float_as_uint(r1.w);
+        float4 c = a.contrib[slot];
+        a.contrib[slot] = make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w);
+        if (a.shadow_bits) { uint32_t i = slot / a.n_local; if (i < 16) atomicOr(&a.shadow_bits[slot - i * a.n_local], 1u << i); }
+    }
+}
+
+// rho += (rho_s + rho_d) * radiance * shadow_attenuation * NdotL (raytrace.rgen.glsl:185), lights in order
+__global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.n_local) return;
+    uint32_t x, y;
+    bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (in)
+        for (uint32_t i = 0; i < a.n_lights; i++) {
+            float4 c = a.contrib[(size_t)i * a.n_local + p];
+            rx += c.x * c.w; ry += c.y * c.w; rz += c.z * c.w;
+        }
+    float4 o = make_float4(rx, ry, rz, 1.0f);
+    if (in) a.color[(size_t)y * a.W + x] = o;
+    if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
+        uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
+        uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
+        a.color_tiles[(size_t)(p >> 10) * kTilePixels + ly * kTile + lx] = o;
+    }
+}
+
+// root side of the gather: shard s's j-th tile sits at gathered[(s*padded + j) * 1024]
+__global__ __launch_bounds__(kBlock) void k_untile(const float4 *__restrict__ gathered, uint32_t shard_count, uint32_t padded, uint32_t W, uint32_t H, float4 *__restrict__ frame) {
+    uint32_t tiles_x = (W + kTile - 1) / kTile;
+    uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
+    if (x >= W || y >= H) return;
+    uint32_t tx = x / kTile, ty = y / kTile;
+    uint32_t s = tile_owner(tx, ty, shard_count);
+    // index of (tx,ty) among shard s's tiles in row-major tile order
+    uint32_t j = 0;
+    for (uint32_t yy = 0; yy <= ty; yy++) {
+        uint32_t xe = yy == ty ? tx : tiles_x;
+        // tiles with (xx + 5*yy) % count == s, xx in [0, xe)
+        uint32_t first = (s + shard_count - (5u * yy) % shard_count) % shard_count;
+        if (xe > first) j += (xe - first + shard_count - 1) / shard_count;
+    }
+    frame[(size_t)y * W + x] = gathered[((size_t)s * padded + j) * kTilePixels + (y % kTile) * kTile + (x % kTile)];
+}
+
+__global__ __launch_bounds__(kBlock) void k_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits) {
+    __shared__ int stack[kLdsStack * kBlock];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
+    Ray r; ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, r1.w);
+    Hit h; uint32_t gid;
+    traverse<false>(nodes, tris, r, &stack[threadIdx.x], h, gid);
+    hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.pos));
+}
+__global__ __launch_bounds__(kBlock) void k_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit) {
+    __shared__ int stack[kLdsStack * kBlock];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
+    Ray r; ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, r1.w);
+    Hit h; uint32_t gid;
+    traverse<true>(nodes, tris, r, &stack[threadIdx.x], h, gid);
+    hit[i] = h.pos != kNoHit ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+void launch_primary(const FrameArgs &a, hipStream_t s) { k_primary<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
+void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
+void launch_shadow(const FrameArgs &a, hipStream_t s) {
+    if (a.n_lights == 0) return;
+    k_shadow<<<blocks_for(a.n_local * a.n_lights), kBlock, 0, s>>>(a);
+}
+void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
+void launch_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits, hipStream_t s) {
+    if (n) k_query_closest<<<blocks_for(n), kBlock, 0, s>>>(nodes, tris, rays, n, hits);
+}
+void launch_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit, hipStream_t s) {
+    if (n) k_query_any<<<blocks_for(n), kBlock, 0, s>>>(nodes, tris, rays, n, hit);
+}
+void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
+    dim3 g((W + 31) / 32, (H + 7) / 8);
+    k_untile<<<g, kBlock, 0, s>>>(gathered, shard_count ? shard_count : 1, padded_tiles, W, H, frame);
+}
+
+} // namespace art

@@ -1,0 +1,351 @@
+"""Host-side mirror of the reference's renderer API over the libart C ABI.
+
+Names follow /root/reference/src/vk_renderer: `Renderer` ~ `VulkanTempleRayTracedRenderer` (renderer.rs:121-137:
+new / add_model / prepare_first_frame / render_frame / camera_mut / lights_mut), `Camera` ~ `VkCamera`
+(vk_camera.rs:128-193), `Lights`, `PointLight`, `SpotLight`, `DirectionalLight`, `AreaLight` ~ lights.rs.
+All arithmetic (matrices, light records, tracing) happens inside libart; this module only marshals.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArtCamera, ArtConfig, ArtLight, ArtStats, check
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ------------------------------------------------------------------------------------------------ lights (lights.rs)
+class PointLight:
+    def __init__(self, pos, color, falloff_distance, casts_shadows):  # lights.rs:103
+        self.pos, self.color, self.falloff_distance, self.casts_shadows = tuple(pos), tuple(color), float(falloff_distance), bool(casts_shadows)
+
+    def get_light_shader_data(self) -> ArtLight:  # lights.rs:144-159
+        o = ArtLight()
+        check(_lib.load().art_light_point(_f3(self.pos), _f3(self.color), self.falloff_distance, int(self.casts_shadows), C.byref(o)))
+        return o
+
+
+class SpotLight:
+    def __init__(self, pos, dir, color, falloff_distance, penumbra_umbra_angles, casts_shadows):  # lights.rs:171
+        self.pos, self.dir, self.color = tuple(pos), tuple(dir), tuple(color)
+        self.falloff_distance, self.penumbra_umbra_angles, self.casts_shadows = float(falloff_distance), tuple(penumbra_umbra_angles), bool(casts_shadows)
+
+    def get_light_shader_data(self) -> ArtLight:  # lights.rs:228-243
+        o = ArtLight()
+        check(_lib.load().art_light_spot(_f3(self.pos), _f3(self.dir), _f3(self.color), self.falloff_distance, self.penumbra_umbra_angles[0],
+                                         self.penumbra_umbra_angles[1], int(self.casts_shadows), C.byref(o)))
+        return o
+
+
+class DirectionalLight:
+    def __init__(self, dir, color, casts_shadows):  # lights.rs:252
+        self.dir, self.color, self.casts_shadows = tuple(dir), tuple(color), bool(casts_shadows)
+
+    def get_light_shader_data(self) -> ArtLight:  # lights.rs:281-296
+        o = ArtLight()
+        check(_lib.load().art_light_directional(_f3(self.dir), _f3(self.color), int(self.casts_shadows), C.byref(o)))
+        return o
+
+
+class AreaLight:
+    def __init__(self, pos, pos2, pos3, invert_normal, color, falloff_distance, penumbra_umbra_angles, casts_shadows):  # lights.rs:310
+        self.pos, self.pos2, self.pos3, self.invert_normal, self.color = tuple(pos), tuple(pos2), tuple(pos3), bool(invert_normal), tuple(color)
+        self.falloff_distance, self.penumbra_umbra_angles, self.casts_shadows = float(falloff_distance), tuple(penumbra_umbra_angles), bool(casts_shadows)
+
+    def get_light_shader_data(self) -> ArtLight:  # lights.rs:383-403
+        o = ArtLight()
+        check(_lib.load().art_light_area(_f3(self.pos), _f3(self.pos2), _f3(self.pos3), int(self.invert_normal), _f3(self.color), self.falloff_distance,
+                                         self.penumbra_umbra_angles[0], self.penumbra_umbra_angles[1], int(self.casts_shadows), C.byref(o)))
+        return o
+
+
+class Lights:
+    """lights.rs:4-67.  Serialisation order point, spot, directional, area; unlike the reference's
+    copy_lights_shader_data (lights.rs:24-47, which writes every light of a kind into one slot) each light gets
+    its own slot -- identical whenever there is at most one light per kind."""
+
+    def __init__(self):
+        self.point_lights, self.spot_lights, self.directional_lights, self.area_lights = [], [], [], []
+
+    def get_point_lights_mut(self):
+        return self.point_lights
+
+    def get_spot_lights_mut(self):
+        return self.spot_lights
+
+    def get_directional_lights_mut(self):
+        return self.directional_lights
+
+    def get_area_lights_mut(self):
+        return self.area_lights
+
+    def get_lights_count(self):
+        return len(self.point_lights) + len(self.spot_lights) + len(self.directional_lights) + len(self.area_lights)
+
+    def copy_lights_shader_data(self):
+        all_ = self.point_lights + self.spot_lights + self.directional_lights + self.area_lights
+        arr = (ArtLight * max(1, len(all_)))()
+        for i, l in enumerate(all_):
+            arr[i] = l.get_light_shader_data()
+        return arr, len(all_)
+
+    def push_dict(self, d):
+        k = d["kind"]
+        if k == "point":
+            self.point_lights.append(PointLight(d["pos"], d["color"], d["falloff"], d["casts_shadows"]))
+        elif k == "spot":
+            self.spot_lights.append(SpotLight(d["pos"], d["dir"], d["color"], d["falloff"], (d["penumbra"], d["umbra"]), d["casts_shadows"]))
+        elif k == "directional":
+            self.directional_lights.append(DirectionalLight(d["dir"], d["color"], d["casts_shadows"]))
+        elif k == "area":
+            self.area_lights.append(AreaLight(d["pos"], d["pos2"], d["pos3"], d.get("invert_normal", False), d["color"], d["falloff"],
+                                              (d["penumbra"], d["umbra"]), d["casts_shadows"]))
+        else:
+            raise ValueError(k)
+
+
+# ------------------------------------------------------------------------------------------------ camera (vk_camera.rs)
+class Camera:
+    def __init__(self, pos, dir, aspect, fovy, znear, zfar):  # VkCamera::new, defaults renderer.rs:222-231
+        self._pos, self._dir, self._aspect, self._fovy, self._znear, self._zfar = tuple(pos), tuple(dir), aspect, fovy, znear, zfar
+        self.needs_update = True
+        self._block = ArtCamera()
+
+    def set_pos(self, pos):
+        self._pos, self.needs_update = tuple(pos), True
+
+    def set_dir(self, dir):
+        self._dir, self.needs_update = tuple(dir), True  # normalised inside libart like vk_camera.rs:133-136
+
+    def set_aspect(self, aspect):
+        self._aspect, self.needs_update = aspect, True
+
+    def set_fovy(self, fovy):
+        self._fovy, self.needs_update = fovy, True
+
+    def set_znear(self, znear):
+        self._znear, self.needs_update = znear, True
+
+    def set_zfar(self, zfar):
+        self._zfar, self.needs_update = zfar, True
+
+    def pos(self):
+        return self._pos
+
+    def dir(self):
+        return self._dir
+
+    def aspect(self):
+        return self._aspect
+
+    def fovy(self):
+        return self._fovy
+
+    def update_host_buffer(self) -> ArtCamera:  # vk_camera.rs:104-126
+        if self.needs_update:
+            check(_lib.load().art_camera_from_params(_f3(self._pos), _f3(self._dir), self._aspect, self._fovy, self._znear, self._zfar, C.byref(self._block)))
+            self.needs_update = False
+        return self._block
+
+    def view_matrix(self):  # column-major 4x4 as numpy [4,4] (row, col)
+        return np.array(self.update_host_buffer().view, dtype=np.float32).reshape(4, 4).T
+
+    def perspective_matrix(self):
+        return np.array(self.update_host_buffer().proj, dtype=np.float32).reshape(4, 4).T
+
+
+# ------------------------------------------------------------------------------------------------ renderer (renderer.rs)
+class Renderer:
+    """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
+
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False):
+        self._L = _lib.load()
+        w, h = extent
+        cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
+                        flags=_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0, reserved=0)
+        self._ctx = C.c_void_p()
+        check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))
+        self.extent = (w, h)
+        self.shard = shard
+        # defaults of renderer.rs:222-231
+        self._camera = Camera((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), w / h, math.pi / 2, 0.1, 1000.0)
+        self._lights = Lights()
+        self._models = []
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.art_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # renderer.rs:346 -- the reference takes a .glb path; here a model is the list of primitives the GLB reader yields
+    def add_model(self, primitives, model_matrix=None):
+        ids = []
+        for p in primitives:
+            verts = np.ascontiguousarray(p.verts, dtype=np.float32)
+            idx = np.ascontiguousarray(p.indices)
+            if idx.dtype not in (np.uint16, np.uint32):
+                raise TypeError("indices must be uint16 or uint32")
+            tex = np.ascontiguousarray(p.tex, dtype=np.uint8)
+            m = np.ascontiguousarray(model_matrix if model_matrix is not None else p.model, dtype=np.float32)
+            pid = C.c_uint32()
+            check(self._L.art_scene_add_primitive(self._ctx, _ptr(verts), verts.shape[0], _ptr(idx), idx.size, idx.dtype.itemsize, _ptr(tex),
+                                                  tex.shape[2], tex.shape[1], _ptr(m), C.byref(pid)))
+            ids.append(pid.value)
+        self._models.append(ids)
+        return ids
+
+    def models_mut(self):
+        return self._models
+
+    def camera_mut(self) -> Camera:
+        return self._camera
+
+    def lights_mut(self) -> Lights:
+        return self._lights
+
+    def prepare_first_frame(self):  # renderer.rs:356: uploads + BLAS/TLAS builds
+        check(self._L.art_scene_build(self._ctx))
+
+    def set_stream(self, hip_stream_ptr):
+        check(self._L.art_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
+
+    def resize(self, extent):
+        check(self._L.art_resize(self._ctx, extent[0], extent[1]))
+        self.extent = tuple(extent)
+        self._camera.set_aspect(extent[0] / extent[1])
+
+    def upload_state(self):
+        """camera.update_host_buffer + lights.update_host_and_device_buffer (renderer.rs:374, :677)."""
+        check(self._L.art_set_camera(self._ctx, C.byref(self._camera.update_host_buffer())))
+        arr, n = self._lights.copy_lights_shader_data()
+        check(self._L.art_set_lights(self._ctx, arr, n))
+
+    def trace(self):
+        """record + submit of lightning_layer.trace_rays (renderer.rs:679-686); asynchronous."""
+        check(self._L.art_trace(self._ctx))
+
+    def render_frame(self, sync=True):  # renderer.rs:371
+        self.upload_state()
+        self.trace()
+        if sync:
+            self.sync()
+
+    def sync(self):
+        check(self._L.art_sync(self._ctx))
+
+    # outputs (vk_rt_lightning_shadows.rs:161-183)
+    def read_color(self):
+        w, h = self.extent
+        a = np.empty((h, w, 4), np.float32)
+        check(self._L.art_read_color(self._ctx, _ptr(a), a.nbytes))
+        return a
+
+    def read_depth(self):
+        w, h = self.extent
+        a = np.empty((h, w), np.float32)
+        check(self._L.art_read_depth(self._ctx, _ptr(a), a.nbytes))
+        return a
+
+    def read_normal(self):
+        w, h = self.extent
+        a = np.empty((h, w, 4), np.float32)
+        check(self._L.art_read_normal(self._ctx, _ptr(a), a.nbytes))
+        return a
+
+    def device_color(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self._L.art_device_color(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def device_color_tiles(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self._L.art_device_color_tiles(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_color_tiles(self):
+        _, padded = self.shard_tile_count()
+        a = np.empty((padded, 32, 32, 4), np.float32)
+        check(self._L.art_read_color_tiles(self._ctx, _ptr(a), a.nbytes))
+        return a
+
+    def shard_tile_count(self):
+        o, pd = C.c_uint32(), C.c_uint32()
+        check(self._L.art_shard_tile_count(self._ctx, C.byref(o), C.byref(pd)))
+        return o.value, pd.value
+
+    def untile_gathered(self, gathered_dev_ptr, shard_count, frame_dev_ptr=None):
+        check(self._L.art_untile_gathered(self._ctx, C.c_void_p(gathered_dev_ptr), shard_count, C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None))
+
+    def stats(self) -> dict:
+        st = ArtStats()
+        check(self._L.art_get_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    # parity / debug surface
+    def read_hits(self):
+        w, h = self.extent
+        tuv = np.empty((h, w, 4), np.float32)
+        ids = np.empty((h, w, 2), np.int32)
+        check(self._L.art_read_hits(self._ctx, _ptr(tuv), _ptr(ids), w * h))
+        return tuv, ids
+
+    def read_shadow_bits(self):
+        w, h = self.extent
+        b = np.empty((h, w), np.uint32)
+        check(self._L.art_read_shadow_bits(self._ctx, _ptr(b), w * h))
+        return b
+
+    def query_closest(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        tuv = np.zeros((n, 4), np.float32)
+        ids = np.zeros((n, 2), np.int32)
+        check(self._L.art_query_closest(self._ctx, _ptr(rays), n, _ptr(tuv), _ptr(ids)))
+        return tuv, ids
+
+    def query_any(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.zeros(n, np.uint8)
+        check(self._L.art_query_any(self._ctx, _ptr(rays), n, _ptr(hit)))
+        return hit
+
+    def get_lbvh(self):
+        T = self.stats()["num_triangles"]
+        NI = max(T - 1, 0)
+        out = dict(leaf_gid=np.zeros(T, np.uint32), keys=np.zeros(T, np.uint64), child=np.zeros((NI, 2), np.int32), node_lo=np.zeros((NI, 3), np.float32),
+                   node_hi=np.zeros((NI, 3), np.float32), leaf_lo=np.zeros((T, 3), np.float32), leaf_hi=np.zeros((T, 3), np.float32))
+        check(self._L.art_get_lbvh(self._ctx, *[_ptr(out[k]) for k in ("leaf_gid", "keys", "child", "node_lo", "node_hi", "leaf_lo", "leaf_hi")]))
+        return out
+
+
+def renderer_for_scene(scene, extent, n_lights=None, **kw) -> Renderer:
+    """Convenience used by tests and bench: the main.rs:23-66 sequence for a synthetic scene."""
+    r = Renderer(extent, **kw)
+    r.add_model(scene.primitives)
+    cam = r.camera_mut()
+    cam.set_pos(scene.camera["pos"])
+    cam.set_dir(scene.camera["dir"])
+    cam.set_fovy(scene.camera["fovy"])
+    cam.set_znear(scene.camera["znear"])
+    cam.set_zfar(scene.camera["zfar"])
+    for d in (scene.lights if n_lights is None else scene.lights[:n_lights]):
+        r.lights_mut().push_dict(d)
+    r.prepare_first_frame()
+    return r

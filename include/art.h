@@ -1,0 +1,174 @@
+/*
+ * art.h -- C ABI of libart, the MI355X-native (gfx950, HIP) ray-tracing core that stands in for the Vulkan
+ * ray-tracing path of EdoardoLuciani/ARayTracingJourney.
+ *
+ * The reference has no FFI of its own: the path sits behind Rust methods that record Vulkan commands.  Each entry
+ * point below names the reference interface (path:line under /root/reference/src/vk_renderer/) it replaces; the
+ * binding a maintainer of the reference would add (a Rust `extern "C"` block) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative ART_E_* code; art_last_error() gives a thread-local message;
+ *    nothing throws or unwinds across the boundary (the reference panics instead: renderer.rs uses unwrap/expect);
+ *  - a context is single-threaded, like the reference's Rc<RefCell<..>> objects (renderer.rs:122-126);
+ *  - plain pointers and sizes only; device work is enqueued on one HIP stream per context and art_sync() is the
+ *    fence (the reference's analogue is the per-frame VkFence, renderer.rs:451-466);
+ *  - there is NO CPU fallback: every compute entry point fails with ART_E_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef ART_H
+#define ART_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ART_OK 0
+#define ART_E_INVALID (-1)    /* bad argument */
+#define ART_E_STATE (-2)      /* call out of order (e.g. trace before scene build) */
+#define ART_E_NO_DEVICE (-3)  /* no HIP device / kernels not loadable */
+#define ART_E_HIP (-4)        /* HIP runtime error, see art_last_error() */
+#define ART_E_NOMEM (-5)
+
+/* 48-byte interleaved vertex: model_reader.rs:22-35, gltf_model_reader.rs:176-199, raytrace.rgen.glsl:39-50 */
+typedef struct ArtVertex {
+    float pos[3];
+    float uv[2];
+    float normal[3];
+    float tangent[4];
+} ArtVertex;
+
+/* 80-byte light record: lights.rs:69-82 (LightShaderData) == light.glsl:1-12 (Light) */
+typedef struct ArtLight {
+    float pos[3];
+    uint32_t type; /* 0 point, 1 spot, 2 directional, 3 area (lights.rs:88-93) */
+    float dir[3];
+    uint32_t casts_shadows;
+    float color[3];
+    float falloff_distance;
+    float area_pos2[3];
+    float penumbra_angle;
+    float area_pos3[3];
+    float umbra_angle;
+} ArtLight;
+
+/* 268-byte camera block: vk_camera.rs:9-16 (Uniform) == raytrace.rgen.glsl:29-35; column-major mat4 */
+#pragma pack(push, 1)
+typedef struct ArtCamera {
+    float view[16];
+    float view_inv[16];
+    float proj[16];
+    float proj_inv[16];
+    float camera_pos[3];
+} ArtCamera;
+#pragma pack(pop)
+
+typedef struct ArtConfig {
+    int32_t device;       /* HIP device ordinal; -1 = current device */
+    uint32_t width;       /* initial extent (renderer.rs:140 takes vk::Extent2D) */
+    uint32_t height;
+    uint32_t morton_bits; /* 30 or 63; 0 = default (63) */
+    uint32_t shard_rank;  /* screen-tile sharding: this context renders the 32x32 tiles owned by shard_rank of */
+    uint32_t shard_count; /*   shard_count (0 or 1 = whole frame) */
+    uint32_t flags;       /* ART_FLAG_* */
+    uint32_t reserved;
+} ArtConfig;
+
+#define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits) */
+
+typedef struct ArtStats {
+    uint64_t primary_rays;      /* W*H of the pixels this context owns */
+    uint64_t shadow_rays;       /* shadow rays actually traced: hit && casts_shadows && N.L > 0 (raytrace.rgen.glsl:165) */
+    uint64_t hit_pixels;
+    uint64_t ao_rays;
+    uint32_t num_triangles;
+    uint32_t num_primitives;
+    uint32_t num_nodes;         /* nodes of the traversal structure */
+    uint32_t reserved;
+    float build_ms;             /* last art_scene_build, device time */
+    float frame_ms;             /* last art_trace, device time (events on the context's stream) */
+    float trace_primary_ms, shade_ms, trace_shadow_ms, accumulate_ms;
+} ArtStats;
+
+typedef struct ArtContext ArtContext;
+
+const char *art_last_error(void);
+int32_t art_device_count(void);
+
+/* VulkanTempleRayTracedRenderer::new (renderer.rs:140) / Drop */
+int32_t art_create(const ArtConfig *cfg, ArtContext **out);
+int32_t art_destroy(ArtContext *ctx);
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream */
+int32_t art_set_stream(ArtContext *ctx, void *hip_stream);
+
+/* add_model (renderer.rs:346) -> VkModel::create_blas geometry contract (vk_model.rs:886-943): one call per glTF
+ * primitive.  idx_bytes = 2|4 (vk_model.rs:142-150); rgba8 = 3 layers albedo/ORM/normal of tw x th texels
+ * (model_reader.rs:14-19); model3x4 = row-major object->world (vk_model.rs:358-363).  Data are copied. */
+int32_t art_scene_add_primitive(ArtContext *ctx, const ArtVertex *verts, uint32_t n_verts, const void *indices,
+                                uint32_t n_indices, uint32_t idx_bytes, const uint8_t *rgba8, uint32_t tw, uint32_t th,
+                                const float model3x4[12], uint32_t *out_primitive_id);
+int32_t art_scene_clear(ArtContext *ctx);
+/* VkBlasBuilder::build_blas_from_geometry (vk_blas_builder.rs:88-170) + VkTlasBuilder::recreate_tlas
+ * (vk_tlas_builder.rs:38-233): device LBVH over the world-space triangle soup. */
+int32_t art_scene_build(ArtContext *ctx);
+
+/* VkCamera::update_host_buffer (vk_camera.rs:104-126): the 268-byte block; and its producer */
+int32_t art_set_camera(ArtContext *ctx, const ArtCamera *cam);
+int32_t art_camera_from_params(const float pos[3], const float dir[3], float aspect, float fovy, float znear,
+                               float zfar, ArtCamera *out);
+
+/* VkLights::update_host_and_device_buffer (vk_lights.rs:81-139): n 80-byte records; and their producers
+ * (lights.rs:144-159, :228-243, :281-296, :383-403) */
+int32_t art_set_lights(ArtContext *ctx, const ArtLight *lights, uint32_t n);
+int32_t art_light_point(const float pos[3], const float color[3], float falloff, int32_t casts_shadows, ArtLight *out);
+int32_t art_light_spot(const float pos[3], const float dir[3], const float color[3], float falloff, float penumbra,
+                       float umbra, int32_t casts_shadows, ArtLight *out);
+int32_t art_light_directional(const float dir[3], const float color[3], int32_t casts_shadows, ArtLight *out);
+int32_t art_light_area(const float pos[3], const float pos2[3], const float pos3[3], int32_t invert_normal,
+                       const float color[3], float falloff, float penumbra, float umbra, int32_t casts_shadows,
+                       ArtLight *out);
+
+/* VkRTLightningShadows::resize (vk_rt_lightning_shadows.rs:125-159) */
+int32_t art_resize(ArtContext *ctx, uint32_t width, uint32_t height);
+/* VkRTLightningShadows::trace_rays (vk_rt_lightning_shadows.rs:185-278): raygen + closest hit + light loop +
+ * shadow rays + G-buffer stores of raytrace.rgen.glsl:77-200, asynchronous on the context's stream */
+int32_t art_trace(ArtContext *ctx);
+/* the fence (renderer.rs:451-466) */
+int32_t art_sync(ArtContext *ctx);
+
+/* get_color_output_image / get_output_depth_image / get_output_normal_image (vk_rt_lightning_shadows.rs:161-183):
+ * fp32 RGBA colour (the value passed to imageStore, before the reference's lossy image formats), fp32 depth,
+ * fp32 RGBA normal; row-major full frame.  Host copies (synchronising) and raw device pointers. */
+int32_t art_read_color(ArtContext *ctx, void *dst, size_t bytes);
+int32_t art_read_depth(ArtContext *ctx, void *dst, size_t bytes);
+int32_t art_read_normal(ArtContext *ctx, void *dst, size_t bytes);
+int32_t art_device_color(ArtContext *ctx, void **dev_ptr, size_t *bytes);
+int32_t art_device_depth(ArtContext *ctx, void **dev_ptr, size_t *bytes);
+int32_t art_device_normal(ArtContext *ctx, void **dev_ptr, size_t *bytes);
+
+/* screen-tile sharding (new functionality, BASELINE.json): compact per-shard colour tiles for the RCCL gather, and
+ * the un-tile step run by the root on the gathered buffer.  tile = 32x32 px, 16 KiB of RGBA32F each. */
+int32_t art_shard_tile_count(ArtContext *ctx, uint32_t *owned, uint32_t *padded);
+int32_t art_device_color_tiles(ArtContext *ctx, void **dev_ptr, size_t *bytes);
+int32_t art_read_color_tiles(ArtContext *ctx, void *dst, size_t bytes); /* host copy of the same buffer (tests) */
+int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev);
+
+int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
+
+/* ---- parity / debug surface (not part of the reference's API; used by tests through this C ABI) ---- */
+/* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */
+int32_t art_read_hits(ArtContext *ctx, float *tuv, int32_t *ids, size_t n_pixels);
+/* per pixel: bit i = light i shadowed, bit 16+i = shadow ray for light i traced (i < 16) */
+int32_t art_read_shadow_bits(ArtContext *ctx, uint32_t *bits, size_t n_pixels);
+/* arbitrary ray queries on the built scene.  rays: n x 8 floats (o.xyz, tmin, d.xyz, tmax), host memory. */
+int32_t art_query_closest(ArtContext *ctx, const float *rays, uint32_t n, float *tuv, int32_t *ids);
+int32_t art_query_any(ArtContext *ctx, const float *rays, uint32_t n, uint8_t *hit);
+/* the device-built binary LBVH, in the oracle's canonical form (any pointer may be NULL):
+ * leaf_gid[T], keys[T], child[2*(T-1)], node_lo/hi[(T-1)*3], leaf_lo/hi[T*3] */
+int32_t art_get_lbvh(ArtContext *ctx, uint32_t *leaf_gid, uint64_t *keys, int32_t *child, float *node_lo,
+                     float *node_hi, float *leaf_lo, float *leaf_hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ART_H */

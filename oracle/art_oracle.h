@@ -1,0 +1,99 @@
+/*
+ * art_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Scalar C restatement of the reference's ray-tracing hot path
+ * (/root/reference/src/vk_renderer/shaders/rt_lightning_shadows/{raytrace.rgen,light,ray_payload}.glsl, brdfs.glsl,
+ * vk_camera.rs, lights.rs) plus a definition of what the closed Vulkan driver does
+ * behind traceRayEXT (BVH build + traversal), which the reference does not contain.
+ *
+ * PARITY UNPINNED: the reference holds no golden vector, known-answer test or
+ * fixture for this path and cannot be built or run here
+ * (Rust + Vulkan RT).  This oracle is therefore pinned only by analytic known-answer
+ * tests, a brute-force cross-check and an independent numpy restatement of the
+ * shading maths (tests/).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product (araytracingjourney_amd/) never links or calls it.
+ */
+#ifndef ART_ORACLE_H
+#define ART_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcScene OrcScene;
+
+/* 80-byte light record == LightShaderData, lights.rs:69-82 == Light, light.glsl:1-12 */
+typedef struct {
+    float pos[3];    uint32_t type;           /* 0 point 1 spot 2 directional 3 area (lights.rs:88-93) */
+    float dir[3];    uint32_t casts_shadows;
+    float color[3];  float falloff_distance;
+    float area_pos2[3]; float penumbra_angle;
+    float area_pos3[3]; float umbra_angle;
+} OrcLight;
+
+/* 268-byte camera block == Uniform, vk_camera.rs:9-16 (column-major mat4 x4 + vec3) */
+typedef struct {
+    float view[16], view_inv[16], proj[16], proj_inv[16];
+    float camera_pos[3];
+} OrcCamera;
+
+typedef struct {
+    uint64_t primary_rays, shadow_rays;
+    uint64_t hit_pixels;
+    uint64_t n_int_primary, n_tri_primary;   /* canonical-LBVH visit counters */
+    uint64_t n_int_shadow,  n_tri_shadow;
+    uint64_t nonfinite_pixels;
+} OrcStats;
+
+OrcScene *orc_scene_create(void);
+void      orc_scene_destroy(OrcScene *);
+/* verts: nv x 12 floats (pos3 uv2 normal3 tangent4); idx: n_idx indices of idx_bytes (2|4);
+ * tex: 3 layers (albedo, ORM, normal) x th x tw x RGBA8; model3x4: row-major object->world */
+int orc_scene_add_primitive(OrcScene *, const float *verts, uint32_t nv, const void *idx, uint32_t n_idx,
+                            uint32_t idx_bytes, const uint8_t *tex, uint32_t tw, uint32_t th,
+                            const float model3x4[12]);
+/* morton_bits: 30 or 63.  Builds the canonical binary LBVH (one triangle per leaf). */
+int orc_scene_build(OrcScene *, int morton_bits);
+uint32_t orc_scene_num_tris(const OrcScene *);
+/* copies out the LBVH: leaf_gid[T], keys[T] (morton), child[2*(T-1)] (>=0 internal, <0 = ~leaf position),
+ * node boxes lo/hi [T-1][3], leaf boxes [T][3], world triangle vertices [T][9]. Any pointer may be NULL. */
+void orc_scene_get_lbvh(const OrcScene *, uint32_t *leaf_gid, uint64_t *keys, int32_t *child,
+                        float *node_lo, float *node_hi, float *leaf_lo, float *leaf_hi, float *tri_verts);
+
+/* host maths */
+void orc_camera_from_params(const float pos[3], const float dir[3], float aspect, float fovy,
+                            float znear, float zfar, OrcCamera *out);          /* vk_camera.rs:104-126,182-193 */
+void orc_light_point(const float pos[3], const float color[3], float falloff, int casts, OrcLight *out);
+void orc_light_spot(const float pos[3], const float dir[3], const float color[3], float falloff,
+                    float penumbra, float umbra, int casts, OrcLight *out);
+void orc_light_directional(const float dir[3], const float color[3], int casts, OrcLight *out);
+void orc_light_area(const float pos[3], const float pos2[3], const float pos3[3], int invert_normal,
+                    const float color[3], float falloff, float penumbra, float umbra, int casts, OrcLight *out);
+
+/* rays: n x 8 floats (o.xyz, tmin, d.xyz, tmax) */
+void orc_gen_primary(const OrcCamera *, uint32_t w, uint32_t h, float *rays);
+/* mode 0 = canonical LBVH traversal, 1 = brute force over all triangles.
+ * out_hit: n x 4 floats (t,u,v, unused) ; out_id: n x 2 ints (primitive index or -1, triangle id in primitive) */
+void orc_trace_closest(const OrcScene *, const float *rays, uint32_t n, int mode, float *out_tuv, int32_t *out_id,
+                       uint64_t *n_int, uint64_t *n_tri);
+void orc_trace_any(const OrcScene *, const float *rays, uint32_t n, int mode, uint8_t *out_hit,
+                   uint64_t *n_int, uint64_t *n_tri);
+
+/* full frame: color (w*h*4), depth (w*h), normal (w*h*4) in row-major pixel order; rows [y0,y1).
+ * Optional debug outputs (may be NULL): hit_tuv (w*h*4), hit_id (w*h*2), shadow_bits (w*h, bit i = light i shadowed,
+ * bit 16+i = shadow ray i traced). */
+void orc_render(const OrcScene *, const OrcCamera *, const OrcLight *, uint32_t n_lights, uint32_t w, uint32_t h,
+                uint32_t y0, uint32_t y1, float *color, float *depth, float *normal, float *hit_tuv, int32_t *hit_id,
+                uint32_t *shadow_bits, OrcStats *stats, int n_threads);
+
+/* single-point shading for known-answer tests: shades a given hit without tracing the primary ray */
+void orc_brdf_terms(float NdotL, float NdotV, float NdotH, float LdotH, float nc_NdotV, float nc_NdotL, float alpha,
+                    float out[4]); /* D, V_fast, pow5 Schlick weight, Burley_local_sss */
+void orc_light_eval(const OrcLight *, const float p[3], float nn_L[3], float radiance[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,210 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE -- PARITY UNPINNED (see art_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the product never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrcLight(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("type", C.c_uint32), ("dir", C.c_float * 3), ("casts_shadows", C.c_uint32),
+                ("color", C.c_float * 3), ("falloff_distance", C.c_float), ("area_pos2", C.c_float * 3), ("penumbra_angle", C.c_float),
+                ("area_pos3", C.c_float * 3), ("umbra_angle", C.c_float)]
+
+
+class OrcCamera(C.Structure):
+    _pack_ = 1
+    _fields_ = [("view", C.c_float * 16), ("view_inv", C.c_float * 16), ("proj", C.c_float * 16), ("proj_inv", C.c_float * 16),
+                ("camera_pos", C.c_float * 3)]
+
+
+class OrcStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("primary_rays", "shadow_rays", "hit_pixels", "n_int_primary", "n_tri_primary",
+                                          "n_int_shadow", "n_tri_shadow", "nonfinite_pixels")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+assert C.sizeof(OrcLight) == 80 and C.sizeof(OrcCamera) == 268
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_add_primitive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                              C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_scene_build.argtypes = [C.c_void_p, C.c_int]
+        L.orc_scene_num_tris.argtypes = [C.c_void_p]
+        L.orc_scene_num_tris.restype = C.c_uint32
+        L.orc_scene_get_lbvh.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        L.orc_camera_from_params.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_light_point.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        L.orc_light_spot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.orc_light_directional.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_light_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.orc_gen_primary.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_brdf_terms.argtypes = [C.c_float] * 7 + [C.c_void_p]
+        L.orc_light_eval.argtypes = [C.c_void_p] * 4
+        _LIB = L
+    return _LIB
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def camera_from_params(pos, dir, aspect, fovy, znear, zfar) -> OrcCamera:
+    cam = OrcCamera()
+    lib().orc_camera_from_params(_f3(pos), _f3(dir), aspect, fovy, znear, zfar, C.byref(cam))
+    return cam
+
+
+def make_light(d: dict) -> OrcLight:
+    L = lib()
+    o = OrcLight()
+    k = d["kind"]
+    cs = int(bool(d.get("casts_shadows", False)))
+    if k == "point":
+        L.orc_light_point(_f3(d["pos"]), _f3(d["color"]), d["falloff"], cs, C.byref(o))
+    elif k == "spot":
+        L.orc_light_spot(_f3(d["pos"]), _f3(d["dir"]), _f3(d["color"]), d["falloff"], d["penumbra"], d["umbra"], cs, C.byref(o))
+    elif k == "directional":
+        L.orc_light_directional(_f3(d["dir"]), _f3(d["color"]), cs, C.byref(o))
+    elif k == "area":
+        L.orc_light_area(_f3(d["pos"]), _f3(d["pos2"]), _f3(d["pos3"]), int(bool(d.get("invert_normal", False))), _f3(d["color"]),
+                         d["falloff"], d["penumbra"], d["umbra"], cs, C.byref(o))
+    else:
+        raise ValueError(k)
+    return o
+
+
+def make_lights(ds):
+    arr = (OrcLight * max(1, len(ds)))()
+    for i, d in enumerate(ds):
+        arr[i] = make_light(d)
+    return arr
+
+
+class Scene:
+    def __init__(self, primitives=None, morton_bits=30):
+        self._L = lib()
+        self.h = C.c_void_p(self._L.orc_scene_create())
+        if primitives is not None:
+            for p in primitives:
+                self.add_primitive(p.verts, p.indices, p.tex, p.model)
+            self.build(morton_bits)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._L.orc_scene_destroy(self.h)
+            self.h = None
+
+    def add_primitive(self, verts, indices, tex, model):
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        indices = np.ascontiguousarray(indices)
+        assert indices.dtype in (np.uint16, np.uint32)
+        tex = np.ascontiguousarray(tex, dtype=np.uint8)
+        model = np.ascontiguousarray(model, dtype=np.float32)
+        r = self._L.orc_scene_add_primitive(self.h, _ptr(verts), verts.shape[0], _ptr(indices), indices.size, indices.dtype.itemsize,
+                                            _ptr(tex), tex.shape[2], tex.shape[1], _ptr(model))
+        if r < 0:
+            raise ValueError(f"orc_scene_add_primitive failed: {r}")
+        return r
+
+    def build(self, morton_bits=30):
+        r = self._L.orc_scene_build(self.h, morton_bits)
+        if r != 0:
+            raise ValueError(f"orc_scene_build failed: {r}")
+
+    @property
+    def n_tris(self):
+        return int(self._L.orc_scene_num_tris(self.h))
+
+    def lbvh(self):
+        T = self.n_tris
+        NI = max(T - 1, 0)
+        out = dict(leaf_gid=np.zeros(T, np.uint32), keys=np.zeros(T, np.uint64), child=np.zeros((NI, 2), np.int32),
+                   node_lo=np.zeros((NI, 3), np.float32), node_hi=np.zeros((NI, 3), np.float32), leaf_lo=np.zeros((T, 3), np.float32),
+                   leaf_hi=np.zeros((T, 3), np.float32), tri_verts=np.zeros((T, 9), np.float32))
+        self._L.orc_scene_get_lbvh(self.h, *[_ptr(out[k]) for k in ("leaf_gid", "keys", "child", "node_lo", "node_hi", "leaf_lo", "leaf_hi", "tri_verts")])
+        return out
+
+    def trace_closest(self, rays, mode=0):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        tuv = np.zeros((n, 4), np.float32)
+        ids = np.zeros((n, 2), np.int32)
+        ni, nt = C.c_uint64(), C.c_uint64()
+        self._L.orc_trace_closest(self.h, _ptr(rays), n, mode, _ptr(tuv), _ptr(ids), C.byref(ni), C.byref(nt))
+        return tuv, ids, int(ni.value), int(nt.value)
+
+    def trace_any(self, rays, mode=0):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        hit = np.zeros(n, np.uint8)
+        ni, nt = C.c_uint64(), C.c_uint64()
+        self._L.orc_trace_any(self.h, _ptr(rays), n, mode, _ptr(hit), C.byref(ni), C.byref(nt))
+        return hit, int(ni.value), int(nt.value)
+
+    def render(self, cam: OrcCamera, lights, n_lights, w, h, y0=0, y1=None, threads=1, debug=False):
+        y1 = h if y1 is None else y1
+        color = np.zeros((h, w, 4), np.float32)
+        depth = np.zeros((h, w), np.float32)
+        normal = np.zeros((h, w, 4), np.float32)
+        tuv = np.zeros((h, w, 4), np.float32) if debug else None
+        ids = np.zeros((h, w, 2), np.int32) if debug else None
+        sb = np.zeros((h, w), np.uint32) if debug else None
+        st = OrcStats()
+        self._L.orc_render(self.h, C.byref(cam), lights, n_lights, w, h, y0, y1, _ptr(color), _ptr(depth), _ptr(normal), _ptr(tuv), _ptr(ids),
+                           _ptr(sb), C.byref(st), threads)
+        out = dict(color=color, depth=depth, normal=normal, stats=st.as_dict())
+        if debug:
+            out.update(hit_tuv=tuv, hit_id=ids, shadow_bits=sb)
+        return out
+
+
+def gen_primary(cam: OrcCamera, w, h):
+    rays = np.zeros((h * w, 8), np.float32)
+    lib().orc_gen_primary(C.byref(cam), w, h, _ptr(rays))
+    return rays
+
+
+def brdf_terms(NdotL, NdotV, NdotH, LdotH, nc_NdotV, nc_NdotL, alpha):
+    out = np.zeros(4, np.float32)
+    lib().orc_brdf_terms(NdotL, NdotV, NdotH, LdotH, nc_NdotV, nc_NdotL, alpha, _ptr(out))
+    return out
+
+
+def light_eval(light: OrcLight, p):
+    nn = np.zeros(3, np.float32)
+    rad = np.zeros(3, np.float32)
+    pp = np.asarray(p, np.float32)
+    lib().orc_light_eval(C.byref(light), _ptr(pp), _ptr(nn), _ptr(rad))
+    return nn, rad

@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+try:  # load torch's HIP runtime before libart so that the process holds exactly one libamdhip64
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) device")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure; PARITY UNPINNED, see oracle/art_oracle.h)."""
+    from oracle import orc as _orc
+    _orc.build()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    from araytracingjourney_amd import scenes as _s
+    return _s
+
+
+_SCENE_CACHE = {}
+
+
+@pytest.fixture(scope="session")
+def get_scene(scenes):
+    def _get(name, detail=1.0):
+        key = (name, detail)
+        if key not in _SCENE_CACHE:
+            _SCENE_CACHE[key] = scenes.get_scene(name, detail)
+        return _SCENE_CACHE[key]
+    return _get
+
+
+def assert_radiance_close(got, want, rel=1e-4, floor=1e-6, what="radiance"):
+    """per-pixel fp32 radiance within 1e-4 relative (abs floor 1e-6)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape
+    assert np.isfinite(got).all(), f"{what}: non-finite values"
+    err = np.abs(got - want)
+    tol = rel * np.abs(want) + floor
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values off; worst rel err {float((err / (np.abs(want) + floor)).max()):.3e}"

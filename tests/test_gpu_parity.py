@@ -1,0 +1,146 @@
+"""GPU parity tests proper: libart (HIP, through the C ABI) against the CPU oracle on the same inputs.
+Bit-exact for geometry (LBVH, t/u/v/primitive/triangle, shadow bits, ray counts); 1e-4 relative for radiance."""
+import numpy as np
+import pytest
+
+from conftest import assert_radiance_close
+from helpers import oracle_camera, oracle_for, random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    from araytracingjourney_amd import renderer
+    return renderer
+
+
+@pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12)])
+@pytest.mark.parametrize("bits", [30, 63])
+def test_lbvh_matches_oracle_bitwise(R, orc, get_scene, name, detail, bits):
+    sc = get_scene(name, detail)
+    r = R.renderer_for_scene(sc, (64, 64), morton_bits=bits)
+    S = orc.Scene(sc.primitives, morton_bits=bits)
+    dev, ref = r.get_lbvh(), S.lbvh()
+    assert r.stats()["num_triangles"] == S.n_tris == sc.n_tris
+    for k in ("keys", "leaf_gid", "child"):
+        assert np.array_equal(dev[k], ref[k]), k
+    for k in ("leaf_lo", "leaf_hi", "node_lo", "node_hi"):
+        assert np.array_equal(dev[k].view(np.uint32), ref[k].view(np.uint32)), k
+    r.close()
+
+
+@pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12)])
+def test_ray_queries_match_oracle_bitwise(R, orc, get_scene, name, detail):
+    sc = get_scene(name, detail)
+    r = R.renderer_for_scene(sc, (64, 64))
+    S = orc.Scene(sc.primitives, morton_bits=30)  # a different tree than the device's 63-bit one: results must not depend on it
+    rays = random_rays(20000, 7)
+    tuv, ids = r.query_closest(rays)
+    rtuv, rids, _, _ = S.trace_closest(rays)
+    assert np.array_equal(ids, rids)
+    assert np.array_equal(tuv.view(np.uint32)[:, :3], rtuv.view(np.uint32)[:, :3])
+    assert (ids[:, 0] >= 0).sum() > 1000
+    short = rays.copy()
+    short[:, 7] = 1.5
+    hit = r.query_any(short)
+    rhit, _, _ = S.trace_any(short)
+    assert np.array_equal(hit, rhit)
+    assert 0 < hit.sum() < hit.size
+    r.close()
+
+
+def _frame_parity(R, orc, sc, w, h, n_lights):
+    r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True)
+    r.render_frame()
+    S, L, nl = oracle_for(orc, sc, n_lights)
+    ref = S.render(oracle_camera(orc, sc, w, h), L, nl, w, h, threads=8, debug=True)
+    tuv, ids = r.read_hits()
+    assert np.array_equal(ids, ref["hit_id"]), f"{int((ids != ref['hit_id']).any(-1).sum())} hit ids differ"
+    assert np.array_equal(tuv.view(np.uint32)[..., :3], ref["hit_tuv"].view(np.uint32)[..., :3])
+    assert np.array_equal(r.read_shadow_bits(), ref["shadow_bits"])
+    st = r.stats()
+    assert st["primary_rays"] == ref["stats"]["primary_rays"] == w * h
+    assert st["shadow_rays"] == ref["stats"]["shadow_rays"]
+    assert st["hit_pixels"] == ref["stats"]["hit_pixels"]
+    assert ref["stats"]["nonfinite_pixels"] == 0
+    assert_radiance_close(r.read_color(), ref["color"])
+    assert_radiance_close(r.read_depth(), ref["depth"], what="depth")
+    assert_radiance_close(r.read_normal(), ref["normal"], rel=1e-4, floor=1e-5, what="normal")
+    r.close()
+    return ref
+
+
+def test_cornell_frame_matches_oracle(R, orc, get_scene):
+    ref = _frame_parity(R, orc, get_scene("cornell"), 256, 256, None)
+    assert ref["stats"]["shadow_rays"] > 1000
+
+
+@pytest.mark.parametrize("n_lights", [1, 4])
+def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights):
+    sc = get_scene("sponza_like", 0.12)
+    if n_lights == 4:
+        sc = scenes.Scene(sc.name, sc.primitives, sc.camera, scenes.sponza_lights(4))
+    ref = _frame_parity(R, orc, sc, 480, 270, None)
+    assert ref["stats"]["shadow_rays"] > 10000
+
+
+def test_ragged_extent_and_resize(R, orc, get_scene):
+    """extent not a multiple of the 32-pixel tile; then a resize (vk_rt_lightning_shadows.rs:125)"""
+    sc = get_scene("cornell")
+    r = R.renderer_for_scene(sc, (100, 52))
+    S, L, nl = oracle_for(orc, sc)
+    for (w, h) in [(100, 52), (37, 91)]:
+        r.resize((w, h))
+        r.render_frame()
+        ref = S.render(oracle_camera(orc, sc, w, h), L, nl, w, h, threads=4)
+        assert_radiance_close(r.read_color(), ref["color"])
+    r.close()
+
+
+def test_sharded_tiles_gather_to_the_unsharded_frame(R, get_scene):
+    """screen-tile split: 3 shard contexts on one GPU, tiles concatenated as a gather would, un-tiled by shard 0"""
+    import torch
+    sc = get_scene("cornell")
+    w, h, G = 200, 136, 3
+    whole = R.renderer_for_scene(sc, (w, h))
+    whole.render_frame()
+    want = whole.read_color()
+    shards = [R.renderer_for_scene(sc, (w, h), shard=(k, G)) for k in range(G)]
+    bufs = []
+    for s in shards:
+        s.render_frame()
+        bufs.append(s.read_color_tiles())
+    gathered = torch.from_numpy(np.concatenate(bufs)).cuda()   # what dist.gather leaves on the root
+    torch.cuda.synchronize()
+    shards[0].untile_gathered(gathered.data_ptr(), G)
+    got = shards[0].read_color()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    owned = [s.shard_tile_count()[0] for s in shards]
+    assert sum(owned) == ((w + 31) // 32) * ((h + 31) // 32) and max(owned) - min(owned) <= 2
+    for s in shards + [whole]:
+        s.close()
+
+
+def test_single_triangle_known_answers(R):
+    """analytic KAT through the GPU: one triangle, hand-computed t/u/v, edge, parallel, behind, range cases"""
+    from araytracingjourney_amd import scenes
+    mb = scenes.MeshBuilder()
+    mb.add([(0, 0, 2), (1, 0, 2), (0, 1, 2)], [(0, 0), (1, 0), (0, 1)], [(0, 0, -1)] * 3, [(1, 0, 0, 1)] * 3, [0, 1, 2])
+    sc = scenes.Scene("tri", [mb.finish(scenes.constant_texture((200, 200, 200)))], scenes.cornell().camera, [])
+    r = R.renderer_for_scene(sc, (8, 8))
+    rays = np.array([
+        [0.25, 0.25, 0, 0.001, 0, 0, 1, 100],      # hit: t=2, u=.25, v=.25
+        [0.25, 0.25, 0, 0.001, 0, 0, -1, 100],     # behind
+        [2.0, 2.0, 0, 0.001, 0, 0, 1, 100],        # outside
+        [0.25, 0.25, 0, 0.001, 1, 0, 0, 100],      # parallel
+        [0.25, 0.25, 0, 0.001, 0, 0, 1, 1.5],      # tmax too short
+        [0.25, 0.25, 0, 2.5, 0, 0, 1, 100],        # tmin beyond
+        [0.25, 0.25, 4, 0.001, 0, 0, -1, 100],     # back face: two-sided => hit at t=2
+        [0.5, 0.5, 0, 0.001, 0, 0, 1, 100],        # on the hypotenuse: u+v=1 accepted
+    ], np.float32)
+    tuv, ids = r.query_closest(rays)
+    assert ids[:, 0].tolist() == [0, -1, -1, -1, -1, -1, 0, 0]
+    assert np.allclose(tuv[0, :3], [2, .25, .25]) and np.allclose(tuv[6, :3], [2, .25, .25]) and np.allclose(tuv[7, :3], [2, .5, .5])
+    assert r.query_any(rays).tolist() == [1, 0, 0, 0, 0, 0, 1, 1]
+    r.close()
