@@ -79,6 +79,8 @@ SYMBOLS = {
     "art_device_normal": (_I32, [_P, _P, _P]),
     "art_shard_tile_count": (_I32, [_P, _P, _P]),
     "art_device_color_tiles": (_I32, [_P, _P, _P]),
+    "art_bind_color_tiles": (_I32, [_P, _P, _SZ]),
+    "art_collect_timings": (_I32, [_P, _P, _P]),
     "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
     "art_untile_gathered": (_I32, [_P, _P, _U32, _P]),
     "art_get_stats": (_I32, [_P, _P]),

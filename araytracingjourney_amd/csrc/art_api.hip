@@ -58,7 +58,10 @@ struct ArtContext {
     DevBuf<uint32_t> d_tile_list, d_counters, d_shadow_bits;
     DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
     DevBuf<float> d_depth;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kRing = 128;          // per-frame stage events kept for art_collect_timings
+    hipEvent_t ev[kRing][5] = {};
+    uint64_t frame_no = 0, collected_upto = 0;
+    float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
     bool traced = false;
     ArtStats stats{};
 };
@@ -185,7 +188,8 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     c->device = dev;
     hipError_t e = hipSetDevice(dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[i]);
+    for (int f = 0; f < ArtContext::kRing && e == hipSuccess; f++)
+        for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[f][i]);
     if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
     c->stream = c->own_stream;
     c->W = cfg->width; c->H = cfg->height;
@@ -201,7 +205,8 @@ int32_t art_destroy(ArtContext *c) {
     c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release(); c->d_lights.release();
     c->d_tile_list.release(); c->d_counters.release(); c->d_shadow_bits.release(); c->d_hits.release(); c->d_contrib.release();
     c->d_shadow_rays.release(); c->d_color.release(); c->d_normal.release(); c->d_color_tiles.release(); c->d_depth.release();
-    for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int f = 0; f < ArtContext::kRing; f++)
+        for (int i = 0; i < 5; i++) if (c->ev[f][i]) (void)hipEventDestroy(c->ev[f][i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ART_OK;
@@ -387,20 +392,22 @@ int32_t art_trace(ArtContext *c) {
     a.lights = c->d_lights.p; a.n_lights = (uint32_t)c->lights.size();
     a.hits = c->d_hits.p; a.contrib = c->d_contrib.p; a.shadow_rays = c->d_shadow_rays.p; a.counters = c->d_counters.p;
     a.color = c->d_color.p; a.depth = c->d_depth.p; a.normal = c->d_normal.p;
-    a.color_tiles = c->cfg.shard_count > 1 ? c->d_color_tiles.p : nullptr;
+    a.color_tiles = c->cfg.shard_count > 1 ? (c->ext_tiles ? c->ext_tiles : c->d_color_tiles.p) : nullptr;
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? c->d_shadow_bits.p : nullptr;
     hipStream_t s = c->stream;
+    hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     HIPC(hipMemsetAsync(c->d_counters.p, 0, 16 * 4, s));
-    HIPC(hipEventRecord(c->ev[0], s));
+    HIPC(hipEventRecord(ev[0], s));
     if (a.n_local) launch_primary(a, s);
-    HIPC(hipEventRecord(c->ev[1], s));
+    HIPC(hipEventRecord(ev[1], s));
     if (a.n_local) launch_shade(a, s);
-    HIPC(hipEventRecord(c->ev[2], s));
+    HIPC(hipEventRecord(ev[2], s));
     if (a.n_local) launch_shadow(a, s);
-    HIPC(hipEventRecord(c->ev[3], s));
+    HIPC(hipEventRecord(ev[3], s));
     if (a.n_local) launch_accumulate(a, s);
-    HIPC(hipEventRecord(c->ev[4], s));
+    HIPC(hipEventRecord(ev[4], s));
     HIPC(hipGetLastError());
+    c->frame_no++;
     c->traced = true;
     return ART_OK;
 }
@@ -446,12 +453,38 @@ int32_t art_shard_tile_count(ArtContext *c, uint32_t *owned, uint32_t *padded) {
 int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
     int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color_tiles"); if (r) return r;
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
-    *p = c->d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * 16;
+    *p = c->ext_tiles ? c->ext_tiles : c->d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * 16;
+    return ART_OK;
+}
+int32_t art_bind_color_tiles(ArtContext *c, void *dev, size_t bytes) {
+    if (!c) return fail(ART_E_INVALID, "art_bind_color_tiles: null context");
+    if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_bind_color_tiles: context is not sharded");
+    void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_bind_color_tiles"); if (r) return r;
+    if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * 16) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
+    HIPC(hipStreamSynchronize(c->stream));
+    c->ext_tiles = (float4 *)dev; c->ext_tiles_bytes = dev ? bytes : 0;
+    return ART_OK;
+}
+int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames) {
+    if (!c || !sums_ms || !n_frames) return fail(ART_E_INVALID, "art_collect_timings: null argument");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream));
+    uint64_t from = c->collected_upto;
+    if (c->frame_no - from > (uint64_t)ArtContext::kRing) from = c->frame_no - ArtContext::kRing;
+    for (int k = 0; k < 5; k++) sums_ms[k] = 0.f;
+    for (uint64_t f = from; f < c->frame_no; f++) {
+        hipEvent_t *ev = c->ev[f % ArtContext::kRing];
+        float ms = 0;
+        for (int k = 0; k < 4; k++) { HIPC(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); sums_ms[k] += ms; }
+        HIPC(hipEventElapsedTime(&ms, ev[0], ev[4])); sums_ms[4] += ms;
+    }
+    *n_frames = (uint32_t)(c->frame_no - from);
+    c->collected_upto = c->frame_no;
     return ART_OK;
 }
 int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
     if (c && c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
-    return read_back(c, c ? c->d_color_tiles.p : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * 16 : 0, dst, bytes, "art_read_color_tiles");
+    return read_back(c, c ? (c->ext_tiles ? c->ext_tiles : c->d_color_tiles.p) : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * 16 : 0, dst, bytes, "art_read_color_tiles");
 }
 int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev) {
     if (!c || !gathered_dev) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
@@ -479,11 +512,14 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         }
         c->stats.primary_rays = owned; c->stats.shadow_rays = cnt[0]; c->stats.hit_pixels = cnt[1];
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[4]) == hipSuccess) c->stats.frame_ms = ms;
-        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.trace_primary_ms = ms;
-        if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.shade_ms = ms;
-        if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.trace_shadow_ms = ms;
-        if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->stats.accumulate_ms = ms;
+        if (c->frame_no) {
+            hipEvent_t *ev = c->ev[(c->frame_no - 1) % ArtContext::kRing];
+            if (hipEventElapsedTime(&ms, ev[0], ev[4]) == hipSuccess) c->stats.frame_ms = ms;
+            if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.trace_primary_ms = ms;
+            if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->stats.shade_ms = ms;
+            if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.trace_shadow_ms = ms;
+            if (hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess) c->stats.accumulate_ms = ms;
+        }
     }
     *out = c->stats;
     return ART_OK;

@@ -278,6 +278,17 @@ class Renderer:
         check(self._L.art_device_color_tiles(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def bind_color_tiles(self, dev_ptr, nbytes):
+        check(self._L.art_bind_color_tiles(self._ctx, C.c_void_p(dev_ptr) if dev_ptr else None, nbytes))
+
+    def collect_timings(self):
+        sums = (C.c_float * 5)()
+        n = C.c_uint32()
+        check(self._L.art_collect_timings(self._ctx, sums, C.byref(n)))
+        names = ("primary_ms", "shade_ms", "shadow_ms", "accumulate_ms", "frame_ms")
+        k = max(1, n.value)
+        return {nm: sums[i] / k for i, nm in enumerate(names)}, n.value
+
     def read_color_tiles(self):
         _, padded = self.shard_tile_count()
         a = np.empty((padded, 32, 32, 4), np.float32)

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- Mray/s (primary + shadow) on BASELINE.json configs[1]: Sponza-class scene, 1920x1080, one directional
+light, one shadow ray per lit pixel.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one frame of the hot path (primary rays + closest hit, hit reconstruction + PBR direct light, shadow rays,
+accumulation; for N > 1 also the RCCL gather of the HDR tiles to rank 0 and the un-tile).  The scene, BVH, camera and
+lights are resident in HBM before the timed region.  N > 1 shards the frame by 32x32 screen tile (strong scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
+
+
+def algorithmic_bytes(st, n_lights):
+    """bytes(ray) = 32 + 64*N_int + 48*N_tri + B_out on the canonical binary LBVH (oracle counters)."""
+    prim = 32 * st["primary_rays"] + 64 * st["n_int_primary"] + 48 * st["n_tri_primary"] + 16 * st["primary_rays"]
+    shad = 32 * st["shadow_rays"] + 64 * st["n_int_shadow"] + 48 * st["n_tri_shadow"] + 4 * st["shadow_rays"]
+    shade = (24 + 12 + 144 + 48 + 80 * n_lights) * st["hit_pixels"] + 24 * st["primary_rays"]
+    return dict(primary=prim, shadow=shad, shade=shade, frame=prim + shad + shade)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--lights", type=int, default=1, choices=[1, 4])
+    ap.add_argument("--detail", type=float, default=1.0, help="scene detail (1.0 = the 262k-triangle config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from araytracingjourney_amd import renderer, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libart has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    sc = scenes.sponza_like(args.detail)
+    lights = scenes.sponza_lights(args.lights)
+    sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
+    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world))
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+    r.upload_state()
+
+    gathered = tiles = None
+    if world > 1:
+        owned, padded = r.shard_tile_count()
+        tiles = torch.zeros((padded, 32, 32, 4), dtype=torch.float32, device="cuda")
+        r.bind_color_tiles(tiles.data_ptr(), tiles.numel() * 4)
+        if rank == 0:
+            gathered = torch.empty((world, padded, 32, 32, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        r.trace()
+        if world > 1:
+            dist.gather(tiles, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                r.untile_gathered(gathered.data_ptr(), world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.collect_timings()  # drop the warm-up frames from the per-stage event sums
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    fence()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    stage, n_timed = r.collect_timings()  # HIP events on the same stream, over the timed frames (last <= 128)
+
+    st = r.stats()
+    rays_local = st["primary_rays"] + st["shadow_rays"]
+    t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["primary_ms"], stage["shadow_ms"], stage["shade_ms"], stage["frame_ms"]],
+                     dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        wall = float(tmax[0])
+        rays_total, shadow_total = float(tsum[1]), float(tsum[2])
+        stage_max = dict(primary_ms=float(tmax[3]), shadow_ms=float(tmax[4]), shade_ms=float(tmax[5]), frame_ms=float(tmax[6]))
+    else:
+        rays_total, shadow_total = float(rays_local), float(st["shadow_rays"])
+        stage_max = stage
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = wall * 1e3 / args.steps
+    value = rays_total / (wall / args.steps) / 1e6
+
+    # ---- algorithmic bytes: the oracle's canonical-LBVH visit counters for this exact frame
+    tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights))
+    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and args.detail == 1.0 else None
+    ost = json.load(open(fx)) if fx and os.path.exists(fx) else None
+
+    # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import orc
+        ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+        S = orc.Scene(sc.primitives, morton_bits=30)
+        cam = orc.camera_from_params(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
+        L = orc.make_lights(lights)
+        y0, y1 = (0, H) if ost is None else (H // 2 - H // 8, H // 2 + H // 8)   # whole frame when its counters are needed
+        S.render(cam, L, len(lights), W, H, y0, min(y0 + 8, y1), threads=ncores)       # warm-up band
+        c0 = time.perf_counter()
+        out = S.render(cam, L, len(lights), W, H, y0, y1, threads=ncores)
+        cdt = time.perf_counter() - c0
+        cst = out["stats"]
+        cpu = dict(value=(cst["primary_rays"] + cst["shadow_rays"]) / cdt / 1e6, unit="Mray/s", cores=ncores, kind="port",
+                   sample=f"rows [{y0},{y1}) of the same {W}x{H} frame ({cst['primary_rays'] + cst['shadow_rays']} rays, {cdt:.2f} s), "
+                          "scalar C oracle (stands in for the scalar Rust tracer: no Rust toolchain in this image), pthreads over 4-row bands")
+        if ost is None:
+            ost = cst
+    if ost is not None and world == 1:
+        assert ost["shadow_rays"] == st["shadow_rays"] and ost["hit_pixels"] == st["hit_pixels"], \
+            f"GPU ray counts differ from the oracle's: {st['shadow_rays']}/{st['hit_pixels']} vs {ost['shadow_rays']}/{ost['hit_pixels']}"
+
+    roof = None
+    if ost is not None:
+        ab = algorithmic_bytes(ost, args.lights)
+        dom = "primary" if stage_max["primary_ms"] >= stage_max["shadow_ms"] else "shadow"
+        kname = {"primary": "k_primary", "shadow": "k_shadow"}[dom]
+        dur_ms = stage_max[f"{dom}_ms"]
+        per_launch = ab[dom] / world  # each rank's launch handles 1/world of the frame's rays
+        achieved = per_launch / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        roof = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    algorithmic_bytes_per_launch=per_launch, kernel_ms=dur_ms, frames_timed=n_timed,
+                    frame_algorithmic_bytes=ab["frame"], frame_frac=ab["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    note="working set (BVH + triangles, ~30 MB) is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes")
+
+    line = {
+        "metric": "Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}",
+        "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"sponza_like(seed=0x5A0A, {sc.n_tris} triangles, 25 primitives) {W}x{H}, {args.lights} light(s), "
+                               f"{int(shadow_total)} shadow rays/frame", "width": W, "height": H, "lights": args.lights,
+                   "parallelism": "single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather to rank 0"},
+        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "device_ms_per_step_rank0": dev_ms / args.steps,
+        "stage_ms": stage_max, "build_ms": st["build_ms"],
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,10 +150,16 @@ int32_t art_device_normal(ArtContext *ctx, void **dev_ptr, size_t *bytes);
  * the un-tile step run by the root on the gathered buffer.  tile = 32x32 px, 16 KiB of RGBA32F each. */
 int32_t art_shard_tile_count(ArtContext *ctx, uint32_t *owned, uint32_t *padded);
 int32_t art_device_color_tiles(ArtContext *ctx, void **dev_ptr, size_t *bytes);
+/* render the compact tiles straight into a caller-owned device buffer (e.g. the tensor handed to the gather);
+ * bytes must equal padded * 16 KiB; NULL unbinds */
+int32_t art_bind_color_tiles(ArtContext *ctx, void *dev_ptr, size_t bytes);
 int32_t art_read_color_tiles(ArtContext *ctx, void *dst, size_t bytes); /* host copy of the same buffer (tests) */
 int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev);
 
 int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
+/* device time per stage (HIP events on the context's stream) summed over the frames traced since the previous call
+ * (at most the last 128): sums_ms = primary, shade, shadow, accumulate, whole frame */
+int32_t art_collect_timings(ArtContext *ctx, float sums_ms[5], uint32_t *n_frames);
 
 /* ---- parity / debug surface (not part of the reference's API; used by tests through this C ABI) ---- */
 /* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */
