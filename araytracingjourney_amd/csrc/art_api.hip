@@ -106,7 +106,7 @@ int32_t setup_frame(ArtContext *c) {
     size_t nl = c->lights.size() ? c->lights.size() : 1;
     HIPC(c->d_tile_list.ensure(c->tile_list.size()));
     if (!c->tile_list.empty()) HIPC(hipMemcpy(c->d_tile_list.p, c->tile_list.data(), c->tile_list.size() * 4, hipMemcpyHostToDevice));
-    HIPC(c->d_counters.ensure(16));
+    HIPC(c->d_counters.ensure(kCounterWords));
     HIPC(c->d_hits.ensure(c->n_local));
     HIPC(c->d_contrib.ensure(nl * c->n_local));
     HIPC(c->d_shadow_rays.ensure(2 * nl * c->n_local));
@@ -396,7 +396,7 @@ int32_t art_trace(ArtContext *c) {
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? c->d_shadow_bits.p : nullptr;
     hipStream_t s = c->stream;
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
-    HIPC(hipMemsetAsync(c->d_counters.p, 0, 16 * 4, s));
+    HIPC(hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, s));
     HIPC(hipEventRecord(ev[0], s));
     if (a.n_local) launch_primary(a, s);
     HIPC(hipEventRecord(ev[1], s));
@@ -581,7 +581,9 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     std::vector<float4> h(n);
     std::vector<DevTri> tris(c->T);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) { launch_query_closest(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = c->d_counters.ensure(kCounterWords);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, c->stream);
+    if (e == hipSuccess) { launch_query_closest(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);
@@ -607,7 +609,9 @@ int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit
     if (e != hipSuccess) { (void)hipFree(d_r); return hipfail(e, "hipMalloc"); }
     std::vector<uint32_t> h(n);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) { launch_query_any(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = c->d_counters.ensure(kCounterWords);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, c->stream);
+    if (e == hipSuccess) { launch_query_any(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_r); (void)hipFree(d_h);

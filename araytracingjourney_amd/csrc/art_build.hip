@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void k_emit_nodes(uint32_t T, const int32_t *_
         if (n == 0) {
             DevNode d;
             d.q[0] = make_float4(leaf_lo[0], leaf_lo[1], leaf_lo[2], leaf_hi[0]);
-            d.q[1] = make_float4(leaf_hi[1], leaf_hi[2], 3.0e38f, 3.0e38f);
-            d.q[2] = make_float4(3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            d.q[1] = make_float4(leaf_hi[1], leaf_hi[2], 3.0e38f, 3.0e38f); // a far-away point box: every slab test fails
+            d.q[2] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
             d.q[3] = make_float4(__int_as_float(~0), __int_as_float(~0), 0.f, 0.f);
             nodes[0] = d;
         }

@@ -64,8 +64,8 @@ struct FrameArgs {
     const ArtLight *lights; uint32_t n_lights;
     float4 *hits;              // [n_local] t,u,v,gid
     float4 *contrib;           // [n_lights][n_local]
-    float4 *shadow_rays;       // [2 * n_lights * n_local] o.xyz,tmax | d.xyz,slot
-    uint32_t *counters;        // [0] shadow ray count, [1] hit pixels, [2..] work cursors
+    float4 *shadow_rays;       // [2 * n_lights * n_local] dense per (light, pixel): o.xyz,tmax (<=0: none) | d.xyz,-
+    uint32_t *counters;        // kCounterWords, zeroed every frame
     float4 *color; float *depth; float4 *normal; // full frame, row-major
     float4 *color_tiles;       // compact [n_local] (sharded mode) or nullptr
     uint32_t *shadow_bits;     // debug, [n_local] or nullptr
@@ -74,8 +74,9 @@ void launch_primary(const FrameArgs &a, hipStream_t s);
 void launch_shade(const FrameArgs &a, hipStream_t s);
 void launch_shadow(const FrameArgs &a, hipStream_t s);
 void launch_accumulate(const FrameArgs &a, hipStream_t s);
-void launch_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits, hipStream_t s);
-void launch_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit, hipStream_t s);
+void launch_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
+void launch_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);
+constexpr uint32_t kCounterWords = 1024; // [0] shadow rays, [1] hit pixels, [64..] primary cursors, [64+256..] shadow cursors, [64+512..] query cursors
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s);
 
 // shard tile ownership: 32x32 tile (tx,ty) belongs to shard (tx + 5*ty) % count -- a diagonal interleave, so that

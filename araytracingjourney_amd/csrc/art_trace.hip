@@ -86,21 +86,33 @@ __device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v
 }
 
 constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], conflict-free); deeper entries spill to scratch
-constexpr int kOvfStack = 80;
+constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (63 key bits + 32 index bits)
 constexpr int kBlock = 256;
+constexpr int kChunk = 128;     // candidate slots a wave takes from the work cursor at a time
+constexpr int kRefill = 12;     // refill a wave's idle lanes once this many are idle (Aila & Laine 2009, dynamic fetch)
+constexpr int kCursorStride = 32; // one 128-byte line per XCD cursor
 
-struct Hit { float t, u, v; uint32_t pos; }; // pos = leaf-order triangle slot, kNoHit = none; gid compared for ties
+// local pixel id -> frame coordinates.  p = tile*1024 + sub*64 + lane; a wave covers an 8x8 pixel block.
+__device__ __forceinline__ bool local_to_xy(uint32_t p, const uint32_t *__restrict__ tile_list, uint32_t tiles_x, uint32_t W, uint32_t H, uint32_t &x, uint32_t &y) {
+    uint32_t tile = tile_list[p >> 10];
+    uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
+    x = (tile % tiles_x) * kTile + (sub & 3u) * 8u + (l & 7u);
+    y = (tile / tiles_x) * kTile + (sub >> 2) * 8u + (l >> 3);
+    return x < W && y < H;
+}
 
-// Binary-LBVH traversal.  ANY: stop at the first accepted triangle.
-template <bool ANY>
-__device__ __forceinline__ void traverse(const DevNode *__restrict__ nodes, const DevTri *__restrict__ tris, const Ray &r, int *lds /* &stack[0][lane] */,
-                                         Hit &best, uint32_t &best_gid) {
-    int ovf[kOvfStack];
-    int sp = 0;
-    int node = 0;
-    float tbest = r.tmax;
-    best.t = r.tmax; best.u = 0.f; best.v = 0.f; best.pos = kNoHit; best_gid = kNoHit;
-    for (;;) {
+// One ray's traversal state over the binary LBVH; step() visits one node (both child boxes, leaf triangles at once).
+template <bool ANY> struct Trav {
+    Ray r;
+    float tbest, bu, bv;
+    uint32_t bpos, bgid;
+    int node, sp;
+    __device__ __forceinline__ void start(V3 o, V3 d, float tmin, float tmax) {
+        ray_init(r, o, d, tmin, tmax);
+        tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; node = 0; sp = 0;
+    }
+    // returns true when the ray is finished
+    __device__ __forceinline__ bool step(const DevNode *__restrict__ nodes, const DevTri *__restrict__ tris, int *lds, int *ovf) {
         const float4 *nq = reinterpret_cast<const float4 *>(nodes + node);
         float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
         int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
@@ -118,12 +130,10 @@ __device__ __forceinline__ void traverse(const DevNode *__restrict__ nodes, cons
                 float4 a = tq[0], b = tq[1], cc = tq[2];
                 float t, u, v;
                 if (moller_trumbore(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t, u, v)) {
-                    if (ANY) { best.pos = pos; best.t = t; return; }
+                    if (ANY) { bpos = pos; tbest = t; return true; }
                     float teff = fmaxf(t, te);
                     uint32_t gid = __float_as_uint(cc.w);
-                    if (teff < tbest || (teff == tbest && gid < best_gid)) {
-                        tbest = teff; best.t = teff; best.u = u; best.v = v; best.pos = pos; best_gid = gid;
-                    }
+                    if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
                 }
             }
         }
@@ -136,55 +146,127 @@ __device__ __forceinline__ void traverse(const DevNode *__restrict__ nodes, cons
             bool first0 = te0 <= te1;
             int far = first0 ? c1 : c0;
             node = first0 ? c0 : c1;
-            if (sp < kLdsStack) lds[sp * kBlock] = far; else ovf[sp - kLdsStack] = far;
-            sp++;
+            if (sp < kLdsStack) lds[sp * kBlock] = far; else if (sp < kLdsStack + kOvfStack) ovf[sp - kLdsStack] = far;
+            sp = min(sp + 1, kLdsStack + kOvfStack); // the radix tree cannot be deeper (95 levels); never index past the spill area
         } else if (g0) node = c0;
         else if (g1) node = c1;
         else {
-            if (sp == 0) return;
+            if (sp == 0) return true;
             sp--;
             node = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
         }
+        return false;
     }
-}
+};
 
-// local pixel id -> frame coordinates.  p = tile*1024 + sub*64 + lane; a wave covers an 8x8 pixel block.
-__device__ __forceinline__ bool local_to_xy(uint32_t p, const uint32_t *__restrict__ tile_list, uint32_t tiles_x, uint32_t W, uint32_t H, uint32_t &x, uint32_t &y) {
-    uint32_t tile = tile_list[p >> 10];
-    uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
-    x = (tile % tiles_x) * kTile + (sub & 3u) * 8u + (l & 7u);
-    y = (tile / tiles_x) * kTile + (sub >> 2) * 8u + (l >> 3);
-    return x < W && y < H;
-}
+// what a persistent tracing wave reads its rays from and writes its results to
+enum { MODE_PRIMARY = 0, MODE_SHADOW = 1, MODE_QUERY_CLOSEST = 2, MODE_QUERY_ANY = 3 };
+struct TraceArgs {
+    const DevNode *nodes; const DevTri *tris;
+    uint32_t total;          // candidate slots
+    uint32_t *cursors;       // 8 per-XCD chunk cursors, kCursorStride words apart (zeroed before the launch)
+    uint32_t *count;         // rays actually traced (MODE_SHADOW), may be null
+    // MODE_PRIMARY
+    CameraArg cam; uint32_t W, H; const uint32_t *tile_list; uint32_t tiles_x;
+    float4 *hits;
+    // MODE_SHADOW / MODE_QUERY_*: rays[2*slot] = o.xyz,tmax(<=0: no ray) | rays[2*slot+1] = d.xyz,tmin (queries) / unused
+    const float4 *rays;
+    float4 *contrib; uint32_t n_local; uint32_t *shadow_bits;
+    uint32_t *any_out;
+};
 
-// XCD-aware block remap: blocks are dealt round-robin to the 8 XCDs, so give each XCD a contiguous run of work
-// (neighbouring screen tiles traverse the same BVH region and share that XCD's L2).  Speed only.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
-    uint32_t per = nb >> 3;
-    if (per == 0 || b >= per * 8u) return b;
-    return (b & 7u) * per + (b >> 3);
-}
-
-// raytrace.rgen.glsl:78-101 + rchit/rmiss: primary ray, closest hit
-__global__ __launch_bounds__(kBlock) void k_primary(FrameArgs a) {
+// Persistent-threads wavefront tracer.  Each wave keeps up to 64 rays in flight; when kRefill or more lanes have
+// finished it compacts the idle lanes with __ballot / mbcnt and hands them the next candidates of its chunk; chunks
+// come from eight per-XCD work cursors (one returning atomic per chunk), so neighbouring rays stay on one XCD's L2.
+// Every wave exits once all cursors are exhausted and its lanes are idle.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
+    constexpr bool ANY = MODE == MODE_SHADOW || MODE == MODE_QUERY_ANY;
     __shared__ int stack[kLdsStack * kBlock];
-    uint32_t p = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    if (p >= a.n_local) return;
-    uint32_t x, y;
-    float4 out = make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
-    if (local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y)) {
-        float px = (float)x + 0.5f, py = (float)y + 0.5f;
-        float ux = px / (float)a.W, uy = py / (float)a.H;
-        float dx = ux * 2.0f - 1.0f, dy = uy * 2.0f - 1.0f;
-        V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
-        V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
-        V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
-        Ray r; ray_init(r, org, dir, 0.001f, 10000.0f);
-        Hit h; uint32_t gid;
-        traverse<false>(a.nodes, a.tris, r, &stack[threadIdx.x], h, gid);
-        if (h.pos != kNoHit) out = make_float4(h.t, h.u, h.v, __uint_as_float(h.pos));
+    int ovf[kOvfStack];
+    int *lds = &stack[threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_chunks = (a.total + kChunk - 1) / kChunk; // <= 2^25, so n_chunks * 8 fits
+
+    uint32_t shard = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; // HW_REG_XCC_ID: speed only
+    uint32_t shards_left = 8;
+    uint32_t cur = 0, end = 0; // wave-uniform: the unread part of this wave's chunk
+    bool exhausted = false, active = false;
+    Trav<ANY> tr;
+    uint32_t slot = 0, traced = 0;
+    for (;;) {
+        uint64_t idle = __ballot(!active);
+        uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!exhausted && n_idle >= (uint32_t)kRefill) {
+            if (cur == end) { // take the next chunk: lane 0 pops, everyone learns the result
+                uint32_t got = 0xFFFFFFFFu;
+                if (lane == 0) {
+                    while (shards_left) { // shard s owns chunks [n*s/8, n*(s+1)/8): contiguous, so an XCD keeps a screen region
+                        uint32_t lo = (n_chunks * shard) >> 3, hi = (n_chunks * (shard + 1u)) >> 3;
+                        uint32_t c = hi > lo ? atomicAdd(&a.cursors[shard * kCursorStride], 1u) : 0u;
+                        if (hi > lo && c < hi - lo) { got = lo + c; break; }
+                        shard = (shard + 1u) & 7u; shards_left--;
+                    }
+                }
+                got = __builtin_amdgcn_readfirstlane(got);
+                shard = __builtin_amdgcn_readfirstlane(shard);
+                shards_left = __builtin_amdgcn_readfirstlane(shards_left);
+                if (got >= n_chunks) exhausted = true; // (also the never-expected out-of-range pop: no slot beyond total is touched)
+                else { cur = got * kChunk; end = min(cur + (uint32_t)kChunk, a.total); }
+            }
+            if (!exhausted) {
+                uint32_t avail = end - cur;
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!active && rank < avail) {
+                    uint32_t sidx = cur + rank;
+                    if (MODE == MODE_PRIMARY) {
+                        uint32_t x, y;
+                        if (local_to_xy(sidx, a.tile_list, a.tiles_x, a.W, a.H, x, y)) { // raytrace.rgen.glsl:78-88
+                            float px = (float)x + 0.5f, py = (float)y + 0.5f;
+                            float ux = px / (float)a.W, uy = py / (float)a.H;
+                            float dx = ux * 2.0f - 1.0f, dy = uy * 2.0f - 1.0f;
+                            V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
+                            V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
+                            V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
+                            tr.start(org, dir, 0.001f, 10000.0f);
+                            active = true;
+                        } else a.hits[sidx] = make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+                    } else {
+                        float4 r0 = a.rays[2 * (size_t)sidx];
+                        if (MODE != MODE_SHADOW || r0.w > 0.0f) {
+                            float4 r1 = a.rays[2 * (size_t)sidx + 1];
+                            // shadow rays: tmin 0.01 (raytrace.rgen.glsl:174); queries carry their own tmin
+                            if (MODE == MODE_SHADOW) tr.start(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), 0.01f, r0.w);
+                            else tr.start(mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, r1.w);
+                            active = true;
+                        }
+                    }
+                    if (active) { slot = sidx; traced++; }
+                }
+                cur += min(n_idle, avail);
+            }
+            if (__ballot(active) == 0ull) continue; // nothing to trace yet: fetch again (or find the cursors exhausted)
+        } else if (n_idle == 64u) {
+            if (exhausted) break;
+            continue;
+        }
+        if (active && tr.step(a.nodes, a.tris, lds, ovf)) {
+            active = false;
+            if (MODE == MODE_PRIMARY || MODE == MODE_QUERY_CLOSEST)
+                a.hits[slot] = tr.bpos != kNoHit ? make_float4(tr.tbest, tr.bu, tr.bv, __uint_as_float(tr.bpos))
+                                                 : make_float4(MODE == MODE_PRIMARY ? 10000.0f : tr.r.tmax, 0.f, 0.f, __uint_as_float(kNoHit));
+            else if (MODE == MODE_QUERY_ANY) a.any_out[slot] = tr.bpos != kNoHit ? 1u : 0u;
+            else if (tr.bpos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
+                float4 c = a.contrib[slot];
+                a.contrib[slot] = make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w);
+                if (a.shadow_bits) { uint32_t i = slot / a.n_local; if (i < 16) atomicOr(&a.shadow_bits[slot - i * a.n_local], 1u << i); }
+            }
+        }
     }
-    a.hits[p] = out;
+    if (MODE == MODE_SHADOW && a.count) { // rays this wave traced: one atomic per wave
+        for (int off = 32; off >= 1; off >>= 1) traced += (uint32_t)__shfl_xor((int)traced, off);
+        if (lane == 0 && traced) atomicAdd(a.count, traced);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ lights (light.glsl)
@@ -293,15 +375,19 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= a.n_local) return;
     uint32_t x, y;
-    if (!local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y)) return;
+    bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
     size_t pix = (size_t)y * a.W + x;
     float4 h = a.hits[p];
-    uint32_t pos = __float_as_uint(h.w);
+    uint32_t pos = in ? __float_as_uint(h.w) : kNoHit;
     float out_depth = 10000.0f;
     V3 out_normal = mk(0.5f, 0.5f, 0.5f);
     uint32_t sbits = 0;
     if (pos == kNoHit) {
-        for (uint32_t i = 0; i < a.n_lights; i++) a.contrib[(size_t)i * a.n_local + p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t i = 0; i < a.n_lights; i++) {
+            size_t slot = (size_t)i * a.n_local + p;
+            a.contrib[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a.shadow_rays[2 * slot] = make_float4(0.f, 0.f, 0.f, -1.0f); // no shadow ray in this slot
+        }
     } else {
         const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
         uint32_t pi = __float_as_uint(tq[0].w), tri = __float_as_uint(tq[1].w);
@@ -352,12 +438,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
             V3 c = (rho_s + rho_d) * rad;
             size_t slot = (size_t)i * a.n_local + p;
             a.contrib[slot] = make_float4(c.x, c.y, c.z, NdotL);
-            if (l.casts_shadows && nc_NdotL > 0.0f) { // raytrace.rgen.glsl:165
-                uint32_t q = atomicAdd(&a.counters[0], 1u);
-                a.shadow_rays[2 * (size_t)q] = make_float4(world_pos.x, world_pos.y, world_pos.z, len3(nn_L));
-                a.shadow_rays[2 * (size_t)q + 1] = make_float4(L.x, L.y, L.z, __uint_as_float((uint32_t)slot));
+            if (l.casts_shadows && nc_NdotL > 0.0f) { // raytrace.rgen.glsl:165: origin world_pos, dir L, tmax length(nn_L)
+                a.shadow_rays[2 * slot] = make_float4(world_pos.x, world_pos.y, world_pos.z, len3(nn_L));
+                a.shadow_rays[2 * slot + 1] = make_float4(L.x, L.y, L.z, 0.f);
                 if (i < 16) sbits |= 1u << (16 + i);
-            }
+            } else a.shadow_rays[2 * slot] = make_float4(0.f, 0.f, 0.f, -1.0f);
         }
         V3 vp = mat4_mul(a.cam.view, world_pos.x, world_pos.y, world_pos.z, 1.0f);
         out_depth = -vp.z;
@@ -366,30 +451,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
         on.y = -on.y; on.z = -on.z;
         on = nrm3(on);
         out_normal = mk(on.x * 0.5f + 0.5f, on.y * 0.5f + 0.5f, on.z * 0.5f + 0.5f);
-        atomicAdd(&a.counters[1], 1u);
     }
-    a.depth[pix] = out_depth;
-    a.normal[pix] = make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f);
+    if (in) {
+        a.depth[pix] = out_depth;
+        a.normal[pix] = make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f);
+    }
     if (a.shadow_bits) a.shadow_bits[p] = sbits;
-}
-
-// shadow traceRayEXT (raytrace.rgen.glsl:167-181): TerminateOnFirstHit | Opaque | SkipClosestHit, tmin 0.01;
-// a shadowed light keeps 0.05 of its contribution
-__global__ __launch_bounds__(kBlock) void k_shadow(FrameArgs a) {
-    __shared__ int stack[kLdsStack * kBlock];
-    uint32_t n = a.counters[0];
-    uint32_t q = xcd_remap(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    if (q >= n) return;
-    float4 r0 = a.shadow_rays[2 * (size_t)q], r1 = a.shadow_rays[2 * (size_t)q + 1];
-    Ray r; ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), 0.01f, r0.w);
-    Hit h; uint32_t gid;
-    traverse<true>(a.nodes, a.tris, r, &stack[threadIdx.x], h, gid);
-    if (h.pos != kNoHit) {
-        uint32_t slot = __float_as_uint(r1.w);
-        float4 c = a.contrib[slot];
-        a.contrib[slot] = make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w);
-        if (a.shadow_bits) { uint32_t i = slot / a.n_local; if (i < 16) atomicOr(&a.shadow_bits[slot - i * a.n_local], 1u << i); }
-    }
+    uint64_t hitmask = __ballot(pos != kNoHit); // hit-pixel count: one atomic per wave, off the critical path
+    if ((threadIdx.x & 63u) == 0 && hitmask) atomicAdd(&a.counters[1], (uint32_t)__popcll(hitmask));
 }
 
 // rho += (rho_s + rho_d) * radiance * shadow_attenuation * NdotL (raytrace.rgen.glsl:185), lights in order
@@ -431,41 +500,40 @@ __global__ __launch_bounds__(kBlock) void k_untile(const float4 *__restrict__ ga
     frame[(size_t)y * W + x] = gathered[((size_t)s * padded + j) * kTilePixels + (y % kTile) * kTile + (x % kTile)];
 }
 
-__global__ __launch_bounds__(kBlock) void k_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits) {
-    __shared__ int stack[kLdsStack * kBlock];
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
-    Ray r; ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, r1.w);
-    Hit h; uint32_t gid;
-    traverse<false>(nodes, tris, r, &stack[threadIdx.x], h, gid);
-    hits[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.pos));
-}
-__global__ __launch_bounds__(kBlock) void k_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit) {
-    __shared__ int stack[kLdsStack * kBlock];
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float4 r0 = rays[2 * (size_t)i], r1 = rays[2 * (size_t)i + 1];
-    Ray r; ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), r0.w, r1.w);
-    Hit h; uint32_t gid;
-    traverse<true>(nodes, tris, r, &stack[threadIdx.x], h, gid);
-    hit[i] = h.pos != kNoHit ? 1u : 0u;
-}
-
 // ------------------------------------------------------------------------------------------------ launchers
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
-void launch_primary(const FrameArgs &a, hipStream_t s) { k_primary<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
+// persistent grid: enough waves to fill the chip (8 blocks of 4 waves per CU), never more than the work needs
+static inline uint32_t persistent_blocks(uint32_t total) {
+    uint32_t need = (total + kBlock - 1) / kBlock;
+    return need < 2048u ? (need ? need : 1u) : 2048u;
+}
+void launch_primary(const FrameArgs &f, hipStream_t s) {
+    TraceArgs a{};
+    a.nodes = f.nodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
+    a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
+    k_trace<MODE_PRIMARY><<<persistent_blocks(a.total), kBlock, 0, s>>>(a);
+}
 void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
-void launch_shadow(const FrameArgs &a, hipStream_t s) {
-    if (a.n_lights == 0) return;
-    k_shadow<<<blocks_for(a.n_local * a.n_lights), kBlock, 0, s>>>(a);
+void launch_shadow(const FrameArgs &f, hipStream_t s) {
+    if (f.n_lights == 0) return;
+    TraceArgs a{};
+    a.nodes = f.nodes; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters;
+    a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
+    k_trace<MODE_SHADOW><<<persistent_blocks(a.total), kBlock, 0, s>>>(a);
 }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
-void launch_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits, hipStream_t s) {
-    if (n) k_query_closest<<<blocks_for(n), kBlock, 0, s>>>(nodes, tris, rays, n, hits);
+// queries: rays[2i] = o.xyz,tmin | rays[2i+1] = d.xyz,tmax;  cursors: 8 * kCursorStride zeroed words
+void launch_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s) {
+    if (!n) return;
+    TraceArgs a{};
+    a.nodes = nodes; a.tris = tris; a.total = n; a.cursors = cursors; a.rays = rays; a.hits = hits;
+    k_trace<MODE_QUERY_CLOSEST><<<persistent_blocks(n), kBlock, 0, s>>>(a);
 }
-void launch_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit, hipStream_t s) {
-    if (n) k_query_any<<<blocks_for(n), kBlock, 0, s>>>(nodes, tris, rays, n, hit);
+void launch_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s) {
+    if (!n) return;
+    TraceArgs a{};
+    a.nodes = nodes; a.tris = tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
+    k_trace<MODE_QUERY_ANY><<<persistent_blocks(n), kBlock, 0, s>>>(a);
 }
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
     dim3 g((W + 31) / 32, (H + 7) / 8);

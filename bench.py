@@ -63,7 +63,8 @@ def main():
     lights = scenes.sponza_lights(args.lights)
     sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
     r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world))
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()      # a real (non-null) stream shared by libart's kernels, torch's events and RCCL's waits
+    torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
     r.upload_state()
 
@@ -139,15 +140,22 @@ def main():
         S = orc.Scene(sc.primitives, morton_bits=30)
         cam = orc.camera_from_params(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
         L = orc.make_lights(lights)
-        y0, y1 = (0, H) if ost is None else (H // 2 - H // 8, H // 2 + H // 8)   # whole frame when its counters are needed
-        S.render(cam, L, len(lights), W, H, y0, min(y0 + 8, y1), threads=ncores)       # warm-up band
+        S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)       # warm-up frame
+        reps, cdt, cst = 0, 0.0, None
         c0 = time.perf_counter()
-        out = S.render(cam, L, len(lights), W, H, y0, y1, threads=ncores)
-        cdt = time.perf_counter() - c0
-        cst = out["stats"]
-        cpu = dict(value=(cst["primary_rays"] + cst["shadow_rays"]) / cdt / 1e6, unit="Mray/s", cores=ncores, kind="port",
-                   sample=f"rows [{y0},{y1}) of the same {W}x{H} frame ({cst['primary_rays'] + cst['shadow_rays']} rays, {cdt:.2f} s), "
-                          "scalar C oracle (stands in for the scalar Rust tracer: no Rust toolchain in this image), pthreads over 4-row bands")
+        while cdt < 10.0 and reps < 400:   # the same whole frame, repeated for ~10 s of wall clock
+            cst = S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)["stats"]
+            reps += 1
+            cdt = time.perf_counter() - c0
+        rays1 = cst["primary_rays"] + cst["shadow_rays"]
+        c1 = time.perf_counter()
+        st1 = S.render(cam, L, len(lights), W, H, H // 2 - 16, H // 2 + 16, threads=1)["stats"]   # one thread, a 32-row band
+        dt1 = time.perf_counter() - c1
+        cpu = dict(value=rays1 * reps / cdt / 1e6, unit="Mray/s", cores=ncores, kind="port",
+                   value_1thread=(st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6,
+                   sample=f"the same {W}x{H} frame x {reps} repetitions ({rays1} rays each, {cdt:.1f} s wall) on {ncores} threads; 1-thread figure "
+                          f"on rows [{H // 2 - 16},{H // 2 + 16}) ({dt1:.1f} s); scalar C oracle (stands in for the scalar Rust tracer: no Rust "
+                          "toolchain in this image), pthreads over 4-row bands")
         if ost is None:
             ost = cst
     if ost is not None and world == 1:

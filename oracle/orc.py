@@ -173,11 +173,16 @@ class Scene:
         self._L.orc_trace_any(self.h, _ptr(rays), n, mode, _ptr(hit), C.byref(ni), C.byref(nt))
         return hit, int(ni.value), int(nt.value)
 
-    def render(self, cam: OrcCamera, lights, n_lights, w, h, y0=0, y1=None, threads=1, debug=False):
+    def render(self, cam: OrcCamera, lights, n_lights, w, h, y0=0, y1=None, threads=1, debug=False, reuse=False):
         y1 = h if y1 is None else y1
-        color = np.zeros((h, w, 4), np.float32)
-        depth = np.zeros((h, w), np.float32)
-        normal = np.zeros((h, w, 4), np.float32)
+        if reuse and getattr(self, "_bufs", None) is not None and self._bufs[0].shape == (h, w, 4):
+            color, depth, normal = self._bufs          # timing loops: do not page-fault 75 MB of fresh output per frame
+        else:
+            color = np.zeros((h, w, 4), np.float32)
+            depth = np.zeros((h, w), np.float32)
+            normal = np.zeros((h, w, 4), np.float32)
+            if reuse:
+                self._bufs = (color, depth, normal)
         tuv = np.zeros((h, w, 4), np.float32) if debug else None
         ids = np.zeros((h, w, 2), np.int32) if debug else None
         sb = np.zeros((h, w), np.uint32) if debug else None
