@@ -443,6 +443,24 @@ int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_p
 int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
 int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->d_normal.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 
+int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t *tiles, uint32_t cap, uint32_t *owned, uint32_t *padded) {
+    if (width == 0 || height == 0) return fail(ART_E_INVALID, "art_shard_layout: zero extent");
+    uint32_t count = shard_count > 1 ? shard_count : 1;
+    if (shard_rank >= count) return fail(ART_E_INVALID, "art_shard_layout: shard_rank >= shard_count");
+    uint32_t tx_n = (width + kTile - 1) / kTile, ty_n = (height + kTile - 1) / kTile, mine = 0;
+    std::vector<uint32_t> per(count, 0);
+    for (uint32_t ty = 0; ty < ty_n; ty++)
+        for (uint32_t tx = 0; tx < tx_n; tx++) {
+            uint32_t o = tile_owner(tx, ty, count);
+            per[o]++;
+            if (o == shard_rank) { if (tiles && mine < cap) tiles[mine] = ty * tx_n + tx; mine++; }
+        }
+    if (tiles && mine > cap) return fail(ART_E_INVALID, "art_shard_layout: tiles buffer too small");
+    uint32_t mx = 0; for (uint32_t v : per) mx = v > mx ? v : mx;
+    if (owned) *owned = mine;
+    if (padded) *padded = mx;
+    return ART_OK;
+}
 int32_t art_shard_tile_count(ArtContext *c, uint32_t *owned, uint32_t *padded) {
     if (!c) return fail(ART_E_INVALID, "art_shard_tile_count: null context");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_shard_tile_count"); if (r) return r;

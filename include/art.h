@@ -149,6 +149,11 @@ int32_t art_device_normal(ArtContext *ctx, void **dev_ptr, size_t *bytes);
 /* screen-tile sharding (new functionality, BASELINE.json): compact per-shard colour tiles for the RCCL gather, and
  * the un-tile step run by the root on the gathered buffer.  tile = 32x32 px, 16 KiB of RGBA32F each. */
 int32_t art_shard_tile_count(ArtContext *ctx, uint32_t *owned, uint32_t *padded);
+/* host-only (no device needed): the row-major ids of the tiles shard_rank owns for a width x height frame, in the
+ * order they sit in its compact buffer; *owned = their number, *padded = the largest count over all shards (the
+ * per-rank gather size).  tiles may be NULL to query the counts; cap = capacity of tiles. */
+int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t *tiles,
+                         uint32_t cap, uint32_t *owned, uint32_t *padded);
 int32_t art_device_color_tiles(ArtContext *ctx, void **dev_ptr, size_t *bytes);
 /* render the compact tiles straight into a caller-owned device buffer (e.g. the tensor handed to the gather);
  * bytes must equal padded * 16 KiB; NULL unbinds */

@@ -1,0 +1,179 @@
+"""Independent numpy restatement of the reference's shading maths, written from the GLSL
+(/root/reference/src/vk_renderer/shaders/rt_lightning_shadows/raytrace.rgen.glsl:106-199, light.glsl, brdfs.glsl),
+NOT from the C oracle: it exists to catch transcription errors the oracle and the HIP kernels could share.
+float64 throughout; one pixel at a time is fine at the sizes the tests use."""
+import math
+
+import numpy as np
+
+PI = 3.14159265359
+
+
+def normalize(v):
+    return v / np.sqrt(np.dot(v, v))
+
+
+def mix(x, y, a):
+    return x * (1.0 - a) + y * a
+
+
+def clamp(x, lo, hi):
+    return min(max(x, lo), hi)
+
+
+def texture(tex_layer, uv):
+    """sampler2DArray layer, linear filter, REPEAT, LOD 0 (vk_rt_descriptor_set.rs:42-56)"""
+    th, tw = tex_layer.shape[:2]
+    x, y = uv[0] * tw - 0.5, uv[1] * th - 0.5
+    x0, y0 = math.floor(x), math.floor(y)
+    fx, fy = x - x0, y - y0
+    t = lambda xx, yy: tex_layer[yy % th, xx % tw].astype(np.float64) / 255.0
+    return (t(x0, y0) * (1 - fx) + t(x0 + 1, y0) * fx) * (1 - fy) + (t(x0, y0 + 1) * (1 - fx) + t(x0 + 1, y0 + 1) * fx) * fy
+
+
+def D_GGX(roughness, NdotH):
+    a = NdotH * roughness
+    k = roughness / (1.0 - NdotH * NdotH + a * a)
+    return k * k * (1.0 / PI)
+
+
+def V_SmithGGXCorrelated_fast(roughness, NdotV, NdotL):
+    return 0.5 / mix(2 * NdotL * NdotV, NdotL + NdotV, roughness)
+
+
+def F_Schlick(F0, F90, x):
+    return F0 + (F90 - F0) * (1.0 - x) ** 5.0
+
+
+def Burley_diffuse_local_sss(roughness, NdotV, nc_NdotV, nc_NdotL, LdotH, ratio):
+    F_SS90 = roughness * LdotH * LdotH
+    F_SS = F_Schlick(1.0, F_SS90, nc_NdotL) * F_Schlick(1.0, F_SS90, nc_NdotV)
+    f_ss = (1.0 / (nc_NdotV * nc_NdotL) - 0.5) * F_SS + 0.5
+    local_sss = 1.25 * ratio * f_ss
+    f90 = 0.5 + 2.0 * F_SS90
+    diffuse = (1.0 - ratio) * F_Schlick(1.0, f90, nc_NdotL) * F_Schlick(1.0, f90, nc_NdotV)
+    return NdotV * (diffuse + local_sss) * (1.0 / PI)
+
+
+def compute_barycentric(a, b, c, p):
+    v0, v1, v2 = b - a, c - a, p - a
+    d00, d01, d11, d20, d21 = v0 @ v0, v0 @ v1, v1 @ v1, v2 @ v0, v2 @ v1
+    denom = d00 * d11 - d01 * d01
+    x = (d11 * d20 - d01 * d21) / denom
+    y = (d00 * d21 - d01 * d20) / denom
+    return np.array([x, y, 1 - x - y])
+
+
+def closest_point_to_segment(p0, p1, p):
+    v = p1 - p0
+    t = clamp(((p - p0) @ v) / (v @ v), 0.0, 1.0)
+    return p0 + t * v
+
+
+def closest_point_to_triangle(p0, p1, p2, pt):
+    b = compute_barycentric(p0, p1, p2, pt)
+    if b[0] < 0:
+        return closest_point_to_segment(p2, p0, pt)
+    elif b[2] < 0:
+        return closest_point_to_segment(p1, p2, pt)
+    return pt
+
+
+def get_unnormalized_L_vec(light, pos):
+    t = light["type"]
+    if t in (0, 1):
+        return light["pos"] - pos
+    if t == 2:
+        return -light["dir"] * 10.0
+    if t == 3:
+        distance = light["dir"] @ light["area_pos2"] - light["dir"] @ pos
+        cp = pos + distance * light["dir"]
+        b = compute_barycentric(light["pos"], light["area_pos2"], light["area_pos3"], cp)
+        if b[0] < 0:
+            pos4 = light["pos"] - light["area_pos2"] + light["area_pos3"]
+            c = closest_point_to_triangle(light["pos"], light["area_pos3"], pos4, cp)
+        elif b[1] < 0:
+            c = closest_point_to_segment(light["pos"], light["area_pos2"], cp)
+        elif b[2] < 0:
+            c = closest_point_to_segment(light["area_pos2"], light["area_pos3"], cp)
+        else:
+            c = cp
+        return c - pos
+    return np.ones(3)
+
+
+def get_light_radiance(light, pos, L):
+    rad = light["color"].copy()
+    if light["type"] in (1, 3):
+        theta = math.acos(clamp(light["dir"] @ (-L), -1.0, 1.0))
+        with np.errstate(divide="ignore", invalid="ignore"):   # penumbra == umbra (main.rs:62) divides by zero, as in GLSL
+            q = np.float64(theta - light["umbra"]) / np.float64(light["penumbra"] - light["umbra"])
+        t = clamp(q, 0.0, 1.0)
+        rad = rad * t ** 2.0
+    if light["falloff"] > 0:
+        dist = np.linalg.norm(light["pos"] - pos)
+        rad = rad * max(1 - (dist / light["falloff"]) ** 2.0, 0.0) ** 2.0
+    return rad
+
+
+def light_from_record(rec):
+    """rec: an 80-byte light record as a ctypes struct (either library's)"""
+    f = lambda a: np.array(list(a), dtype=np.float64)
+    return dict(pos=f(rec.pos), type=int(rec.type), dir=f(rec.dir), casts=bool(rec.casts_shadows), color=f(rec.color), falloff=float(rec.falloff_distance),
+                area_pos2=f(rec.area_pos2), penumbra=float(rec.penumbra_angle), area_pos3=f(rec.area_pos3), umbra=float(rec.umbra_angle))
+
+
+def shade_pixel(prim, tri, u, v, cam_view, cam_view_inv, camera_pos, lights, shadowed_bits):
+    """prim: scenes.Primitive; cam_*: 4x4 numpy (row, col); returns (color3, depth, normal3, shadow_ray_mask)"""
+    i0, i1, i2 = [int(x) for x in prim.indices[3 * tri:3 * tri + 3]]
+    V = prim.verts.astype(np.float64)
+    v0, v1, v2 = V[i0], V[i1], V[i2]
+    bary = np.array([1.0 - u - v, u, v])
+    M = np.vstack([prim.model.astype(np.float64).reshape(3, 4), [0, 0, 0, 1]])   # object -> world
+    Minv = np.linalg.inv(M)
+    interp = lambda a, b: v0[a:b] * bary[0] + v1[a:b] * bary[1] + v2[a:b] * bary[2]
+    pos = interp(0, 3)
+    world_pos = (M @ np.append(pos, 1.0))[:3]
+    tex_coord = interp(3, 5)
+    normal = normalize(interp(5, 8))
+    world_normal = normalize((normal @ Minv[:3, :3]))            # normal * world_to_object
+    tangent = normalize(interp(8, 11))
+    world_tangent = normalize(M[:3, :3] @ tangent)
+    world_tangent = normalize(world_tangent - (world_tangent @ world_normal) * world_normal)
+    world_binormal = np.cross(world_normal, world_tangent) * v0[11]
+    tbn = np.stack([world_tangent, world_binormal, world_normal], axis=1)
+    N = normalize(texture(prim.tex[2], tex_coord)[:3] * 2.0 - 1.0)
+    N = normalize(tbn @ N)
+    albedo = texture(prim.tex[0], tex_coord)[:3] ** 2.2
+    orm = texture(prim.tex[1], tex_coord)
+    roughness, metallic = orm[1], orm[2]
+    Vv = normalize(camera_pos - world_pos)
+    F0 = mix(np.full(3, 0.04), albedo, metallic)
+    cr = roughness * roughness
+    nc_NdotV = N @ Vv
+    NdotV = clamp(nc_NdotV, 1e-5, 1.0)
+    rho = np.zeros(3)
+    mask = 0
+    for i, l in enumerate(lights):
+        nn_L = get_unnormalized_L_vec(l, world_pos)
+        L = normalize(nn_L)
+        H = normalize(Vv + L)
+        nc_NdotL = N @ L
+        NdotL = clamp(nc_NdotL, 0.0, 1.0)
+        NdotH = clamp(N @ H, 0.0, 1.0)
+        LdotH = clamp(L @ H, 0.0, 1.0)
+        Ks = F_Schlick(F0, 1.0, LdotH)
+        Kd = (1.0 - metallic) * albedo
+        rho_s = D_GGX(cr, NdotH) * V_SmithGGXCorrelated_fast(cr, NdotV, NdotL) * Ks
+        rho_d = Kd * Burley_diffuse_local_sss(cr, NdotV, nc_NdotV, nc_NdotL, LdotH, 0.4)
+        att = 1.0
+        if l["casts"] and nc_NdotL > 0:
+            mask |= 1 << (16 + i)
+            if shadowed_bits >> i & 1:
+                att = 0.05
+        rho = rho + (rho_s + rho_d) * get_light_radiance(l, world_pos, L) * att * NdotL
+    depth = -(cam_view @ np.append(world_pos, 1.0))[2]
+    on = cam_view_inv[:3, :3].T @ N           # mat3(transpose(view_inv)) * N
+    on[1:] = -on[1:]
+    on = normalize(on) * 0.5 + 0.5
+    return rho, depth, on, mask

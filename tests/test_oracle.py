@@ -1,0 +1,305 @@
+"""CPU tests of the oracle itself (oracle/ is test infrastructure; PARITY UNPINNED -- the reference holds no golden
+vectors for this path, so the oracle is pinned by analytic known answers, a brute-force cross-check, invariants, the
+committed fixtures and an independent numpy restatement of the shading)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import np_shading as NP
+from conftest import assert_radiance_close
+from helpers import oracle_camera, oracle_for, random_rays
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ------------------------------------------------------------------------------------------------ camera
+def test_camera_block_closed_form(orc):
+    cam = orc.camera_from_params((0, 0, 0), (0, 0, 1), 1.0, math.pi / 2, 0.1, 1000.0)   # renderer.rs:222-231 defaults
+    view = np.array(cam.view, np.float64).reshape(4, 4).T
+    # eye 0, dir +Z, up -Y  =>  view-x = world-x, view-y = -world-y, camera looks down world +Z
+    assert np.allclose(view, np.diag([1, -1, -1, 1]), atol=1e-7)
+    proj = np.array(cam.proj, np.float64).reshape(4, 4).T
+    zn, zf = 0.1, 1000.0
+    want = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, (zf + zn) / (zn - zf), 2 * zf * zn / (zn - zf)], [0, 0, -1, 0]])
+    assert np.allclose(proj, want, rtol=1e-6)
+    assert np.allclose(np.array(cam.view_inv).reshape(4, 4).T @ view, np.eye(4), atol=1e-6)
+    assert np.allclose(np.array(cam.proj_inv).reshape(4, 4).T @ proj, np.eye(4), atol=1e-4)
+
+
+def test_primary_rays_closed_form(orc):
+    w = h = 256
+    cam = orc.camera_from_params((0.5, -0.25, -0.95), (0, 0, 1), 1.0, math.pi / 2, 0.1, 1000.0)
+    rays = orc.gen_primary(cam, w, h).reshape(h, w, 8)
+    assert np.allclose(rays[..., 0:3], [0.5, -0.25, -0.95], atol=1e-6) and np.all(rays[..., 3] == np.float32(0.001)) and np.all(rays[..., 7] == 10000.0)
+    for (x, y) in [(0, 0), (255, 0), (0, 255), (127, 128), (200, 13)]:
+        dx, dy = (x + 0.5) / w * 2 - 1, (y + 0.5) / h * 2 - 1
+        want = np.array([dx, -dy, 1.0])          # image row 0 is world +Y
+        want /= np.linalg.norm(want)
+        assert np.allclose(rays[y, x, 4:7], want, atol=2e-6), (x, y)
+
+
+# ------------------------------------------------------------------------------------------------ ray / triangle
+def _tri_scene(orc, scenes, tris):
+    prims = []
+    for t in tris:
+        mb = scenes.MeshBuilder()
+        mb.add(t, [(0, 0), (1, 0), (0, 1)], [(0, 0, -1)] * 3, [(1, 0, 0, 1)] * 3, [0, 1, 2])
+        prims.append(mb.finish(scenes.constant_texture((200, 200, 200))))
+    return orc.Scene(prims, morton_bits=30), prims
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_single_triangle_known_answers(orc, scenes, mode):
+    S, _ = _tri_scene(orc, scenes, [[(0, 0, 2), (1, 0, 2), (0, 1, 2)]])
+    rays = np.array([
+        [0.25, 0.25, 0, 0.001, 0, 0, 1, 100],      # t=2, u=.25, v=.25
+        [0.25, 0.25, 0, 0.001, 0, 0, -1, 100],     # behind
+        [2.0, 2.0, 0, 0.001, 0, 0, 1, 100],        # outside
+        [0.25, 0.25, 0, 0.001, 1, 0, 0, 100],      # parallel
+        [0.25, 0.25, 0, 0.001, 0, 0, 1, 1.5],      # tmax too short
+        [0.25, 0.25, 0, 2.5, 0, 0, 1, 100],        # tmin beyond
+        [0.25, 0.25, 4, 0.001, 0, 0, -1, 100],     # back face: two-sided (instance flags 0, vk_model.rs:374)
+        [0.5, 0.5, 0, 0.001, 0, 0, 1, 100],        # on the hypotenuse
+        [0.25, 0.25, 0, 0.001, 0, 0, 1, 2.0],      # t == tmax: open interval, miss
+        [0.25, 0.25, 0, 2.0, 0, 0, 1, 100],        # t == tmin: open interval, miss
+    ], np.float32)
+    tuv, ids, _, _ = S.trace_closest(rays, mode)
+    assert ids[:, 0].tolist() == [0, -1, -1, -1, -1, -1, 0, 0, -1, -1]
+    assert np.allclose(tuv[0, :3], [2, .25, .25]) and np.allclose(tuv[6, :3], [2, .25, .25]) and np.allclose(tuv[7, :3], [2, .5, .5])
+    hit, _, _ = S.trace_any(rays, mode)
+    assert hit.tolist() == [1, 0, 0, 0, 0, 0, 1, 1, 0, 0]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_closest_of_two_and_tie_break(orc, scenes, mode):
+    near, far = [(0, 0, 2), (1, 0, 2), (0, 1, 2)], [(0, 0, 3), (1, 0, 3), (0, 1, 3)]
+    ray = np.array([[0.2, 0.2, 0, 0.001, 0, 0, 1, 100]], np.float32)
+    for order, want in (([far, near], 1), ([near, far], 0)):
+        S, _ = _tri_scene(orc, scenes, order)
+        tuv, ids, _, _ = S.trace_closest(ray, mode)
+        assert ids[0, 0] == want and tuv[0, 0] == 2.0
+    S, _ = _tri_scene(orc, scenes, [near, near, near])      # coincident: the lowest global triangle id wins
+    _, ids, _, _ = S.trace_closest(ray, mode)
+    assert ids[0].tolist() == [0, 0]
+
+
+def test_shared_edge_is_watertight(orc, scenes):
+    """rays through the shared diagonal of a quad must not slip between its two triangles (hardware RT is watertight)"""
+    mb = scenes.MeshBuilder()
+    scenes.quad(mb, (-1, -1, 2), (2, 0, 0), (0, 2, 0))
+    S = orc.Scene([mb.finish(scenes.constant_texture((1, 1, 1)))])
+    n = 4001
+    s = np.linspace(-0.999, 0.999, n)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0], rays[:, 1] = s, s                   # exactly on the diagonal
+    rays[:, 3], rays[:, 6], rays[:, 7] = 0.001, 1.0, 100.0
+    _, ids, _, _ = S.trace_closest(rays)
+    assert (ids[:, 0] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ lights + BRDF
+def test_light_records_and_layout(orc):
+    p = orc.make_light(dict(kind="point", pos=(1, 2, 3), color=(4, 5, 6), falloff=7.0, casts_shadows=True))
+    assert (p.type, p.casts_shadows, list(p.pos), list(p.color), p.falloff_distance) == (0, 1, [1, 2, 3], [4, 5, 6], 7.0)
+    assert list(p.dir) == [0, 0, 0] and p.penumbra_angle == 0 and p.umbra_angle == 0
+    s = orc.make_light(dict(kind="spot", pos=(0, 1.5, 0), dir=(0, -1, 0), color=(1, 1, 1), falloff=3.0, penumbra=0.5, umbra=0.8, casts_shadows=False))
+    assert (s.type, s.casts_shadows, np.float32(s.penumbra_angle), np.float32(s.umbra_angle)) == (1, 0, np.float32(0.5), np.float32(0.8))
+    d = orc.make_light(dict(kind="directional", dir=(0, -1, 0), color=(3, 3, 3), casts_shadows=True))
+    assert d.type == 2 and d.falloff_distance == 0.0
+    a = orc.make_light(dict(kind="area", pos=(-0.7, 0.77, 0.08), pos2=(-0.7, 0.77, -0.16), pos3=(-0.7, 0.9, -0.16), invert_normal=False, color=(1, 1, 1),
+                            falloff=3.0, penumbra=1.0, umbra=1.2, casts_shadows=True))
+    # lights.rs:385-389: normalize((pos - pos2) x (pos3 - pos2)) = normalize((0,0,.24) x (0,.13,0)) = (-1,0,0)
+    assert a.type == 3 and np.allclose(list(a.dir), [-1, 0, 0], atol=1e-6)
+    ai = orc.make_light(dict(kind="area", pos=(-0.7, 0.77, 0.08), pos2=(-0.7, 0.77, -0.16), pos3=(-0.7, 0.9, -0.16), invert_normal=True, color=(1, 1, 1),
+                             falloff=3.0, penumbra=1.0, umbra=1.2, casts_shadows=True))
+    assert np.allclose(list(ai.dir), [1, 0, 0], atol=1e-6)
+
+
+def test_light_vectors_and_radiance_known_answers(orc):
+    pt = orc.make_light(dict(kind="point", pos=(0, 2, 0), color=(8, 8, 8), falloff=4.0, casts_shadows=True))
+    nn, rad = orc.light_eval(pt, (0, 0, 0))
+    assert np.allclose(nn, [0, 2, 0]) and np.allclose(rad, 8 * (1 - 0.25) ** 2)           # max(1-(d/f)^2,0)^2
+    _, rad = orc.light_eval(pt, (0, -3, 0))
+    assert np.allclose(rad, 0)                                                                # beyond the falloff distance
+    dl = orc.make_light(dict(kind="directional", dir=(0, -1, 0), color=(3, 3, 3), casts_shadows=True))
+    nn, rad = orc.light_eval(dl, (5, 5, 5))
+    assert np.allclose(nn, [0, 10, 0]) and np.allclose(rad, 3)                               # light.glsl:97-99: -dir * 10
+    sp = orc.make_light(dict(kind="spot", pos=(0, 1, 0), dir=(0, -1, 0), color=(1, 1, 1), falloff=0.0, penumbra=math.radians(30), umbra=math.radians(45), casts_shadows=True))
+    _, rad = orc.light_eval(sp, (0, 0, 0))                                                   # on axis: theta=0 -> t = (0-u)/(p-u) = 3 -> clamp 1
+    assert np.allclose(rad, 1)
+    ang = math.radians(37.5)
+    _, rad = orc.light_eval(sp, (math.tan(ang), 0, 0))                                       # half way between penumbra and umbra: t = .5
+    assert np.allclose(rad, 0.25, rtol=1e-4)
+    _, rad = orc.light_eval(sp, (math.tan(math.radians(50)), 0, 0))
+    assert np.allclose(rad, 0)
+    # area light: parallelogram pos=(0,1,0) pos2=(1,1,0) pos3=(1,1,1) => pos4=(0,1,1); plane y=1
+    ar = dict(kind="area", pos=(0, 1, 0), pos2=(1, 1, 0), pos3=(1, 1, 1), invert_normal=False, color=(1, 1, 1), falloff=0.0, penumbra=math.radians(90),
+              umbra=math.radians(90), casts_shadows=True)
+    al = orc.make_light(ar)
+    for p, want in [((0.6, 0, 0.3), (0.6, 1, 0.3)),      # inside triangle pos,pos2,pos3
+                    ((0.3, 0, 0.6), (0.3, 1, 0.6)),      # inside the other half (pos, pos3, pos4)
+                    ((0.5, 0, -1.0), (0.5, 1, 0.0)),     # beyond edge pos-pos2
+                    ((2.0, 0, 0.5), (1.0, 1, 0.5)),      # beyond edge pos2-pos3
+                    ((0.5, 0, 3.0), (0.5, 1, 1.0)),      # beyond edge pos3-pos4
+                    ((-2.0, 0, 0.5), (0.0, 1, 0.5))]:    # beyond edge pos4-pos
+        nn, _ = orc.light_eval(al, p)
+        ref = NP.get_unnormalized_L_vec(NP.light_from_record(al), np.array(p, np.float64))
+        assert np.allclose(nn, ref, atol=1e-6), (p, nn, ref)
+        assert np.allclose(nn, np.array(want) - np.array(p), atol=1e-5), (p, nn)
+
+
+def test_brdf_terms_against_closed_forms(orc):
+    for (NdotL, NdotV, NdotH, LdotH, alpha) in [(0.7, 0.5, 0.9, 0.8, 0.25), (0.2, 0.9, 0.4, 0.3, 0.81), (1.0, 1e-5, 1.0, 1.0, 0.04), (0.05, 0.3, 0.999, 0.1, 0.5)]:
+        got = orc.brdf_terms(NdotL, NdotV, NdotH, LdotH, NdotV, NdotL, alpha)
+        want = [NP.D_GGX(alpha, NdotH), NP.V_SmithGGXCorrelated_fast(alpha, NdotV, NdotL), (1 - LdotH) ** 5, NP.Burley_diffuse_local_sss(alpha, NdotV, NdotV, NdotL, LdotH, 0.4)]
+        assert np.allclose(got, want, rtol=2e-5), (got, want)
+
+
+# ------------------------------------------------------------------------------------------------ whole pixels
+def _floor_scene(scenes, blocker_height=None):
+    prims = []
+    mb = scenes.MeshBuilder()
+    scenes.quad(mb, (-0.9, 0, -0.9), (0, 0, 1.8), (1.8, 0, 0))   # floor y=0, normal +y
+    prims.append(mb.finish(scenes.constant_texture((200, 200, 200))))
+    if blocker_height is not None:
+        mb = scenes.MeshBuilder()
+        scenes.quad(mb, (-0.9, blocker_height, -0.9), (0, 0, 1.8), (1.8, 0, 0))
+        prims.append(mb.finish(scenes.constant_texture((200, 200, 200))))
+    cam = dict(pos=(0.0, 0.5, 0.0), dir=(0.0, -1.0, 0.001), fovy=math.pi / 3, znear=0.1, zfar=1000.0)
+    return prims, cam
+
+
+def _centre(orc, prims, cam, lights):
+    sc_lights = orc.make_lights(lights)
+    S = orc.Scene(prims)
+    c = orc.camera_from_params(cam["pos"], cam["dir"], 1.0, cam["fovy"], cam["znear"], cam["zfar"])
+    out = S.render(c, sc_lights, len(lights), 8, 8, debug=True)
+    return out
+
+
+def test_shadowed_light_keeps_five_percent_and_directional_range_is_ten(orc, scenes):
+    """raytrace.rgen.glsl:179-181 (0.05) and light.glsl:97-99 (tmax = |-dir*10| = 10 for directional lights)"""
+    light = [dict(kind="directional", dir=(0, -1, 0), color=(3, 3, 3), casts_shadows=True)]
+    prims, cam = _floor_scene(scenes)
+    lit = _centre(orc, prims, cam, light)
+    # the camera (y=.5) looks down; a blocker above the camera is not seen by primary rays but is crossed by shadow rays
+    for height, shadowed in ((9.0, True), (11.0, False)):
+        prims_b, _ = _floor_scene(scenes, blocker_height=height)
+        out = _centre(orc, prims_b, cam, light)
+        sb = out["shadow_bits"][4, 4]
+        assert bool(sb & 1) == shadowed and bool(sb >> 16 & 1)
+        ratio = out["color"][4, 4, :3] / lit["color"][4, 4, :3]
+        assert np.allclose(ratio, 0.05 if shadowed else 1.0, rtol=1e-5)
+    assert lit["stats"]["shadow_rays"] == 64 and lit["stats"]["hit_pixels"] == 64
+
+
+def test_miss_outputs(orc, scenes):
+    prims, cam = _floor_scene(scenes)
+    cam = dict(cam, dir=(0.0, 1.0, 0.001))        # look away from the floor
+    out = _centre(orc, prims, cam, [dict(kind="directional", dir=(0, -1, 0), color=(3, 3, 3), casts_shadows=True)])
+    assert (out["hit_id"] == -1).all()
+    assert np.array_equal(out["color"][..., :3], np.zeros((8, 8, 3), np.float32)) and (out["color"][..., 3] == 1).all()   # raytrace.rgen.glsl:103-105,197
+    assert (out["depth"] == 10000.0).all() and np.array_equal(out["normal"][..., :3], np.full((8, 8, 3), 0.5, np.float32))
+    assert out["stats"]["shadow_rays"] == 0
+
+
+def test_shading_matches_independent_numpy_restatement(orc, scenes):
+    """every light type, normal-mapped + textured surfaces: C oracle vs the numpy restatement written from the GLSL"""
+    sc = scenes.sponza_like(0.05)
+    lights = scenes.sponza_lights(4)
+    w, h = 48, 27
+    S = orc.Scene(sc.primitives)
+    cam = oracle_camera(orc, sc, w, h)
+    recs = orc.make_lights(lights)
+    out = S.render(cam, recs, 4, w, h, debug=True)
+    view = np.array(cam.view, np.float64).reshape(4, 4).T
+    view_inv = np.array(cam.view_inv, np.float64).reshape(4, 4).T
+    nl = [NP.light_from_record(recs[i]) for i in range(4)]
+    checked = 0
+    for y in range(0, h, 2):
+        for x in range(0, w, 3):
+            pi, ti = out["hit_id"][y, x]
+            if pi < 0:
+                continue
+            _, u, v, _ = out["hit_tuv"][y, x]
+            rho, depth, on, mask = NP.shade_pixel(sc.primitives[pi], int(ti), float(u), float(v), view, view_inv, np.array(cam.camera_pos, np.float64), nl,
+                                                  int(out["shadow_bits"][y, x]) & 0xFFFF)
+            assert mask == int(out["shadow_bits"][y, x]) & 0xFFFF0000, (x, y)
+            assert np.allclose(out["color"][y, x, :3], rho, rtol=2e-4, atol=2e-6), (x, y, out["color"][y, x], rho)
+            assert np.isclose(out["depth"][y, x], depth, rtol=1e-5) and np.allclose(out["normal"][y, x, :3], on, atol=1e-5)
+            checked += 1
+    assert checked > 80
+
+
+# ------------------------------------------------------------------------------------------------ LBVH + traversal
+@pytest.mark.parametrize("name,detail,bits", [("cornell", 1.0, 30), ("sponza_like", 0.05, 30), ("sponza_like", 0.05, 63)])
+def test_lbvh_invariants(orc, get_scene, name, detail, bits):
+    sc = get_scene(name, detail)
+    S = orc.Scene(sc.primitives, morton_bits=bits)
+    b = S.lbvh()
+    T = S.n_tris
+    assert T == sc.n_tris
+    keys, gid = b["keys"].astype(object), b["leaf_gid"].astype(object)
+    comp = [k * (1 << 32) + g for k, g in zip(keys, gid)]
+    assert all(comp[i] < comp[i + 1] for i in range(T - 1))               # (key, gid) strictly increasing
+    assert sorted(b["leaf_gid"].tolist()) == list(range(T))
+    child = b["child"]
+    seen_leaf, seen_int = np.zeros(T, int), np.zeros(T - 1, int)
+    lo, hi = np.concatenate([b["node_lo"], b["leaf_lo"]]), np.concatenate([b["node_hi"], b["leaf_hi"]])
+    idx = lambda c: (T - 1 + (~c)) if c < 0 else c
+    for n in range(T - 1):
+        for c in child[n]:
+            if c < 0:
+                seen_leaf[~c] += 1
+            else:
+                seen_int[c] += 1
+        a, bb = idx(child[n, 0]), idx(child[n, 1])
+        assert np.array_equal(lo[n], np.minimum(lo[a], lo[bb])) and np.array_equal(hi[n], np.maximum(hi[a], hi[bb]))   # exact union
+    assert (seen_leaf == 1).all() and seen_int[0] == 0 and (seen_int[1:] == 1).all()
+    tv = b["tri_verts"].reshape(T, 3, 3)[b["leaf_gid"]]
+    assert np.array_equal(b["leaf_lo"], tv.min(1)) and np.array_equal(b["leaf_hi"], tv.max(1))
+
+
+@pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.03)])
+def test_bvh_traversal_equals_brute_force(orc, get_scene, name, detail):
+    """the structure-independent definition: argmin over ALL triangles of (t_eff, gid) -- exact equality"""
+    sc = get_scene(name, detail)
+    rays = random_rays(10000, 3)
+    S30, S63 = orc.Scene(sc.primitives, morton_bits=30), orc.Scene(sc.primitives, morton_bits=63)
+    tb, ib, _, _ = S30.trace_closest(rays, 1)
+    for S in (S30, S63):
+        t, i, n_int, n_tri = S.trace_closest(rays, 0)
+        assert np.array_equal(i, ib) and np.array_equal(t.view(np.uint32), tb.view(np.uint32))
+        assert n_int > 0 and n_tri < 10000 * sc.n_tris
+    short = rays.copy()
+    short[:, 7] = 1.2
+    hb, _, _ = S30.trace_any(short, 1)
+    for S in (S30, S63):
+        hh, _, _ = S.trace_any(short, 0)
+        assert np.array_equal(hh, hb)
+    assert 0 < hb.sum() < hb.size
+
+
+# ------------------------------------------------------------------------------------------------ fixtures
+@pytest.mark.parametrize("n", [64, 256])
+def test_cornell_golden_fixture(orc, get_scene, n):
+    sc = get_scene("cornell")
+    S, L, nl = oracle_for(orc, sc)
+    out = S.render(oracle_camera(orc, sc, n, n), L, nl, n, n, threads=4)
+    gold = np.load(os.path.join(GOLD, f"cornell_{n}.npz"))
+    assert_radiance_close(out["color"], gold["color"], rel=1e-5)
+    assert_radiance_close(out["depth"], gold["depth"], rel=1e-6, what="depth")
+    assert_radiance_close(out["normal"], gold["normal"], rel=1e-5, what="normal")
+    assert out["stats"] == json.load(open(os.path.join(GOLD, f"cornell_{n}.stats.json")))
+    assert out["stats"]["nonfinite_pixels"] == 0 and sc.n_tris == 34
+
+
+def test_threads_do_not_change_the_frame(orc, get_scene):
+    sc = get_scene("cornell")
+    S, L, nl = oracle_for(orc, sc)
+    a = S.render(oracle_camera(orc, sc, 96, 64), L, nl, 96, 64, threads=1)
+    b = S.render(oracle_camera(orc, sc, 96, 64), L, nl, 96, 64, threads=5)
+    assert np.array_equal(a["color"], b["color"]) and a["stats"] == b["stats"]
