@@ -3,6 +3,7 @@
 #include "art_internal.h"
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -46,6 +47,7 @@ struct ArtContext {
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
+    int kind_primary = 2, kind_shadow = 4; // structure walked: 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
     // device scene
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
     Lbvh bvh{};
@@ -193,6 +195,8 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
     c->stream = c->own_stream;
     c->W = cfg->width; c->H = cfg->height;
+    if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
+        if (ok(w[0])) { c->kind_primary = w[0] - '0'; c->kind_shadow = ok(w[1]) ? w[1] - '0' : c->kind_primary; } }
     *out = c;
     return ART_OK;
 }
@@ -287,7 +291,7 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(hipEventRecord(e1, c->stream)); HIPC(hipEventSynchronize(e1));
     float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    c->stats.build_ms = ms; c->stats.num_triangles = T; c->stats.num_primitives = (uint32_t)dp.size(); c->stats.num_nodes = T > 1 ? T - 1 : 1;
+    c->stats.build_ms = ms; c->stats.num_triangles = T; c->stats.num_primitives = (uint32_t)dp.size(); c->stats.num_nodes = c->kind_primary == 4 ? c->bvh.n_wide : (T > 1 ? T - 1 : 1);
     c->built = true;
     return ART_OK;
 }
@@ -388,7 +392,7 @@ int32_t art_trace(ArtContext *c) {
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local;
-    a.nodes = c->bvh.nodes; a.tris = c->bvh.tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
+    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
     a.lights = c->d_lights.p; a.n_lights = (uint32_t)c->lights.size();
     a.hits = c->d_hits.p; a.contrib = c->d_contrib.p; a.shadow_rays = c->d_shadow_rays.p; a.counters = c->d_counters.p;
     a.color = c->d_color.p; a.depth = c->d_depth.p; a.normal = c->d_normal.p;
@@ -520,8 +524,10 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
     if (c->traced && c->frame_ready) {
         int32_t r = use_device(c); if (r) return r;
         HIPC(hipStreamSynchronize(c->stream));
-        uint32_t cnt[2] = {0, 0};
-        HIPC(hipMemcpy(cnt, c->d_counters.p, 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> raw(kCounterWords);
+        HIPC(hipMemcpy(raw.data(), c->d_counters.p, kCounterWords * 4, hipMemcpyDeviceToHost));
+        uint64_t cnt[2] = {0, 0};
+        for (uint32_t k = 0; k < kSlotCount; k++) { cnt[0] += raw[kShadowSlots + k * kSlotStride]; cnt[1] += raw[kHitSlots + k * kSlotStride]; }
         uint64_t owned = 0; // pixels of owned tiles that fall inside the frame
         for (uint32_t t : c->tile_list) {
             uint32_t tx = t % c->tiles_x, ty = t / c->tiles_x;
@@ -601,7 +607,7 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = c->d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, c->stream);
-    if (e == hipSuccess) { launch_query_closest(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_primary}, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);
@@ -629,7 +635,7 @@ int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = c->d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, c->stream);
-    if (e == hipSuccess) { launch_query_any(c->bvh.nodes, c->bvh.tris, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) { launch_query_any(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_shadow}, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_r); (void)hipFree(d_h);

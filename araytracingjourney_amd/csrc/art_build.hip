@@ -9,6 +9,8 @@
 // 64-byte traversal nodes + 48-byte leaf-ordered triangles.
 #include "art_internal.h"
 #include <rocprim/rocprim.hpp>
+#include <cmath>
+#include <vector>
 
 namespace art {
 
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(256) void k_karras(int T, const uint64_t *__restric
 // leaf boxes + leaf-ordered triangle records
 __global__ __launch_bounds__(256) void k_leaves(uint32_t T, const uint32_t *__restrict__ leaf_gid, const float *__restrict__ triw, const float *__restrict__ tlo,
                                                 const float *__restrict__ thi, const uint32_t *__restrict__ tri_prim, const uint32_t *__restrict__ first_tri,
-                                                float *__restrict__ leaf_lo, float *__restrict__ leaf_hi, DevTri *__restrict__ tris) {
+                                                float *__restrict__ leaf_lo, float *__restrict__ leaf_hi, DevTri *__restrict__ tris,
+                                                const DevPrim *__restrict__ prims, DevShadeTri *__restrict__ shade_tris) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= T) return;
     uint32_t g = leaf_gid[p];
@@ -140,6 +143,20 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t T, const uint32_t *__re
     t.v[1] = make_float4(w[3], w[4], w[5], __uint_as_float(g - first_tri[pr]));
     t.v[2] = make_float4(w[6], w[7], w[8], __uint_as_float(g));
     tris[p] = t;
+    // shading record: get_indices + three vertex fetches of raytrace.rgen.glsl:107-114, done once
+    const DevPrim &P = prims[pr];
+    uint32_t tl = g - first_tri[pr], ix[3];
+    if (P.single_index_size == 2) { const uint16_t *q = (const uint16_t *)P.indices + 3 * (size_t)tl; ix[0] = q[0]; ix[1] = q[1]; ix[2] = q[2]; }
+    else { const uint32_t *q = (const uint32_t *)P.indices + 3 * (size_t)tl; ix[0] = q[0]; ix[1] = q[1]; ix[2] = q[2]; }
+    DevShadeTri st;
+    for (int k = 0; k < 3; k++) {
+        const float *v = P.vertices + (size_t)ix[k] * 12;
+        for (int j = 0; j < 3; j++) { st.f[3 * k + j] = v[j]; st.f[15 + 3 * k + j] = v[5 + j]; st.f[24 + 3 * k + j] = v[8 + j]; }
+        st.f[9 + 2 * k] = v[3]; st.f[10 + 2 * k] = v[4];
+        if (k == 0) st.f[33] = v[11];
+    }
+    st.f[34] = __uint_as_float(pr); st.f[35] = 0.f;
+    shade_tris[p] = st;
 }
 
 // bottom-up refit: the second thread to arrive at a node owns it (its sibling's box is complete and visible)
@@ -196,7 +213,135 @@ __global__ __launch_bounds__(256) void k_emit_nodes(uint32_t T, const int32_t *_
     nodes[n] = d;
 }
 
+// ---- 4-wide collapse + 8-bit quantisation of the binary LBVH (host side; build time only) ----------------------
+// Greedy collapse: start from a binary node's two children and keep replacing the internal candidate with the largest
+// surface area by its own two children until there are four (or only leaves are left).
+namespace {
+struct BoxRef { const float *lo, *hi; };
+inline float half_area(const float *lo, const float *hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+} // namespace
+
+static hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
+    const uint32_t NI = T > 1 ? T - 1 : 0;
+    std::vector<int32_t> child(NI ? (size_t)NI * 2 : 2);
+    std::vector<float> nlo(NI ? (size_t)NI * 3 : 3), nhi(NI ? (size_t)NI * 3 : 3), llo((size_t)T * 3), lhi((size_t)T * 3);
+    HIPQ(hipStreamSynchronize(s));
+    if (NI) {
+        HIPQ(hipMemcpy(child.data(), l.child, (size_t)NI * 8, hipMemcpyDeviceToHost));
+        HIPQ(hipMemcpy(nlo.data(), l.node_lo, (size_t)NI * 12, hipMemcpyDeviceToHost));
+        HIPQ(hipMemcpy(nhi.data(), l.node_hi, (size_t)NI * 12, hipMemcpyDeviceToHost));
+    }
+    HIPQ(hipMemcpy(llo.data(), l.leaf_lo, (size_t)T * 12, hipMemcpyDeviceToHost));
+    HIPQ(hipMemcpy(lhi.data(), l.leaf_hi, (size_t)T * 12, hipMemcpyDeviceToHost));
+    auto box = [&](int32_t ref) -> BoxRef {
+        if (ref < 0) return BoxRef{llo.data() + 3 * (size_t)(~ref), lhi.data() + 3 * (size_t)(~ref)};
+        return BoxRef{nlo.data() + 3 * (size_t)ref, nhi.data() + 3 * (size_t)ref};
+    };
+    std::vector<DevNode4> wide;
+    std::vector<int32_t> todo; // binary node behind each wide node, in wide-index order (BFS)
+    wide.reserve(NI / 2 + 2);
+    if (NI == 0) todo.push_back(~0); // single triangle: a root with one leaf child
+    else todo.push_back(0);
+    for (size_t w = 0; w < todo.size(); w++) {
+        int32_t cand[4]; int nc = 0;
+        if (todo[w] < 0) { cand[nc++] = todo[w]; }
+        else {
+            cand[nc++] = child[2 * (size_t)todo[w]]; cand[nc++] = child[2 * (size_t)todo[w] + 1];
+            while (nc < 4) {
+                int best = -1; float ba = -1.0f;
+                for (int i = 0; i < nc; i++)
+                    if (cand[i] >= 0) { BoxRef b = box(cand[i]); float a = half_area(b.lo, b.hi); if (a > ba) { ba = a; best = i; } }
+                if (best < 0) break;
+                int32_t n = cand[best];
+                cand[best] = child[2 * (size_t)n];
+                cand[nc++] = child[2 * (size_t)n + 1];
+            }
+        }
+        DevNode4 d; std::memset(&d, 0, sizeof(d));
+        float org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < nc; i++) { BoxRef b = box(cand[i]); for (int k = 0; k < 3; k++) { org[k] = std::fmin(org[k], b.lo[k]); top[k] = std::fmax(top[k], b.hi[k]); } }
+        d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
+        uint32_t ebits[3]; float scale[3];
+        for (int k = 0; k < 3; k++) {
+            // smallest power of two with 255 * scale >= extent (as evaluated by the device's fma), at least 2^-100
+            double ext = (double)top[k] - (double)org[k];
+            int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+            if (e < -100) e = -100;
+            for (;;) { scale[k] = std::ldexp(1.0f, e); if (std::fmaf(255.0f, scale[k], org[k]) >= top[k]) break; e++; }
+            ebits[k] = (uint32_t)(e + 127);
+        }
+        uint32_t mask = 0;
+        for (int i = 0; i < 4; i++) {
+            if (i >= nc) { d.child[i] = 0x7FFFFFFF; continue; }
+            mask |= 1u << i;
+            BoxRef b = box(cand[i]);
+            for (int k = 0; k < 3; k++) {
+                int ql = (int)std::floor(((double)b.lo[k] - (double)org[k]) / (double)scale[k]);
+                int qh = (int)std::ceil(((double)b.hi[k] - (double)org[k]) / (double)scale[k]);
+                ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                while (ql > 0 && std::fmaf((float)ql, scale[k], org[k]) > b.lo[k]) ql--;   // never taken by construction; kept as a guard
+                while (qh < 255 && std::fmaf((float)qh, scale[k], org[k]) < b.hi[k]) qh++;
+                d.q[k] |= (uint32_t)ql << (8 * i);
+                d.q[3 + k] |= (uint32_t)qh << (8 * i);
+            }
+            if (cand[i] < 0) d.child[i] = cand[i];
+            else { d.child[i] = (int32_t)todo.size(); todo.push_back(cand[i]); }
+        }
+        d.exps = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (mask << 24);
+        wide.push_back(d);
+    }
+    l.n_wide = (uint32_t)wide.size();
+    HIPQ(hipMalloc(&l.wide, wide.size() * sizeof(DevNode4)));
+    HIPQ(hipMemcpy(l.wide, wide.data(), wide.size() * sizeof(DevNode4), hipMemcpyHostToDevice));
+    return hipSuccess;
+}
+
+// quantised binary nodes, one thread per internal node (device; double arithmetic only for the exact floor/ceil)
+__global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t T, const int32_t *__restrict__ child, const float *__restrict__ node_lo, const float *__restrict__ node_hi,
+                                                     const float *__restrict__ leaf_lo, const float *__restrict__ leaf_hi, DevNodeQ *__restrict__ out) {
+    uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    int c0, c1; bool absent1 = false;
+    if (T == 1) { if (n != 0) return; c0 = ~0; c1 = ~0; absent1 = true; }
+    else { if (n >= T - 1) return; c0 = child[2 * n]; c1 = child[2 * n + 1]; }
+    const float *l0 = c0 < 0 ? leaf_lo + 3 * (size_t)(~c0) : node_lo + 3 * (size_t)c0, *h0 = c0 < 0 ? leaf_hi + 3 * (size_t)(~c0) : node_hi + 3 * (size_t)c0;
+    const float *l1 = c1 < 0 ? leaf_lo + 3 * (size_t)(~c1) : node_lo + 3 * (size_t)c1, *h1 = c1 < 0 ? leaf_hi + 3 * (size_t)(~c1) : node_hi + 3 * (size_t)c1;
+    uint32_t qb[12]; // lo0 xyz, hi0 xyz, lo1 xyz, hi1 xyz
+    uint32_t eb[3]; float org[3];
+    for (int k = 0; k < 3; k++) {
+        float o = fminf(l0[k], l1[k]), top = fmaxf(h0[k], h1[k]);
+        double ext = (double)top - (double)o;
+        int e = ext > 0.0 ? ilogb(ext) - 8 : -100; // 2^(e+8) <= ext: start below and walk up
+        if (e < -100) e = -100;
+        float sc;
+        for (;;) { sc = ldexpf(1.0f, e); if (fmaf(255.0f, sc, o) >= top) break; e++; }
+        org[k] = o; eb[k] = (uint32_t)(e + 127);
+        const float v[4] = {l0[k], h0[k], l1[k], h1[k]};
+        for (int j = 0; j < 4; j++) {
+            double rel = ((double)v[j] - (double)o) / (double)sc;
+            int q = (j & 1) ? (int)ceil(rel) : (int)floor(rel);
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            if (j & 1) { while (q < 255 && fmaf((float)q, sc, o) < v[j]) q++; }
+            else { while (q > 0 && fmaf((float)q, sc, o) > v[j]) q--; }
+            qb[(j >> 1) * 6 + (j & 1) * 3 + k] = (uint32_t)q;
+        }
+    }
+    uint32_t gamma = (uint32_t)(c0 < 0 ? ~c0 : c0);
+    uint32_t flags = (c0 < 0 ? 1u : 0u) | (c1 < 0 ? 2u : 0u) | (absent1 ? 4u : 0u);
+    DevNodeQ d;
+    d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
+    d.exps = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (flags << 24);
+    d.q[0] = qb[0] | (qb[1] << 8) | (qb[2] << 16) | (qb[3] << 24);
+    d.q[1] = qb[4] | (qb[5] << 8) | (qb[6] << 16) | (qb[7] << 24);
+    d.q[2] = qb[8] | (qb[9] << 8) | (qb[10] << 16) | (qb[11] << 24);
+    d.gamma = gamma;
+    out[n] = d;
+}
+
 void lbvh_free(Lbvh &l) {
+    hipFree(l.wide); hipFree(l.qnodes); hipFree(l.shade_tris);
     hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
     hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim);
     l = Lbvh{};
@@ -222,6 +367,8 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
         HIPQ(hipMalloc(&out.leaf_lo, (size_t)T * 12)); HIPQ(hipMalloc(&out.leaf_hi, (size_t)T * 12));
         HIPQ(hipMalloc(&out.tris, (size_t)T * sizeof(DevTri))); HIPQ(hipMalloc(&out.nodes, (size_t)NI * sizeof(DevNode)));
         HIPQ(hipMalloc(&out.tri_prim, (size_t)T * 4));
+        HIPQ(hipMalloc(&out.qnodes, (size_t)NI * sizeof(DevNodeQ)));
+        HIPQ(hipMalloc(&out.shade_tris, (size_t)T * sizeof(DevShadeTri)));
         const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
         HIPQ(hipMemcpyAsync(cb, init, 24, hipMemcpyHostToDevice, s));
         HIPQ(hipMemsetAsync(arrive, 0, (size_t)NI * 4, s));
@@ -231,18 +378,20 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
         HIPQ(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
         HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
         HIPQ(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
-        k_leaves<<<GT, B, 0, s>>>(T, out.leaf_gid, triw, tlo, thi, out.tri_prim, in.prim_first_tri, out.leaf_lo, out.leaf_hi, out.tris);
+        k_leaves<<<GT, B, 0, s>>>(T, out.leaf_gid, triw, tlo, thi, out.tri_prim, in.prim_first_tri, out.leaf_lo, out.leaf_hi, out.tris, in.prims, out.shade_tris);
         if (T > 1) {
             k_karras<<<(T - 1 + B - 1) / B, B, 0, s>>>((int)T, out.keys, out.leaf_gid, out.child, parent_int, parent_leaf);
             k_refit<<<GT, B, 0, s>>>(T, out.child, parent_int, parent_leaf, out.leaf_lo, out.leaf_hi, out.node_lo, out.node_hi, arrive);
         }
         k_emit_nodes<<<(NI + B - 1) / B, B, 0, s>>>(T, out.child, out.node_lo, out.node_hi, out.leaf_lo, out.leaf_hi, out.nodes);
+        k_emit_qnodes<<<(NI + B - 1) / B, B, 0, s>>>(T, out.child, out.node_lo, out.node_hi, out.leaf_lo, out.leaf_hi, out.qnodes);
         HIPQ(hipGetLastError());
         HIPQ(hipStreamSynchronize(s));
         return hipSuccess;
     };
     err = body();
     hipFree(triw); hipFree(tlo); hipFree(thi); hipFree(cb); hipFree(gid_in); hipFree(keys_in); hipFree(arrive); hipFree(parent_int); hipFree(parent_leaf); hipFree(tmp);
+    if (err == hipSuccess) err = wide_build(out, T, s);
     if (err != hipSuccess) lbvh_free(out);
     return err;
 }

@@ -27,8 +27,25 @@ struct DevPrim {
 //   q0 = lo0.xyz hi0.x | q1 = hi0.yz lo1.xy | q2 = lo1.z hi1.xyz | q3 = child0 child1 - -
 // child >= 0: internal node index; child < 0: ~position of the triangle in leaf (Morton) order.
 struct alignas(16) DevNode { float4 q[4]; };
+// 64-byte 4-wide node with 8-bit quantised child boxes (the structure the tracer walks by default):
+//   origin.xyz | exps = ex | ey<<8 | ez<<16 | valid_mask<<24   (scale_k = 2^(e_k-127), bit pattern e_k<<23)
+//   q[0..2] = lo x/y/z, q[3..5] = hi x/y/z, byte c of each word = child c;  child box = origin + q*scale (exact fma),
+//   rounded outwards at build time so that it contains the child's float box exactly
+//   child[c] >= 0: wide node index; < 0: ~position of a triangle in leaf order
+struct alignas(16) DevNode4 { float ox, oy, oz; uint32_t exps; uint32_t q[6]; uint32_t spare[2]; int32_t child[4]; };
+static_assert(sizeof(DevNode4) == 64, "DevNode4 layout");
+// 32-byte binary node with 8-bit quantised child boxes: half the bytes of DevNode through the vector-memory path.
+//   w0 = origin.xyz | ex | ey<<8 | ez<<16 | flags<<24   (flags: 1 child0 is a leaf, 2 child1 is a leaf, 4 child1 absent)
+//   w1 = lo0x lo0y lo0z hi0x | hi0y hi0z lo1x lo1y | lo1z hi1x hi1y hi1z | gamma
+//   Karras' children are gamma and gamma+1 (as node indices or leaf positions), so one word addresses both.
+struct alignas(16) DevNodeQ { float ox, oy, oz; uint32_t exps; uint32_t q[3]; uint32_t gamma; };
+static_assert(sizeof(DevNodeQ) == 32, "DevNodeQ layout");
 // 48-byte triangle in leaf order: v0.xyz|prim  v1.xyz|tri-in-prim  v2.xyz|gid
 struct alignas(16) DevTri { float4 v[3]; };
+// 144-byte shading record in leaf order: everything raytrace.rgen.glsl:107-114 fetches through PrimitiveInfo -> indices ->
+// three 48-byte vertices, gathered once at build time so that hit reconstruction is one dependent fetch instead of three.
+//   f[0..8] object-space positions p0 p1 p2 | f[9..14] uv0 uv1 uv2 | f[15..23] normals | f[24..32] tangent.xyz | f[33] v0.tangent.w | f[34] primitive id (bits)
+struct alignas(16) DevShadeTri { float f[36]; };
 
 struct CameraArg { float view[16], view_inv[16], proj[16], proj_inv[16], camera_pos[3]; };
 
@@ -51,6 +68,10 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevTri *tris;           // [T] leaf order
     DevNode *nodes;         // [max(T-1,1)]
     uint32_t *tri_prim;     // [T] gid -> primitive
+    DevNode4 *wide;         // [n_wide] collapsed + quantised traversal structure
+    uint32_t n_wide;
+    DevNodeQ *qnodes;       // [max(T-1,1)] quantised binary nodes
+    DevShadeTri *shade_tris; // [T] leaf order
 };
 hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s); // allocates out.*, frees temporaries
 void lbvh_free(Lbvh &l);
@@ -60,7 +81,8 @@ struct FrameArgs {
     uint32_t W, H;
     const uint32_t *tile_list; uint32_t n_tiles_owned; uint32_t tiles_x; // owned 32x32 tiles
     uint32_t n_local;          // n_tiles_owned * 1024
-    const DevNode *nodes; const DevTri *tris; const DevPrim *prims; const uint32_t *tex_pool;
+    const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
+    int trace_kind[2];         // structure walked by primary / shadow rays: 2 binary, 4 wide quantised, 1 binary quantised
     const ArtLight *lights; uint32_t n_lights;
     float4 *hits;              // [n_local] t,u,v,gid
     float4 *contrib;           // [n_lights][n_local]
@@ -74,9 +96,14 @@ void launch_primary(const FrameArgs &a, hipStream_t s);
 void launch_shade(const FrameArgs &a, hipStream_t s);
 void launch_shadow(const FrameArgs &a, hipStream_t s);
 void launch_accumulate(const FrameArgs &a, hipStream_t s);
-void launch_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
-void launch_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);
-constexpr uint32_t kCounterWords = 1024; // [0] shadow rays, [1] hit pixels, [64..] primary cursors, [64+256..] shadow cursors, [64+512..] query cursors
+struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; int kind; }; // kind: 2 | 4 | 1
+void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
+void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);
+// per-frame counter block (zeroed every frame): [64..] primary cursors, [64+256..] shadow cursors, [64+512..] query cursors,
+// then 64 hit-pixel slots and 64 shadow-ray slots, each on its own 128-byte line: one word would serialise ~11 ns per atomic
+// (32 640 waves on one address cost the shading kernel 0.3 ms)
+constexpr uint32_t kCounterWords = 8192;
+constexpr uint32_t kHitSlots = 1024, kShadowSlots = 1024 + 64 * 32, kSlotStride = 32, kSlotCount = 64;
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s);
 
 // shard tile ownership: 32x32 tile (tx,ty) belongs to shard (tx + 5*ty) % count -- a diagonal interleave, so that

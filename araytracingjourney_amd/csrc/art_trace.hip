@@ -11,6 +11,8 @@
 //   accept(tri, ray) := slab(AABB(tri), ray) passes AND Moller-Trumbore hits with tmin < t < tmax
 //   t_eff := max(t_MT, t_entry(AABB(tri)));  closest := argmin (t_eff, gid);  any := exists accept
 #include "art_internal.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace art {
 
@@ -28,6 +30,7 @@ __device__ __forceinline__ V3 cross3(V3 a, V3 b) {
 }
 __device__ __forceinline__ float len3(V3 a) { return sqrtf(dot3(a, a)); }
 __device__ __forceinline__ V3 nrm3(V3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return a * inv; }
+__device__ __forceinline__ V3 fast_nrm3(V3 a) { return a * __frsqrt_rn(dot3(a, a)); } // radiance-only values
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 __device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
@@ -88,8 +91,18 @@ __device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v
 constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], conflict-free); deeper entries spill to scratch
 constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (63 key bits + 32 index bits)
 constexpr int kBlock = 256;
-constexpr int kChunk = 128;     // candidate slots a wave takes from the work cursor at a time
-constexpr int kRefill = 12;     // refill a wave's idle lanes once this many are idle (Aila & Laine 2009, dynamic fetch)
+// tunables of the persistent tracer (defaults; ART_CHUNK / ART_REFILL / ART_BLOCKS in the environment override them for sweeps)
+struct Tune { uint32_t chunk = 64, refill = 12, blocks = 1536; bool init = false; };
+static Tune g_tune;
+static const Tune &tune() {
+    if (!g_tune.init) {
+        if (const char *e = getenv("ART_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) g_tune.chunk = (uint32_t)v; }
+        if (const char *e = getenv("ART_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) g_tune.refill = (uint32_t)v; }
+        if (const char *e = getenv("ART_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 16384) g_tune.blocks = (uint32_t)v; }
+        g_tune.init = true;
+    }
+    return g_tune;
+}
 constexpr int kCursorStride = 32; // one 128-byte line per XCD cursor
 
 // local pixel id -> frame coordinates.  p = tile*1024 + sub*64 + lane; a wave covers an 8x8 pixel block.
@@ -159,11 +172,144 @@ template <bool ANY> struct Trav {
     }
 };
 
+// Traversal over the 32-byte quantised binary nodes: the binary walk above with two 16-byte loads per node.  A child box
+// is dequantised (origin + q*scale, one exact fma) and goes through the same slab(); a leaf's quantised box is looser
+// than its triangle's AABB, so the leaf test applies the exact triangle-AABB slab itself (accept() of DESIGN.md 1.1).
+template <bool ANY> struct TravQ {
+    Ray r;
+    float tbest, bu, bv;
+    uint32_t bpos, bgid;
+    int node, sp;
+    __device__ __forceinline__ void start(V3 o, V3 d, float tmin, float tmax) {
+        ray_init(r, o, d, tmin, tmax);
+        tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; node = 0; sp = 0;
+    }
+    __device__ __forceinline__ bool step(const DevNodeQ *__restrict__ qn, const DevTri *__restrict__ tris, int *lds, int *ovf) {
+        const uint4 *nq = reinterpret_cast<const uint4 *>(qn + node);
+        uint4 a = nq[0], b = nq[1];
+        float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
+        float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
+        uint32_t flags = a.w >> 24;
+        int c0 = (flags & 1u) ? (int)~b.w : (int)b.w, c1 = (flags & 2u) ? (int)~(b.w + 1u) : (int)(b.w + 1u);
+        float te0, te1;
+        bool h0 = slab(r, fmaf((float)(b.x & 255u), sx, ox), fmaf((float)((b.x >> 8) & 255u), sy, oy), fmaf((float)((b.x >> 16) & 255u), sz, oz),
+                       fmaf((float)(b.x >> 24), sx, ox), fmaf((float)(b.y & 255u), sy, oy), fmaf((float)((b.y >> 8) & 255u), sz, oz), tbest, te0);
+        bool h1 = slab(r, fmaf((float)((b.y >> 16) & 255u), sx, ox), fmaf((float)(b.y >> 24), sy, oy), fmaf((float)(b.z & 255u), sz, oz),
+                       fmaf((float)((b.z >> 8) & 255u), sx, ox), fmaf((float)((b.z >> 16) & 255u), sy, oy), fmaf((float)(b.z >> 24), sz, oz), tbest, te1) && !(flags & 4u);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            bool h = k == 0 ? h0 : h1;
+            int c = k == 0 ? c0 : c1;
+            float teq = k == 0 ? te0 : te1;
+            if (h && c < 0 && fmaxf(teq, r.tmin) <= tbest) {
+                uint32_t pos = (uint32_t)~c;
+                const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
+                float4 va = tq[0], vb = tq[1], vc = tq[2];
+                float te;
+                if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+                         fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
+                    float t, u, v;
+                    if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
+                        if (ANY) { bpos = pos; tbest = t; return true; }
+                        float teff = fmaxf(t, te);
+                        uint32_t gid = __float_as_uint(vc.w);
+                        if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
+                    }
+                }
+            }
+        }
+        bool g0 = h0 && c0 >= 0, g1 = h1 && c1 >= 0;
+        if (!ANY) { g0 = g0 && fmaxf(te0, r.tmin) <= tbest; g1 = g1 && fmaxf(te1, r.tmin) <= tbest; }
+        if (g0 && g1) {
+            bool first0 = te0 <= te1;
+            int far = first0 ? c1 : c0;
+            node = first0 ? c0 : c1;
+            if (sp < kLdsStack) lds[sp * kBlock] = far; else if (sp < kLdsStack + kOvfStack) ovf[sp - kLdsStack] = far;
+            sp = min(sp + 1, kLdsStack + kOvfStack);
+        } else if (g0) node = c0;
+        else if (g1) node = c1;
+        else {
+            if (sp == 0) return true;
+            sp--;
+            node = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
+        }
+        return false;
+    }
+};
+
+// Traversal over the 4-wide quantised nodes.  Stack entries are child references: >= 0 a wide node, < 0 a triangle
+// (~leaf position), so triangle tests are postponed until their entry is popped.  A child box is dequantised to
+// floats (origin + q*scale, one exact fma) and then goes through the very same slab() as every other box, which keeps
+// the monotonicity argument of DESIGN.md 1.1 intact.
+constexpr int kOvfStack4 = 288; // 16 + 288 >= 3 pending siblings per level * 95 levels + 1
+template <bool ANY> struct Trav4 {
+    Ray r;
+    float tbest, bu, bv;
+    uint32_t bpos, bgid;
+    int cur, sp;
+    __device__ __forceinline__ void start(V3 o, V3 d, float tmin, float tmax) {
+        ray_init(r, o, d, tmin, tmax);
+        tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; cur = 0; sp = 0;
+    }
+    __device__ __forceinline__ void push(int ref, int *lds, int *ovf) {
+        if (sp < kLdsStack) lds[sp * kBlock] = ref; else if (sp < kLdsStack + kOvfStack4) ovf[sp - kLdsStack] = ref;
+        sp = min(sp + 1, kLdsStack + kOvfStack4);
+    }
+    __device__ __forceinline__ bool pop(int *lds, int *ovf) { // returns true when the stack is empty (ray finished)
+        if (sp == 0) return true;
+        sp--;
+        cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
+        return false;
+    }
+    __device__ __forceinline__ bool step(const DevNode4 *__restrict__ wide, const DevTri *__restrict__ tris, int *lds, int *ovf) {
+        if (cur >= 0) {
+            const uint4 *nq = reinterpret_cast<const uint4 *>(wide + cur);
+            uint4 a = nq[0], b = nq[1], c = nq[2], d = nq[3];
+            float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
+            float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
+            uint32_t mask = a.w >> 24;
+            int refs[4] = {(int)d.x, (int)d.y, (int)d.z, (int)d.w};
+            float te[4]; bool h[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float lx = fmaf((float)((b.x >> (8 * i)) & 255u), sx, ox), ly = fmaf((float)((b.y >> (8 * i)) & 255u), sy, oy), lz = fmaf((float)((b.z >> (8 * i)) & 255u), sz, oz);
+                float hx = fmaf((float)((b.w >> (8 * i)) & 255u), sx, ox), hy = fmaf((float)((c.x >> (8 * i)) & 255u), sy, oy), hz = fmaf((float)((c.y >> (8 * i)) & 255u), sz, oz);
+                h[i] = slab(r, lx, ly, lz, hx, hy, hz, tbest, te[i]) && ((mask >> i) & 1u);
+            }
+            // continue with the nearest hit child, stack the others
+            float tn = 3.0e38f; int ni = -1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (h[i] && te[i] < tn) { tn = te[i]; ni = i; }
+            if (ni < 0) return pop(lds, ovf);
+#pragma unroll
+            for (int i = 0; i < 4; i++) if (h[i] && i != ni) push(refs[i], lds, ovf);
+            cur = ni == 0 ? refs[0] : (ni == 1 ? refs[1] : (ni == 2 ? refs[2] : refs[3]));
+            return false;
+        }
+        uint32_t pos = (uint32_t)~cur;
+        const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
+        float4 va = tq[0], vb = tq[1], vc = tq[2];
+        float te;
+        if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+                 fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
+            float t, u, v;
+            if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
+                if (ANY) { bpos = pos; tbest = t; return true; }
+                float teff = fmaxf(t, te);
+                uint32_t gid = __float_as_uint(vc.w);
+                if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
+            }
+        }
+        return pop(lds, ovf);
+    }
+};
+
 // what a persistent tracing wave reads its rays from and writes its results to
 enum { MODE_PRIMARY = 0, MODE_SHADOW = 1, MODE_QUERY_CLOSEST = 2, MODE_QUERY_ANY = 3 };
 struct TraceArgs {
-    const DevNode *nodes; const DevTri *tris;
+    const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris;
     uint32_t total;          // candidate slots
+    uint32_t chunk, refill;  // slots a wave takes from a cursor at a time; idle lanes that trigger a refill (Aila & Laine 2009, dynamic fetch)
     uint32_t *cursors;       // 8 per-XCD chunk cursors, kCursorStride words apart (zeroed before the launch)
     uint32_t *count;         // rays actually traced (MODE_SHADOW), may be null
     // MODE_PRIMARY
@@ -179,25 +325,25 @@ struct TraceArgs {
 // finished it compacts the idle lanes with __ballot / mbcnt and hands them the next candidates of its chunk; chunks
 // come from eight per-XCD work cursors (one returning atomic per chunk), so neighbouring rays stay on one XCD's L2.
 // Every wave exits once all cursors are exhausted and its lanes are idle.
-template <int MODE>
+template <int MODE, int WIDTH>
 __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
     constexpr bool ANY = MODE == MODE_SHADOW || MODE == MODE_QUERY_ANY;
     __shared__ int stack[kLdsStack * kBlock];
-    int ovf[kOvfStack];
+    int ovf[WIDTH == 4 ? kOvfStack4 : kOvfStack];
     int *lds = &stack[threadIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_chunks = (a.total + kChunk - 1) / kChunk; // <= 2^25, so n_chunks * 8 fits
+    const uint32_t n_chunks = (a.total + a.chunk - 1) / a.chunk; // <= 2^25, so n_chunks * 8 fits
 
     uint32_t shard = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; // HW_REG_XCC_ID: speed only
     uint32_t shards_left = 8;
     uint32_t cur = 0, end = 0; // wave-uniform: the unread part of this wave's chunk
     bool exhausted = false, active = false;
-    Trav<ANY> tr;
+    typename std::conditional<WIDTH == 4, Trav4<ANY>, typename std::conditional<WIDTH == 1, TravQ<ANY>, Trav<ANY>>::type>::type tr;
     uint32_t slot = 0, traced = 0;
     for (;;) {
         uint64_t idle = __ballot(!active);
         uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (!exhausted && n_idle >= (uint32_t)kRefill) {
+        if (!exhausted && n_idle >= a.refill) {
             if (cur == end) { // take the next chunk: lane 0 pops, everyone learns the result
                 uint32_t got = 0xFFFFFFFFu;
                 if (lane == 0) {
@@ -212,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
                 shard = __builtin_amdgcn_readfirstlane(shard);
                 shards_left = __builtin_amdgcn_readfirstlane(shards_left);
                 if (got >= n_chunks) exhausted = true; // (also the never-expected out-of-range pop: no slot beyond total is touched)
-                else { cur = got * kChunk; end = min(cur + (uint32_t)kChunk, a.total); }
+                else { cur = got * a.chunk; end = min(cur + a.chunk, a.total); }
             }
             if (!exhausted) {
                 uint32_t avail = end - cur;
@@ -250,7 +396,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
             if (exhausted) break;
             continue;
         }
-        if (active && tr.step(a.nodes, a.tris, lds, ovf)) {
+        bool done = false;
+        if (active) { if constexpr (WIDTH == 4) done = tr.step(a.wide, a.tris, lds, ovf); else if constexpr (WIDTH == 1) done = tr.step(a.qnodes, a.tris, lds, ovf); else done = tr.step(a.nodes, a.tris, lds, ovf); }
+        if (done) {
             active = false;
             if (MODE == MODE_PRIMARY || MODE == MODE_QUERY_CLOSEST)
                 a.hits[slot] = tr.bpos != kNoHit ? make_float4(tr.tbest, tr.bu, tr.bv, __uint_as_float(tr.bpos))
@@ -265,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
     }
     if (MODE == MODE_SHADOW && a.count) { // rays this wave traced: one atomic per wave
         for (int off = 32; off >= 1; off >>= 1) traced += (uint32_t)__shfl_xor((int)traced, off);
-        if (lane == 0 && traced) atomicAdd(a.count, traced);
+        if (lane == 0 && traced) atomicAdd(a.count + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlotCount) * kSlotStride, traced);
     }
 }
 
@@ -314,11 +462,12 @@ __device__ V3 get_light_radiance(const ArtLight &l, V3 pos, V3 L) { // light.gls
     if (l.type == 1u || l.type == 3u) {
         float theta_s = acosf(clampf(dot3(ld3(l.dir), neg(L)), -1.0f, 1.0f));
         float t = clampf((theta_s - l.umbra_angle) / (l.penumbra_angle - l.umbra_angle), 0.0f, 1.0f);
-        rad = rad * powf(t, 2.0f);
+        rad = rad * (t * t);
     }
     if (l.falloff_distance > 0.0f) {
-        float dist = len3(ld3(l.pos) - pos);
-        rad = rad * powf(fmaxf(1.0f - powf(dist / l.falloff_distance, 2.0f), 0.0f), 2.0f);
+        float q = __fdividef(len3(ld3(l.pos) - pos), l.falloff_distance);
+        float w = fmaxf(1.0f - q * q, 0.0f);
+        rad = rad * (w * w);
     }
     return rad;
 }
@@ -328,18 +477,18 @@ __device__ V3 get_light_radiance(const ArtLight &l, V3 pos, V3 L) { // light.gls
 __device__ __forceinline__ float D_GGX(float a_, float NdotH) { // brdfs.glsl:6-14
     float om = 1.0f - NdotH * NdotH;
     float a = NdotH * a_;
-    float k = a_ / (om + a * a);
+    float k = __fdividef(a_, om + a * a);
     return k * k * ART_INV_PI;
 }
 __device__ __forceinline__ float V_SmithGGXCorrelated_fast(float a_, float NdotV, float NdotL) { // brdfs.glsl:25-29
-    return 0.5f / mixf(2.0f * NdotL * NdotV, NdotL + NdotV, a_);
+    return __fdividef(0.5f, mixf(2.0f * NdotL * NdotV, NdotL + NdotV, a_));
 }
-__device__ __forceinline__ float pow5(float x) { return powf(x, 5.0f); }
+__device__ __forceinline__ float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
 __device__ __forceinline__ float F_Schlick1(float F0, float F90, float x) { return F0 + (F90 - F0) * pow5(1.0f - x); } // brdfs.glsl:44-49
 __device__ float Burley_diffuse_local_sss(float a_, float NdotV, float nc_NdotV, float nc_NdotL, float LdotH, float ratio) { // brdfs.glsl:89-99
     float F_SS90 = a_ * LdotH * LdotH;
     float F_SS = F_Schlick1(1.0f, F_SS90, nc_NdotL) * F_Schlick1(1.0f, F_SS90, nc_NdotV);
-    float f_ss = (1.0f / (nc_NdotV * nc_NdotL) - 0.5f) * F_SS + 0.5f;
+    float f_ss = (__fdividef(1.0f, nc_NdotV * nc_NdotL) - 0.5f) * F_SS + 0.5f;
     float local_sss = 1.25f * ratio * f_ss;
     float f90 = 0.5f + 2.0f * F_SS90;
     float diffuse = (1.0f - ratio) * F_Schlick1(1.0f, f90, nc_NdotL) * F_Schlick1(1.0f, f90, nc_NdotV);
@@ -389,32 +538,29 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
             a.shadow_rays[2 * slot] = make_float4(0.f, 0.f, 0.f, -1.0f); // no shadow ray in this slot
         }
     } else {
-        const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
-        uint32_t pi = __float_as_uint(tq[0].w), tri = __float_as_uint(tq[1].w);
-        const DevPrim &P = a.prims[pi];
-        uint32_t i0, i1, i2; // get_indices, raytrace.rgen.glsl:55-66
-        if (P.single_index_size == 2) { const uint16_t *ix = (const uint16_t *)P.indices + 3 * (size_t)tri; i0 = ix[0]; i1 = ix[1]; i2 = ix[2]; }
-        else { const uint32_t *ix = (const uint32_t *)P.indices + 3 * (size_t)tri; i0 = ix[0]; i1 = ix[1]; i2 = ix[2]; }
-        const float *a0 = P.vertices + (size_t)i0 * 12, *a1 = P.vertices + (size_t)i1 * 12, *a2 = P.vertices + (size_t)i2 * 12;
+        // one dependent fetch: the shading record holds what get_indices + three vertex reads would return (rgen:107-114)
+        const float4 *sq = reinterpret_cast<const float4 *>(a.shade_tris + pos);
+        float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3], s4 = sq[4], s5 = sq[5], s6 = sq[6], s7 = sq[7], s8 = sq[8];
+        const DevPrim &P = a.prims[__float_as_uint(s8.z)];
         float bx = 1.0f - h.y - h.z, by = h.y, bz = h.z;
-        V3 posv = (ld3(a0) * bx + ld3(a1) * by) + ld3(a2) * bz;
+        V3 posv = (mk(s0.x, s0.y, s0.z) * bx + mk(s0.w, s1.x, s1.y) * by) + mk(s1.z, s1.w, s2.x) * bz;
         V3 world_pos = xform_point(P.o2w, posv);
-        float tu = (a0[3] * bx + a1[3] * by) + a2[3] * bz, tv = (a0[4] * bx + a1[4] * by) + a2[4] * bz;
-        V3 nrm = nrm3((ld3(a0 + 5) * bx + ld3(a1 + 5) * by) + ld3(a2 + 5) * bz);
+        float tu = (s2.y * bx + s2.w * by) + s3.y * bz, tv = (s2.z * bx + s3.x * by) + s3.z * bz;
+        V3 nrm = nrm3((mk(s3.w, s4.x, s4.y) * bx + mk(s4.z, s4.w, s5.x) * by) + mk(s5.y, s5.z, s5.w) * bz);
         const float *Wm = P.w2o;
         V3 world_normal = nrm3(mk(dot3(nrm, mk(Wm[0], Wm[4], Wm[8])), dot3(nrm, mk(Wm[1], Wm[5], Wm[9])), dot3(nrm, mk(Wm[2], Wm[6], Wm[10]))));
-        V3 tan = nrm3((ld3(a0 + 8) * bx + ld3(a1 + 8) * by) + ld3(a2 + 8) * bz);
+        V3 tan = nrm3((mk(s6.x, s6.y, s6.z) * bx + mk(s6.w, s7.x, s7.y) * by) + mk(s7.z, s7.w, s8.x) * bz);
         V3 world_tangent = nrm3(xform_vec(P.o2w, tan));
         world_tangent = nrm3(world_tangent - world_normal * dot3(world_tangent, world_normal));
-        V3 world_binormal = cross3(world_normal, world_tangent) * a0[11];
+        V3 world_binormal = cross3(world_normal, world_tangent) * s8.y;
         float4 tx = sample_tex(a.tex_pool, P, 2, tu, tv);
         V3 N = nrm3(mk(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f));
         N = nrm3((world_tangent * N.x + world_binormal * N.y) + world_normal * N.z);
         tx = sample_tex(a.tex_pool, P, 0, tu, tv);
-        V3 albedo = mk(powf(tx.x, 2.2f), powf(tx.y, 2.2f), powf(tx.z, 2.2f));
+        V3 albedo = mk(__powf(tx.x, 2.2f), __powf(tx.y, 2.2f), __powf(tx.z, 2.2f)); // radiance-only from here: fast intrinsics
         tx = sample_tex(a.tex_pool, P, 1, tu, tv);
         float roughness = tx.y, metallic = tx.z;
-        V3 Vv = nrm3(ld3(a.cam.camera_pos) - world_pos);
+        V3 Vv = fast_nrm3(ld3(a.cam.camera_pos) - world_pos);
         V3 F0 = mk(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
         float alpha = roughness * roughness;
         float nc_NdotV = dot3(N, Vv);
@@ -423,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
             const ArtLight &l = a.lights[i];
             V3 nn_L = get_unnormalized_L_vec(l, world_pos);
             V3 L = nrm3(nn_L);
-            V3 Hh = nrm3(Vv + L);
+            V3 Hh = fast_nrm3(Vv + L);
             float nc_NdotL = dot3(N, L);
             float NdotL = clampf(nc_NdotL, 0.0f, 1.0f);
             float NdotH = clampf(dot3(N, Hh), 0.0f, 1.0f);
@@ -458,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
     }
     if (a.shadow_bits) a.shadow_bits[p] = sbits;
     uint64_t hitmask = __ballot(pos != kNoHit); // hit-pixel count: one atomic per wave, off the critical path
-    if ((threadIdx.x & 63u) == 0 && hitmask) atomicAdd(&a.counters[1], (uint32_t)__popcll(hitmask));
+    if ((threadIdx.x & 63u) == 0 && hitmask) atomicAdd(&a.counters[kHitSlots + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlotCount) * kSlotStride], (uint32_t)__popcll(hitmask));
 }
 
 // rho += (rho_s + rho_d) * radiance * shadow_attenuation * NdotL (raytrace.rgen.glsl:185), lights in order
@@ -504,36 +650,43 @@ __global__ __launch_bounds__(kBlock) void k_untile(const float4 *__restrict__ ga
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 // persistent grid: enough waves to fill the chip (8 blocks of 4 waves per CU), never more than the work needs
 static inline uint32_t persistent_blocks(uint32_t total) {
-    uint32_t need = (total + kBlock - 1) / kBlock;
-    return need < 2048u ? (need ? need : 1u) : 2048u;
+    uint32_t need = (total + kBlock - 1) / kBlock, cap = tune().blocks;
+    return need < cap ? (need ? need : 1u) : cap;
+}
+template <int MODE> static void launch_trace(TraceArgs &a, int kind, hipStream_t s) {
+    uint32_t nb = persistent_blocks(a.total);
+    a.chunk = tune().chunk; a.refill = tune().refill;
+    if (kind == 4) k_trace<MODE, 4><<<nb, kBlock, 0, s>>>(a);
+    else if (kind == 1) k_trace<MODE, 1><<<nb, kBlock, 0, s>>>(a);
+    else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);
 }
 void launch_primary(const FrameArgs &f, hipStream_t s) {
     TraceArgs a{};
-    a.nodes = f.nodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
+    a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
-    k_trace<MODE_PRIMARY><<<persistent_blocks(a.total), kBlock, 0, s>>>(a);
+    launch_trace<MODE_PRIMARY>(a, f.trace_kind[0], s);
 }
 void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 void launch_shadow(const FrameArgs &f, hipStream_t s) {
     if (f.n_lights == 0) return;
     TraceArgs a{};
-    a.nodes = f.nodes; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters;
+    a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
-    k_trace<MODE_SHADOW><<<persistent_blocks(a.total), kBlock, 0, s>>>(a);
+    launch_trace<MODE_SHADOW>(a, f.trace_kind[1], s);
 }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 // queries: rays[2i] = o.xyz,tmin | rays[2i+1] = d.xyz,tmax;  cursors: 8 * kCursorStride zeroed words
-void launch_query_closest(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s) {
+void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s) {
     if (!n) return;
     TraceArgs a{};
-    a.nodes = nodes; a.tris = tris; a.total = n; a.cursors = cursors; a.rays = rays; a.hits = hits;
-    k_trace<MODE_QUERY_CLOSEST><<<persistent_blocks(n), kBlock, 0, s>>>(a);
+    a.nodes = b.nodes; a.wide = b.wide; a.qnodes = b.qnodes; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.hits = hits;
+    launch_trace<MODE_QUERY_CLOSEST>(a, b.kind, s);
 }
-void launch_query_any(const DevNode *nodes, const DevTri *tris, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s) {
+void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s) {
     if (!n) return;
     TraceArgs a{};
-    a.nodes = nodes; a.tris = tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
-    k_trace<MODE_QUERY_ANY><<<persistent_blocks(n), kBlock, 0, s>>>(a);
+    a.nodes = b.nodes; a.wide = b.wide; a.qnodes = b.qnodes; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
+    launch_trace<MODE_QUERY_ANY>(a, b.kind, s);
 }
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
     dim3 g((W + 31) / 32, (H + 7) / 8);
