@@ -35,7 +35,7 @@ class ArtCamera(C.Structure):
 
 class ArtConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("morton_bits", C.c_uint32),
-                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("frames_in_flight", C.c_uint32)]
 
 
 class ArtStats(C.Structure):
@@ -80,10 +80,13 @@ SYMBOLS = {
     "art_shard_layout": (_I32, [_U32, _U32, _U32, _U32, _P, _U32, _P, _P]),
     "art_shard_tile_count": (_I32, [_P, _P, _P]),
     "art_device_color_tiles": (_I32, [_P, _P, _P]),
-    "art_bind_color_tiles": (_I32, [_P, _P, _SZ]),
+    "art_bind_color_tiles": (_I32, [_P, _U32, _P, _SZ]),
+    "art_frames_in_flight": (_I32, [_P, _P, _P]),
+    "art_stream_wait_frame": (_I32, [_P, _P]),
+    "art_wait_external_event": (_I32, [_P, _P]),
     "art_collect_timings": (_I32, [_P, _P, _P]),
     "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
-    "art_untile_gathered": (_I32, [_P, _P, _U32, _P]),
+    "art_untile_gathered": (_I32, [_P, _P, _U32, _P, _P]),
     "art_get_stats": (_I32, [_P, _P]),
     "art_read_hits": (_I32, [_P, _P, _P, _SZ]),
     "art_read_shadow_bits": (_I32, [_P, _P, _SZ]),

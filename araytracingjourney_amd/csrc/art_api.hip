@@ -40,10 +40,28 @@ template <class T> struct DevBuf {
 
 } // namespace
 
+// one frame in flight: its own stream and per-frame buffers, like the reference's FrameData ring (renderer.rs:135, :300-318)
+struct FrameSlot {
+    hipStream_t own = nullptr;
+    DevBuf<uint32_t> d_counters, d_shadow_bits;
+    DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
+    DevBuf<float> d_depth;
+    float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
+    hipEvent_t done = nullptr;       // recorded after the slot's last frame
+    void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
+    void release() {
+        d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
+        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release();
+    }
+};
+constexpr uint32_t kMaxFrames = 4;
+
 struct ArtContext {
     ArtConfig cfg{};
     int device = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t ext_stream = nullptr; // art_set_stream (single frame in flight only)
+    uint32_t F = 1, last = 0;         // frames in flight; slot of the most recently submitted frame
+    FrameSlot slot[kMaxFrames];
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
@@ -54,18 +72,17 @@ struct ArtContext {
     uint32_t T = 0;
     ArtCamera camera{};
     std::vector<ArtLight> lights;
-    DevBuf<ArtLight> d_lights;
+    DevBuf<ArtLight> d_lights[2]; int lights_cur = 0; // double-buffered: frames in flight may still read the previous records
     // frame
     std::vector<uint32_t> tile_list; uint32_t tiles_x = 0, tiles_y = 0, padded_tiles = 0, n_local = 0;
-    DevBuf<uint32_t> d_tile_list, d_counters, d_shadow_bits;
-    DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
-    DevBuf<float> d_depth;
+    DevBuf<uint32_t> d_tile_list;
     static constexpr int kRing = 128;          // per-frame stage events kept for art_collect_timings
     hipEvent_t ev[kRing][5] = {};
     uint64_t frame_no = 0, collected_upto = 0;
-    float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
     bool traced = false;
     ArtStats stats{};
+    hipStream_t stream_of(uint32_t k) const { return (ext_stream && F == 1) ? ext_stream : slot[k].own; }
+    hipStream_t main_stream() const { return stream_of(0); }
 };
 
 namespace {
@@ -89,6 +106,11 @@ int32_t use_device(ArtContext *c) {
     return ART_OK;
 }
 
+int32_t sync_all(ArtContext *c) {
+    for (uint32_t k = 0; k < c->F; k++) HIPC(hipStreamSynchronize(c->stream_of(k)));
+    return ART_OK;
+}
+
 int32_t setup_frame(ArtContext *c) {
     // tile ownership + per-frame buffers for the current extent / light count
     c->tiles_x = (c->W + kTile - 1) / kTile; c->tiles_y = (c->H + kTile - 1) / kTile;
@@ -108,15 +130,19 @@ int32_t setup_frame(ArtContext *c) {
     size_t nl = c->lights.size() ? c->lights.size() : 1;
     HIPC(c->d_tile_list.ensure(c->tile_list.size()));
     if (!c->tile_list.empty()) HIPC(hipMemcpy(c->d_tile_list.p, c->tile_list.data(), c->tile_list.size() * 4, hipMemcpyHostToDevice));
-    HIPC(c->d_counters.ensure(kCounterWords));
-    HIPC(c->d_hits.ensure(c->n_local));
-    HIPC(c->d_contrib.ensure(nl * c->n_local));
-    HIPC(c->d_shadow_rays.ensure(2 * nl * c->n_local));
-    HIPC(c->d_color.ensure(npix)); HIPC(c->d_normal.ensure(npix)); HIPC(c->d_depth.ensure(npix));
-    HIPC(hipMemset(c->d_color.p, 0, npix * 16)); HIPC(hipMemset(c->d_normal.p, 0, npix * 16)); HIPC(hipMemset(c->d_depth.p, 0, npix * 4));
-    if (count > 1) { HIPC(c->d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(c->d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * 16)); }
-    if (c->cfg.flags & ART_FLAG_KEEP_DEBUG) HIPC(c->d_shadow_bits.ensure(c->n_local));
-    HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the context's stream is non-blocking
+    for (uint32_t k = 0; k < c->F; k++) {
+        FrameSlot &S = c->slot[k];
+        HIPC(S.d_counters.ensure(kCounterWords));
+        HIPC(S.d_hits.ensure(c->n_local));
+        HIPC(S.d_contrib.ensure(nl * c->n_local));
+        HIPC(S.d_shadow_rays.ensure(2 * nl * c->n_local));
+        HIPC(S.d_color.ensure(npix)); HIPC(S.d_normal.ensure(npix)); HIPC(S.d_depth.ensure(npix));
+        HIPC(hipMemset(S.d_color.p, 0, npix * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * 4));
+        if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * 16)); }
+        if (c->cfg.flags & ART_FLAG_KEEP_DEBUG) HIPC(S.d_shadow_bits.ensure(c->n_local));
+        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * 16) { S.ext_tiles = nullptr; S.ext_tiles_bytes = 0; }
+    }
+    HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
     c->frame_ready = true;
     return ART_OK;
 }
@@ -183,17 +209,21 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
         return fail(ART_E_NO_DEVICE, std::string("art_create: device is ") + prop.gcnArchName + ", libart is built for gfx950 only");
     if (cfg->morton_bits != 0 && cfg->morton_bits != 30 && cfg->morton_bits != 63) return fail(ART_E_INVALID, "art_create: morton_bits must be 0, 30 or 63");
     if (cfg->shard_count > 1 && cfg->shard_rank >= cfg->shard_count) return fail(ART_E_INVALID, "art_create: shard_rank >= shard_count");
+    if (cfg->frames_in_flight > kMaxFrames) return fail(ART_E_INVALID, "art_create: at most 4 frames in flight");
     ArtContext *c = new (std::nothrow) ArtContext();
     if (!c) return fail(ART_E_NOMEM, "art_create: out of memory");
     c->cfg = *cfg;
     if (c->cfg.morton_bits == 0) c->cfg.morton_bits = 63;
     c->device = dev;
+    c->F = cfg->frames_in_flight == 0 ? 1 : cfg->frames_in_flight;
     hipError_t e = hipSetDevice(dev);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    for (uint32_t k = 0; k < c->F && e == hipSuccess; k++) {
+        e = hipStreamCreateWithFlags(&c->slot[k].own, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming);
+    }
     for (int f = 0; f < ArtContext::kRing && e == hipSuccess; f++)
         for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[f][i]);
     if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
-    c->stream = c->own_stream;
     c->W = cfg->width; c->H = cfg->height;
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
         if (ok(w[0])) { c->kind_primary = w[0] - '0'; c->kind_shadow = ok(w[1]) ? w[1] - '0' : c->kind_primary; } }
@@ -204,21 +234,27 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
 int32_t art_destroy(ArtContext *c) {
     if (!c) return ART_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    for (uint32_t k = 0; k < c->F; k++) (void)hipStreamSynchronize(c->stream_of(k));
     lbvh_free(c->bvh);
-    c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release(); c->d_lights.release();
-    c->d_tile_list.release(); c->d_counters.release(); c->d_shadow_bits.release(); c->d_hits.release(); c->d_contrib.release();
-    c->d_shadow_rays.release(); c->d_color.release(); c->d_normal.release(); c->d_color_tiles.release(); c->d_depth.release();
+    c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release();
+    c->d_lights[0].release(); c->d_lights[1].release(); c->d_tile_list.release();
+    for (uint32_t k = 0; k < kMaxFrames; k++) {
+        c->slot[k].release();
+        if (c->slot[k].done) (void)hipEventDestroy(c->slot[k].done);
+        if (c->slot[k].own) (void)hipStreamDestroy(c->slot[k].own);
+    }
     for (int f = 0; f < ArtContext::kRing; f++)
         for (int i = 0; i < 5; i++) if (c->ev[f][i]) (void)hipEventDestroy(c->ev[f][i]);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return ART_OK;
 }
 
 int32_t art_set_stream(ArtContext *c, void *hip_stream) {
     if (!c) return fail(ART_E_INVALID, "art_set_stream: null context");
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (hip_stream && c->F > 1) return fail(ART_E_STATE, "art_set_stream: a context with several frames in flight owns its streams (use art_stream_wait_frame / art_wait_external_event)");
+    int32_t r = use_device(c); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    c->ext_stream = (hipStream_t)hip_stream;
     return ART_OK;
 }
 
@@ -257,7 +293,7 @@ int32_t art_scene_build(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "art_scene_build: null context");
     if (c->prims.empty()) return fail(ART_E_STATE, "art_scene_build: no primitives");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
+    r = sync_all(c); if (r) return r;
     lbvh_free(c->bvh); c->built = false;
     size_t nv = 0, ib = 0, nt = 0; uint32_t T = 0;
     for (auto &p : c->prims) { nv += p.verts.size(); ib += (p.indices.size() + 15) & ~(size_t)15; nt += (size_t)3 * p.tw * p.th; }
@@ -285,10 +321,10 @@ int32_t art_scene_build(ArtContext *c) {
     BuildInputs in{c->d_prims.p, (uint32_t)dp.size(), c->d_first_tri.p, T, c->cfg.morton_bits};
     hipEvent_t e0, e1;
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
-    HIPC(hipEventRecord(e0, c->stream));
-    hipError_t e = lbvh_build(in, c->bvh, c->stream);
+    HIPC(hipEventRecord(e0, c->main_stream()));
+    hipError_t e = lbvh_build(in, c->bvh, c->main_stream());
     if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "lbvh_build"); }
-    HIPC(hipEventRecord(e1, c->stream)); HIPC(hipEventSynchronize(e1));
+    HIPC(hipEventRecord(e1, c->main_stream())); HIPC(hipEventSynchronize(e1));
     float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     c->stats.build_ms = ms; c->stats.num_triangles = T; c->stats.num_primitives = (uint32_t)dp.size(); c->stats.num_nodes = c->kind_primary == 4 ? c->bvh.n_wide : (T > 1 ? T - 1 : 1);
@@ -333,10 +369,13 @@ int32_t art_set_lights(ArtContext *c, const ArtLight *lights, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) if (lights[i].type > 3) return fail(ART_E_INVALID, "art_set_lights: unknown light type");
     int32_t r = use_device(c); if (r) return r;
     bool resized = n != c->lights.size();
+    bool same = !resized && (n == 0 || std::memcmp(c->lights.data(), lights, (size_t)n * sizeof(ArtLight)) == 0);
+    if (same) return ART_OK; // like VkLights' dirty flag (vk_lights.rs:81-139)
     c->lights.assign(lights, lights + n);
-    HIPC(c->d_lights.ensure(n));
-    HIPC(hipStreamSynchronize(c->stream));
-    if (n) HIPC(hipMemcpy(c->d_lights.p, lights, (size_t)n * sizeof(ArtLight), hipMemcpyHostToDevice));
+    if (resized) { r = sync_all(c); if (r) return r; } // the per-frame buffers are resized with the light count
+    c->lights_cur ^= 1; // frames in flight keep reading the previous buffer
+    HIPC(c->d_lights[c->lights_cur].ensure(n));
+    if (n) HIPC(hipMemcpy(c->d_lights[c->lights_cur].p, lights, (size_t)n * sizeof(ArtLight), hipMemcpyHostToDevice));
     if (resized) c->frame_ready = false;
     return ART_OK;
 }
@@ -376,7 +415,7 @@ int32_t art_light_area(const float pos[3], const float pos2[3], const float pos3
 int32_t art_resize(ArtContext *c, uint32_t w, uint32_t h) {
     if (!c || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(ART_E_INVALID, "art_resize: bad extent");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
+    r = sync_all(c); if (r) return r;
     c->W = w; c->H = h; c->frame_ready = false; c->traced = false;
     return ART_OK;
 }
@@ -387,20 +426,23 @@ int32_t art_trace(ArtContext *c) {
     if (!c->have_camera) return fail(ART_E_STATE, "art_trace: no camera (art_set_camera)");
     if (c->W == 0 || c->H == 0) return fail(ART_E_STATE, "art_trace: zero extent (art_resize)");
     int32_t r = use_device(c); if (r) return r;
-    if (!c->frame_ready) { HIPC(hipStreamSynchronize(c->stream)); r = setup_frame(c); if (r) return r; }
+    if (!c->frame_ready) { r = sync_all(c); if (r) return r; r = setup_frame(c); if (r) return r; }
+    const uint32_t k = (uint32_t)(c->frame_no % c->F);
+    FrameSlot &S = c->slot[k];
+    hipStream_t s = c->stream_of(k);
+    if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
     FrameArgs a{};
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local;
-    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
-    a.lights = c->d_lights.p; a.n_lights = (uint32_t)c->lights.size();
-    a.hits = c->d_hits.p; a.contrib = c->d_contrib.p; a.shadow_rays = c->d_shadow_rays.p; a.counters = c->d_counters.p;
-    a.color = c->d_color.p; a.depth = c->d_depth.p; a.normal = c->d_normal.p;
-    a.color_tiles = c->cfg.shard_count > 1 ? (c->ext_tiles ? c->ext_tiles : c->d_color_tiles.p) : nullptr;
-    a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? c->d_shadow_bits.p : nullptr;
-    hipStream_t s = c->stream;
+    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
+    a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
+    a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
+    a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
+    a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr;
+    a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
-    HIPC(hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, s));
+    HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s));
     HIPC(hipEventRecord(ev[0], s));
     if (a.n_local) launch_primary(a, s);
     HIPC(hipEventRecord(ev[1], s));
@@ -410,7 +452,9 @@ int32_t art_trace(ArtContext *c) {
     HIPC(hipEventRecord(ev[3], s));
     if (a.n_local) launch_accumulate(a, s);
     HIPC(hipEventRecord(ev[4], s));
+    HIPC(hipEventRecord(S.done, s));
     HIPC(hipGetLastError());
+    c->last = k;
     c->frame_no++;
     c->traced = true;
     return ART_OK;
@@ -419,8 +463,7 @@ int32_t art_trace(ArtContext *c) {
 int32_t art_sync(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "art_sync: null context");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
-    return ART_OK;
+    return sync_all(c);
 }
 
 static int32_t read_back(ArtContext *c, const void *src, size_t have, void *dst, size_t bytes, const char *who) {
@@ -428,13 +471,13 @@ static int32_t read_back(ArtContext *c, const void *src, size_t have, void *dst,
     if (!c->traced) return fail(ART_E_STATE, std::string(who) + ": nothing traced yet");
     if (bytes != have) return fail(ART_E_INVALID, std::string(who) + ": size mismatch");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipStreamSynchronize(c->stream_of(c->last)));
     HIPC(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return ART_OK;
 }
-int32_t art_read_color(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->d_color.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_color"); }
-int32_t art_read_depth(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->d_depth.p : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_depth"); }
-int32_t art_read_normal(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->d_normal.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_normal"); }
+int32_t art_read_color(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_color.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_color"); }
+int32_t art_read_depth(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_depth.p : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_depth"); }
+int32_t art_read_normal(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_normal.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_normal"); }
 
 static int32_t dev_ptr(ArtContext *c, void *p, size_t n, void **out, size_t *bytes, const char *who) {
     if (!c || !out) return fail(ART_E_INVALID, std::string(who) + ": null argument");
@@ -443,9 +486,9 @@ static int32_t dev_ptr(ArtContext *c, void *p, size_t n, void **out, size_t *byt
     *out = nullptr; if (bytes) *bytes = n;
     return ART_OK;
 }
-int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color"); if (r) return r; *p = c->d_color.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
-int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
-int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->d_normal.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
+int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color"); if (r) return r; *p = c->slot[c->last].d_color.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
+int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
+int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->slot[c->last].d_normal.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 
 int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t *tiles, uint32_t cap, uint32_t *owned, uint32_t *padded) {
     if (width == 0 || height == 0) return fail(ART_E_INVALID, "art_shard_layout: zero extent");
@@ -475,22 +518,42 @@ int32_t art_shard_tile_count(ArtContext *c, uint32_t *owned, uint32_t *padded) {
 int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
     int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color_tiles"); if (r) return r;
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
-    *p = c->ext_tiles ? c->ext_tiles : c->d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * 16;
+    FrameSlot &S = c->slot[c->last];
+    *p = S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * 16;
     return ART_OK;
 }
-int32_t art_bind_color_tiles(ArtContext *c, void *dev, size_t bytes) {
+int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t bytes) {
     if (!c) return fail(ART_E_INVALID, "art_bind_color_tiles: null context");
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_bind_color_tiles: context is not sharded");
+    if (slot >= c->F) return fail(ART_E_INVALID, "art_bind_color_tiles: slot >= frames in flight");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_bind_color_tiles"); if (r) return r;
     if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * 16) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
-    HIPC(hipStreamSynchronize(c->stream));
-    c->ext_tiles = (float4 *)dev; c->ext_tiles_bytes = dev ? bytes : 0;
+    HIPC(hipStreamSynchronize(c->stream_of(slot)));
+    c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
+    return ART_OK;
+}
+int32_t art_frames_in_flight(ArtContext *c, uint32_t *frames, uint32_t *next_slot) {
+    if (!c) return fail(ART_E_INVALID, "art_frames_in_flight: null context");
+    if (frames) *frames = c->F;
+    if (next_slot) *next_slot = (uint32_t)(c->frame_no % c->F);
+    return ART_OK;
+}
+int32_t art_stream_wait_frame(ArtContext *c, void *hip_stream) {
+    if (!c) return fail(ART_E_INVALID, "art_stream_wait_frame: null context");
+    if (!c->traced) return fail(ART_E_STATE, "art_stream_wait_frame: nothing traced yet");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipStreamWaitEvent((hipStream_t)hip_stream, c->slot[c->last].done, 0));
+    return ART_OK;
+}
+int32_t art_wait_external_event(ArtContext *c, void *hip_event) {
+    if (!c) return fail(ART_E_INVALID, "art_wait_external_event: null context");
+    c->slot[c->frame_no % c->F].wait_event = hip_event;
     return ART_OK;
 }
 int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames) {
     if (!c || !sums_ms || !n_frames) return fail(ART_E_INVALID, "art_collect_timings: null argument");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
+    r = sync_all(c); if (r) return r;
     uint64_t from = c->collected_upto;
     if (c->frame_no - from > (uint64_t)ArtContext::kRing) from = c->frame_no - ArtContext::kRing;
     for (int k = 0; k < 5; k++) sums_ms[k] = 0.f;
@@ -506,14 +569,16 @@ int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames)
 }
 int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
     if (c && c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
-    return read_back(c, c ? (c->ext_tiles ? c->ext_tiles : c->d_color_tiles.p) : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * 16 : 0, dst, bytes, "art_read_color_tiles");
+    FrameSlot *S = c ? &c->slot[c->last] : nullptr;
+    return read_back(c, S ? (S->ext_tiles ? S->ext_tiles : S->d_color_tiles.p) : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * 16 : 0, dst, bytes, "art_read_color_tiles");
 }
-int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev) {
+int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream) {
     if (!c || !gathered_dev) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_untile_gathered"); if (r) return r;
     if (shard_count != (c->cfg.shard_count > 1 ? c->cfg.shard_count : 1)) return fail(ART_E_INVALID, "art_untile_gathered: shard_count differs from the context's");
     r = use_device(c); if (r) return r;
-    launch_untile((const float4 *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->d_color.p, c->stream);
+    launch_untile((const float4 *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->slot[c->last].d_color.p,
+                  hip_stream ? (hipStream_t)hip_stream : c->stream_of(c->last));
     HIPC(hipGetLastError());
     c->traced = true;
     return ART_OK;
@@ -523,9 +588,9 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
     if (!c || !out) return fail(ART_E_INVALID, "art_get_stats: null argument");
     if (c->traced && c->frame_ready) {
         int32_t r = use_device(c); if (r) return r;
-        HIPC(hipStreamSynchronize(c->stream));
+        r = sync_all(c); if (r) return r;
         std::vector<uint32_t> raw(kCounterWords);
-        HIPC(hipMemcpy(raw.data(), c->d_counters.p, kCounterWords * 4, hipMemcpyDeviceToHost));
+        HIPC(hipMemcpy(raw.data(), c->slot[c->last].d_counters.p, kCounterWords * 4, hipMemcpyDeviceToHost));
         uint64_t cnt[2] = {0, 0};
         for (uint32_t k = 0; k < kSlotCount; k++) { cnt[0] += raw[kShadowSlots + k * kSlotStride]; cnt[1] += raw[kHitSlots + k * kSlotStride]; }
         uint64_t owned = 0; // pixels of owned tiles that fall inside the frame
@@ -555,10 +620,10 @@ int32_t art_read_hits(ArtContext *c, float *tuv, int32_t *ids, size_t n_pixels) 
     if (!c->traced) return fail(ART_E_STATE, "art_read_hits: nothing traced yet");
     if (n_pixels != (size_t)c->W * c->H) return fail(ART_E_INVALID, "art_read_hits: size mismatch");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
+    r = sync_all(c); if (r) return r;
     std::vector<float4> h(c->n_local);
     std::vector<DevTri> tris(c->T);
-    HIPC(hipMemcpy(h.data(), c->d_hits.p, (size_t)c->n_local * 16, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(h.data(), c->slot[c->last].d_hits.p, (size_t)c->n_local * 16, hipMemcpyDeviceToHost));
     HIPC(hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n_pixels; i++) { tuv[4 * i] = 0; tuv[4 * i + 1] = 0; tuv[4 * i + 2] = 0; tuv[4 * i + 3] = 0; ids[2 * i] = -2; ids[2 * i + 1] = -2; } // -2: not owned
     for (uint32_t p = 0; p < c->n_local; p++) {
@@ -580,9 +645,9 @@ int32_t art_read_shadow_bits(ArtContext *c, uint32_t *bits, size_t n_pixels) {
     if (!c->traced) return fail(ART_E_STATE, "art_read_shadow_bits: nothing traced yet");
     if (n_pixels != (size_t)c->W * c->H) return fail(ART_E_INVALID, "art_read_shadow_bits: size mismatch");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
+    r = sync_all(c); if (r) return r;
     std::vector<uint32_t> sb(c->n_local);
-    HIPC(hipMemcpy(sb.data(), c->d_shadow_bits.p, (size_t)c->n_local * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(sb.data(), c->slot[c->last].d_shadow_bits.p, (size_t)c->n_local * 4, hipMemcpyDeviceToHost));
     std::memset(bits, 0, n_pixels * 4);
     for (uint32_t p = 0; p < c->n_local; p++) {
         uint32_t tile = c->tile_list[p >> 10], q = p & 1023u, sub = q >> 6, l = q & 63u;
@@ -605,10 +670,11 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     std::vector<float4> h(n);
     std::vector<DevTri> tris(c->T);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = c->d_counters.ensure(kCounterWords);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, c->stream);
-    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_primary}, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && sync_all(c) != ART_OK) e = hipErrorUnknown;
+    if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
+    if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
+    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_primary}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);
     (void)hipFree(d_r); (void)hipFree(d_h);
@@ -633,10 +699,11 @@ int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit
     if (e != hipSuccess) { (void)hipFree(d_r); return hipfail(e, "hipMalloc"); }
     std::vector<uint32_t> h(n);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = c->d_counters.ensure(kCounterWords);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_counters.p, 0, kCounterWords * 4, c->stream);
-    if (e == hipSuccess) { launch_query_any(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_shadow}, d_r, n, d_h, c->d_counters.p + 64 + 512, c->stream); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && sync_all(c) != ART_OK) e = hipErrorUnknown;
+    if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
+    if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
+    if (e == hipSuccess) { launch_query_any(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_shadow}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_r); (void)hipFree(d_h);
     if (e != hipSuccess) return hipfail(e, "art_query_any");
@@ -648,7 +715,7 @@ int32_t art_get_lbvh(ArtContext *c, uint32_t *leaf_gid, uint64_t *keys, int32_t 
     if (!c) return fail(ART_E_INVALID, "art_get_lbvh: null context");
     if (!c->built) return fail(ART_E_STATE, "art_get_lbvh: scene not built");
     int32_t r = use_device(c); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream));
+    r = sync_all(c); if (r) return r;
     size_t T = c->T, NI = T > 1 ? T - 1 : 0;
     if (leaf_gid) HIPC(hipMemcpy(leaf_gid, c->bvh.leaf_gid, T * 4, hipMemcpyDeviceToHost));
     if (keys) HIPC(hipMemcpy(keys, c->bvh.keys, T * 8, hipMemcpyDeviceToHost));

@@ -82,6 +82,7 @@ struct FrameArgs {
     const uint32_t *tile_list; uint32_t n_tiles_owned; uint32_t tiles_x; // owned 32x32 tiles
     uint32_t n_local;          // n_tiles_owned * 1024
     const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
+    bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
     int trace_kind[2];         // structure walked by primary / shadow rays: 2 binary, 4 wide quantised, 1 binary quantised
     const ArtLight *lights; uint32_t n_lights;
     float4 *hits;              // [n_local] t,u,v,gid

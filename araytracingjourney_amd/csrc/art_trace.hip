@@ -91,17 +91,24 @@ __device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v
 constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], conflict-free); deeper entries spill to scratch
 constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (63 key bits + 32 index bits)
 constexpr int kBlock = 256;
-// tunables of the persistent tracer (defaults; ART_CHUNK / ART_REFILL / ART_BLOCKS in the environment override them for sweeps)
-struct Tune { uint32_t chunk = 64, refill = 12, blocks = 1536; bool init = false; };
-static Tune g_tune;
-static const Tune &tune() {
-    if (!g_tune.init) {
-        if (const char *e = getenv("ART_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) g_tune.chunk = (uint32_t)v; }
-        if (const char *e = getenv("ART_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) g_tune.refill = (uint32_t)v; }
-        if (const char *e = getenv("ART_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 16384) g_tune.blocks = (uint32_t)v; }
-        g_tune.init = true;
+// tunables of the persistent tracer: {chunk, refill, blocks, leaf_batch}.  Measured on config 2 (profiles/README.md):
+// one frame at a time is bound by the slowest wave's critical path -> small chunks, more waves; several frames in flight
+// are throughput-bound -> fewer cursor atomics, fewer resident waves.  ART_CHUNK / ART_REFILL / ART_BLOCKS / ART_LEAF_BATCH
+// in the environment override both presets (sweeps).
+struct Tune { uint32_t chunk, refill, blocks, leaf_batch; };
+static Tune g_tune[2] = {{64, 12, 1536, 1}, {128, 24, 1024, 1}};
+static bool g_tune_init = false;
+static const Tune &tune(bool pipelined) {
+    if (!g_tune_init) {
+        for (int k = 0; k < 2; k++) {
+            if (const char *e = getenv("ART_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) g_tune[k].chunk = (uint32_t)v; }
+            if (const char *e = getenv("ART_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) g_tune[k].refill = (uint32_t)v; }
+            if (const char *e = getenv("ART_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) g_tune[k].leaf_batch = (uint32_t)v; }
+            if (const char *e = getenv("ART_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 16384) g_tune[k].blocks = (uint32_t)v; }
+        }
+        g_tune_init = true;
     }
-    return g_tune;
+    return g_tune[pipelined ? 1 : 0];
 }
 constexpr int kCursorStride = 32; // one 128-byte line per XCD cursor
 
@@ -114,135 +121,13 @@ __device__ __forceinline__ bool local_to_xy(uint32_t p, const uint32_t *__restri
     return x < W && y < H;
 }
 
-// One ray's traversal state over the binary LBVH; step() visits one node (both child boxes, leaf triangles at once).
-template <bool ANY> struct Trav {
-    Ray r;
-    float tbest, bu, bv;
-    uint32_t bpos, bgid;
-    int node, sp;
-    __device__ __forceinline__ void start(V3 o, V3 d, float tmin, float tmax) {
-        ray_init(r, o, d, tmin, tmax);
-        tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; node = 0; sp = 0;
-    }
-    // returns true when the ray is finished
-    __device__ __forceinline__ bool step(const DevNode *__restrict__ nodes, const DevTri *__restrict__ tris, int *lds, int *ovf) {
-        const float4 *nq = reinterpret_cast<const float4 *>(nodes + node);
-        float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
-        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-        float te0, te1;
-        bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0);
-        bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            bool h = k == 0 ? h0 : h1;
-            int c = k == 0 ? c0 : c1;
-            float te = k == 0 ? te0 : te1;
-            if (h && c < 0 && fmaxf(te, r.tmin) <= tbest) {
-                uint32_t pos = (uint32_t)~c;
-                const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
-                float4 a = tq[0], b = tq[1], cc = tq[2];
-                float t, u, v;
-                if (moller_trumbore(r, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(cc.x, cc.y, cc.z), t, u, v)) {
-                    if (ANY) { bpos = pos; tbest = t; return true; }
-                    float teff = fmaxf(t, te);
-                    uint32_t gid = __float_as_uint(cc.w);
-                    if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
-                }
-            }
-        }
-        bool g0 = h0 && c0 >= 0, g1 = h1 && c1 >= 0;
-        if (!ANY) { // the leaf tests above may have shortened the ray
-            g0 = g0 && fmaxf(te0, r.tmin) <= tbest;
-            g1 = g1 && fmaxf(te1, r.tmin) <= tbest;
-        }
-        if (g0 && g1) {
-            bool first0 = te0 <= te1;
-            int far = first0 ? c1 : c0;
-            node = first0 ? c0 : c1;
-            if (sp < kLdsStack) lds[sp * kBlock] = far; else if (sp < kLdsStack + kOvfStack) ovf[sp - kLdsStack] = far;
-            sp = min(sp + 1, kLdsStack + kOvfStack); // the radix tree cannot be deeper (95 levels); never index past the spill area
-        } else if (g0) node = c0;
-        else if (g1) node = c1;
-        else {
-            if (sp == 0) return true;
-            sp--;
-            node = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
-        }
-        return false;
-    }
-};
-
-// Traversal over the 32-byte quantised binary nodes: the binary walk above with two 16-byte loads per node.  A child box
-// is dequantised (origin + q*scale, one exact fma) and goes through the same slab(); a leaf's quantised box is looser
-// than its triangle's AABB, so the leaf test applies the exact triangle-AABB slab itself (accept() of DESIGN.md 1.1).
-template <bool ANY> struct TravQ {
-    Ray r;
-    float tbest, bu, bv;
-    uint32_t bpos, bgid;
-    int node, sp;
-    __device__ __forceinline__ void start(V3 o, V3 d, float tmin, float tmax) {
-        ray_init(r, o, d, tmin, tmax);
-        tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; node = 0; sp = 0;
-    }
-    __device__ __forceinline__ bool step(const DevNodeQ *__restrict__ qn, const DevTri *__restrict__ tris, int *lds, int *ovf) {
-        const uint4 *nq = reinterpret_cast<const uint4 *>(qn + node);
-        uint4 a = nq[0], b = nq[1];
-        float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
-        float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
-        uint32_t flags = a.w >> 24;
-        int c0 = (flags & 1u) ? (int)~b.w : (int)b.w, c1 = (flags & 2u) ? (int)~(b.w + 1u) : (int)(b.w + 1u);
-        float te0, te1;
-        bool h0 = slab(r, fmaf((float)(b.x & 255u), sx, ox), fmaf((float)((b.x >> 8) & 255u), sy, oy), fmaf((float)((b.x >> 16) & 255u), sz, oz),
-                       fmaf((float)(b.x >> 24), sx, ox), fmaf((float)(b.y & 255u), sy, oy), fmaf((float)((b.y >> 8) & 255u), sz, oz), tbest, te0);
-        bool h1 = slab(r, fmaf((float)((b.y >> 16) & 255u), sx, ox), fmaf((float)(b.y >> 24), sy, oy), fmaf((float)(b.z & 255u), sz, oz),
-                       fmaf((float)((b.z >> 8) & 255u), sx, ox), fmaf((float)((b.z >> 16) & 255u), sy, oy), fmaf((float)(b.z >> 24), sz, oz), tbest, te1) && !(flags & 4u);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            bool h = k == 0 ? h0 : h1;
-            int c = k == 0 ? c0 : c1;
-            float teq = k == 0 ? te0 : te1;
-            if (h && c < 0 && fmaxf(teq, r.tmin) <= tbest) {
-                uint32_t pos = (uint32_t)~c;
-                const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
-                float4 va = tq[0], vb = tq[1], vc = tq[2];
-                float te;
-                if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
-                         fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
-                    float t, u, v;
-                    if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
-                        if (ANY) { bpos = pos; tbest = t; return true; }
-                        float teff = fmaxf(t, te);
-                        uint32_t gid = __float_as_uint(vc.w);
-                        if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
-                    }
-                }
-            }
-        }
-        bool g0 = h0 && c0 >= 0, g1 = h1 && c1 >= 0;
-        if (!ANY) { g0 = g0 && fmaxf(te0, r.tmin) <= tbest; g1 = g1 && fmaxf(te1, r.tmin) <= tbest; }
-        if (g0 && g1) {
-            bool first0 = te0 <= te1;
-            int far = first0 ? c1 : c0;
-            node = first0 ? c0 : c1;
-            if (sp < kLdsStack) lds[sp * kBlock] = far; else if (sp < kLdsStack + kOvfStack) ovf[sp - kLdsStack] = far;
-            sp = min(sp + 1, kLdsStack + kOvfStack);
-        } else if (g0) node = c0;
-        else if (g1) node = c1;
-        else {
-            if (sp == 0) return true;
-            sp--;
-            node = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
-        }
-        return false;
-    }
-};
-
-// Traversal over the 4-wide quantised nodes.  Stack entries are child references: >= 0 a wide node, < 0 a triangle
-// (~leaf position), so triangle tests are postponed until their entry is popped.  A child box is dequantised to
-// floats (origin + q*scale, one exact fma) and then goes through the very same slab() as every other box, which keeps
-// the monotonicity argument of DESIGN.md 1.1 intact.
+// ---- per-ray traversal state --------------------------------------------------------------------------------------
+// `cur` and the stack hold child references: >= 0 an internal node of the structure being walked, < 0 a triangle
+// (~leaf position).  Internal steps and triangle tests are separate so that the wave can batch the triangle tests: the
+// Moeller-Trumbore block is ~150 instructions and, run whenever any single lane reaches a leaf, it was 60 % of all
+// issued instructions at ~2 % lane utilisation.
 constexpr int kOvfStack4 = 288; // 16 + 288 >= 3 pending siblings per level * 95 levels + 1
-template <bool ANY> struct Trav4 {
+template <bool ANY, int OVF> struct TravBase {
     Ray r;
     float tbest, bu, bv;
     uint32_t bpos, bgid;
@@ -252,40 +137,17 @@ template <bool ANY> struct Trav4 {
         tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; cur = 0; sp = 0;
     }
     __device__ __forceinline__ void push(int ref, int *lds, int *ovf) {
-        if (sp < kLdsStack) lds[sp * kBlock] = ref; else if (sp < kLdsStack + kOvfStack4) ovf[sp - kLdsStack] = ref;
-        sp = min(sp + 1, kLdsStack + kOvfStack4);
+        if (sp < kLdsStack) lds[sp * kBlock] = ref; else if (sp < kLdsStack + OVF) ovf[sp - kLdsStack] = ref;
+        sp = min(sp + 1, kLdsStack + OVF); // the tree cannot need more (see the bounds above); never index past the spill area
     }
-    __device__ __forceinline__ bool pop(int *lds, int *ovf) { // returns true when the stack is empty (ray finished)
+    __device__ __forceinline__ bool pop(int *lds, int *ovf) { // true: stack empty, the ray is finished
         if (sp == 0) return true;
         sp--;
         cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
         return false;
     }
-    __device__ __forceinline__ bool step(const DevNode4 *__restrict__ wide, const DevTri *__restrict__ tris, int *lds, int *ovf) {
-        if (cur >= 0) {
-            const uint4 *nq = reinterpret_cast<const uint4 *>(wide + cur);
-            uint4 a = nq[0], b = nq[1], c = nq[2], d = nq[3];
-            float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
-            float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
-            uint32_t mask = a.w >> 24;
-            int refs[4] = {(int)d.x, (int)d.y, (int)d.z, (int)d.w};
-            float te[4]; bool h[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float lx = fmaf((float)((b.x >> (8 * i)) & 255u), sx, ox), ly = fmaf((float)((b.y >> (8 * i)) & 255u), sy, oy), lz = fmaf((float)((b.z >> (8 * i)) & 255u), sz, oz);
-                float hx = fmaf((float)((b.w >> (8 * i)) & 255u), sx, ox), hy = fmaf((float)((c.x >> (8 * i)) & 255u), sy, oy), hz = fmaf((float)((c.y >> (8 * i)) & 255u), sz, oz);
-                h[i] = slab(r, lx, ly, lz, hx, hy, hz, tbest, te[i]) && ((mask >> i) & 1u);
-            }
-            // continue with the nearest hit child, stack the others
-            float tn = 3.0e38f; int ni = -1;
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (h[i] && te[i] < tn) { tn = te[i]; ni = i; }
-            if (ni < 0) return pop(lds, ovf);
-#pragma unroll
-            for (int i = 0; i < 4; i++) if (h[i] && i != ni) push(refs[i], lds, ovf);
-            cur = ni == 0 ? refs[0] : (ni == 1 ? refs[1] : (ni == 2 ? refs[2] : refs[3]));
-            return false;
-        }
+    // accept() of DESIGN.md 1.1 for the triangle in `cur`: exact triangle-AABB slab, then Moeller-Trumbore
+    __device__ __forceinline__ bool step_leaf(const DevTri *__restrict__ tris, int *lds, int *ovf) {
         uint32_t pos = (uint32_t)~cur;
         const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
         float4 va = tq[0], vb = tq[1], vc = tq[2];
@@ -302,6 +164,79 @@ template <bool ANY> struct Trav4 {
         }
         return pop(lds, ovf);
     }
+    // two children with hit flags / entry distances: continue with the nearer, stack the farther
+    __device__ __forceinline__ bool descend2(bool h0, bool h1, float te0, float te1, int c0, int c1, int *lds, int *ovf) {
+        if (h0 && h1) {
+            bool first0 = te0 <= te1;
+            push(first0 ? c1 : c0, lds, ovf);
+            cur = first0 ? c0 : c1;
+            return false;
+        }
+        if (h0) { cur = c0; return false; }
+        if (h1) { cur = c1; return false; }
+        return pop(lds, ovf);
+    }
+};
+
+// 64-byte binary nodes (DevNode): both child boxes in full precision
+template <bool ANY> struct Trav : TravBase<ANY, kOvfStack> {
+    using Nodes = const DevNode *;
+    __device__ __forceinline__ bool step_internal(Nodes nodes, int *lds, int *ovf) {
+        const float4 *nq = reinterpret_cast<const float4 *>(nodes + this->cur);
+        float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+        float te0, te1;
+        bool h0 = slab(this->r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, this->tbest, te0);
+        bool h1 = slab(this->r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, this->tbest, te1);
+        return this->descend2(h0, h1, te0, te1, __float_as_int(q3.x), __float_as_int(q3.y), lds, ovf);
+    }
+};
+
+// 32-byte quantised binary nodes (DevNodeQ): a child box is dequantised (origin + q*scale, one exact fma) and goes through
+// the same slab(), which keeps the monotonicity argument of DESIGN.md 1.1 intact
+template <bool ANY> struct TravQ : TravBase<ANY, kOvfStack> {
+    using Nodes = const DevNodeQ *;
+    __device__ __forceinline__ bool step_internal(Nodes qn, int *lds, int *ovf) {
+        const uint4 *nq = reinterpret_cast<const uint4 *>(qn + this->cur);
+        uint4 a = nq[0], b = nq[1];
+        float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
+        float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
+        uint32_t flags = a.w >> 24;
+        int c0 = (flags & 1u) ? (int)~b.w : (int)b.w, c1 = (flags & 2u) ? (int)~(b.w + 1u) : (int)(b.w + 1u);
+        float te0, te1;
+        bool h0 = slab(this->r, fmaf((float)(b.x & 255u), sx, ox), fmaf((float)((b.x >> 8) & 255u), sy, oy), fmaf((float)((b.x >> 16) & 255u), sz, oz),
+                       fmaf((float)(b.x >> 24), sx, ox), fmaf((float)(b.y & 255u), sy, oy), fmaf((float)((b.y >> 8) & 255u), sz, oz), this->tbest, te0);
+        bool h1 = slab(this->r, fmaf((float)((b.y >> 16) & 255u), sx, ox), fmaf((float)(b.y >> 24), sy, oy), fmaf((float)(b.z & 255u), sz, oz),
+                       fmaf((float)((b.z >> 8) & 255u), sx, ox), fmaf((float)((b.z >> 16) & 255u), sy, oy), fmaf((float)(b.z >> 24), sz, oz), this->tbest, te1) && !(flags & 4u);
+        return this->descend2(h0, h1, te0, te1, c0, c1, lds, ovf);
+    }
+};
+
+// 64-byte 4-wide quantised nodes (DevNode4)
+template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
+    using Nodes = const DevNode4 *;
+    __device__ __forceinline__ bool step_internal(Nodes wide, int *lds, int *ovf) {
+        const uint4 *nq = reinterpret_cast<const uint4 *>(wide + this->cur);
+        uint4 a = nq[0], b = nq[1], c = nq[2], d = nq[3];
+        float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
+        float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
+        uint32_t mask = a.w >> 24;
+        int refs[4] = {(int)d.x, (int)d.y, (int)d.z, (int)d.w};
+        float te[4]; bool h[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float lx = fmaf((float)((b.x >> (8 * i)) & 255u), sx, ox), ly = fmaf((float)((b.y >> (8 * i)) & 255u), sy, oy), lz = fmaf((float)((b.z >> (8 * i)) & 255u), sz, oz);
+            float hx = fmaf((float)((b.w >> (8 * i)) & 255u), sx, ox), hy = fmaf((float)((c.x >> (8 * i)) & 255u), sy, oy), hz = fmaf((float)((c.y >> (8 * i)) & 255u), sz, oz);
+            h[i] = slab(this->r, lx, ly, lz, hx, hy, hz, this->tbest, te[i]) && ((mask >> i) & 1u);
+        }
+        float tn = 3.0e38f; int ni = -1; // continue with the nearest hit child, stack the others
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (h[i] && te[i] < tn) { tn = te[i]; ni = i; }
+        if (ni < 0) return this->pop(lds, ovf);
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (h[i] && i != ni) this->push(refs[i], lds, ovf);
+        this->cur = ni == 0 ? refs[0] : (ni == 1 ? refs[1] : (ni == 2 ? refs[2] : refs[3]));
+        return false;
+    }
 };
 
 // what a persistent tracing wave reads its rays from and writes its results to
@@ -309,6 +244,7 @@ enum { MODE_PRIMARY = 0, MODE_SHADOW = 1, MODE_QUERY_CLOSEST = 2, MODE_QUERY_ANY
 struct TraceArgs {
     const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris;
     uint32_t total;          // candidate slots
+    uint32_t leaf_batch;     // lanes that must wait on a triangle before the wave runs the triangle test
     uint32_t chunk, refill;  // slots a wave takes from a cursor at a time; idle lanes that trigger a refill (Aila & Laine 2009, dynamic fetch)
     uint32_t *cursors;       // 8 per-XCD chunk cursors, kCursorStride words apart (zeroed before the launch)
     uint32_t *count;         // rays actually traced (MODE_SHADOW), may be null
@@ -330,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
     constexpr bool ANY = MODE == MODE_SHADOW || MODE == MODE_QUERY_ANY;
     __shared__ int stack[kLdsStack * kBlock];
     int ovf[WIDTH == 4 ? kOvfStack4 : kOvfStack];
+    const uint32_t leaf_batch = a.leaf_batch;
     int *lds = &stack[threadIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_chunks = (a.total + a.chunk - 1) / a.chunk; // <= 2^25, so n_chunks * 8 fits
@@ -396,8 +333,19 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
             if (exhausted) break;
             continue;
         }
+        // one internal step for every lane standing on a node ...
         bool done = false;
-        if (active) { if constexpr (WIDTH == 4) done = tr.step(a.wide, a.tris, lds, ovf); else if constexpr (WIDTH == 1) done = tr.step(a.qnodes, a.tris, lds, ovf); else done = tr.step(a.nodes, a.tris, lds, ovf); }
+        if (active && tr.cur >= 0) {
+            if constexpr (WIDTH == 4) done = tr.step_internal(a.wide, lds, ovf);
+            else if constexpr (WIDTH == 1) done = tr.step_internal(a.qnodes, lds, ovf);
+            else done = tr.step_internal(a.nodes, lds, ovf);
+        }
+        // ... and the triangle tests only once enough lanes wait on one (or nobody can move without it)
+        bool on_leaf = active && !done && tr.cur < 0;
+        uint64_t lm = __ballot(on_leaf);
+        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_batch || __ballot(active && !done && tr.cur >= 0) == 0ull)) {
+            if (on_leaf) done = tr.step_leaf(a.tris, lds, ovf);
+        }
         if (done) {
             active = false;
             if (MODE == MODE_PRIMARY || MODE == MODE_QUERY_CLOSEST)
@@ -649,13 +597,14 @@ __global__ __launch_bounds__(kBlock) void k_untile(const float4 *__restrict__ ga
 // ------------------------------------------------------------------------------------------------ launchers
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 // persistent grid: enough waves to fill the chip (8 blocks of 4 waves per CU), never more than the work needs
-static inline uint32_t persistent_blocks(uint32_t total) {
-    uint32_t need = (total + kBlock - 1) / kBlock, cap = tune().blocks;
+static inline uint32_t persistent_blocks(uint32_t total, bool pipelined) {
+    uint32_t need = (total + kBlock - 1) / kBlock, cap = tune(pipelined).blocks;
     return need < cap ? (need ? need : 1u) : cap;
 }
-template <int MODE> static void launch_trace(TraceArgs &a, int kind, hipStream_t s) {
-    uint32_t nb = persistent_blocks(a.total);
-    a.chunk = tune().chunk; a.refill = tune().refill;
+template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipelined, hipStream_t s) {
+    uint32_t nb = persistent_blocks(a.total, pipelined);
+    const Tune &t = tune(pipelined);
+    a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = t.leaf_batch;
     if (kind == 4) k_trace<MODE, 4><<<nb, kBlock, 0, s>>>(a);
     else if (kind == 1) k_trace<MODE, 1><<<nb, kBlock, 0, s>>>(a);
     else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);
@@ -664,7 +613,7 @@ void launch_primary(const FrameArgs &f, hipStream_t s) {
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
-    launch_trace<MODE_PRIMARY>(a, f.trace_kind[0], s);
+    launch_trace<MODE_PRIMARY>(a, f.trace_kind[0], f.pipelined, s);
 }
 void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 void launch_shadow(const FrameArgs &f, hipStream_t s) {
@@ -672,7 +621,7 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
-    launch_trace<MODE_SHADOW>(a, f.trace_kind[1], s);
+    launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 // queries: rays[2i] = o.xyz,tmin | rays[2i+1] = d.xyz,tmax;  cursors: 8 * kCursorStride zeroed words
@@ -680,13 +629,13 @@ void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, floa
     if (!n) return;
     TraceArgs a{};
     a.nodes = b.nodes; a.wide = b.wide; a.qnodes = b.qnodes; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.hits = hits;
-    launch_trace<MODE_QUERY_CLOSEST>(a, b.kind, s);
+    launch_trace<MODE_QUERY_CLOSEST>(a, b.kind, false, s);
 }
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s) {
     if (!n) return;
     TraceArgs a{};
     a.nodes = b.nodes; a.wide = b.wide; a.qnodes = b.qnodes; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
-    launch_trace<MODE_QUERY_ANY>(a, b.kind, s);
+    launch_trace<MODE_QUERY_ANY>(a, b.kind, false, s);
 }
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
     dim3 g((W + 31) / 32, (H + 7) / 8);

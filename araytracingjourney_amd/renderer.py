@@ -168,11 +168,11 @@ class Camera:
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
-    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False):
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1):
         self._L = _lib.load()
         w, h = extent
         cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
-                        flags=_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0, reserved=0)
+                        flags=_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0, frames_in_flight=frames_in_flight)
         self._ctx = C.c_void_p()
         check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))
         self.extent = (w, h)
@@ -278,8 +278,19 @@ class Renderer:
         check(self._L.art_device_color_tiles(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def bind_color_tiles(self, dev_ptr, nbytes):
-        check(self._L.art_bind_color_tiles(self._ctx, C.c_void_p(dev_ptr) if dev_ptr else None, nbytes))
+    def bind_color_tiles(self, slot, dev_ptr, nbytes):
+        check(self._L.art_bind_color_tiles(self._ctx, slot, C.c_void_p(dev_ptr) if dev_ptr else None, nbytes))
+
+    def frames_in_flight(self):
+        f, nxt = C.c_uint32(), C.c_uint32()
+        check(self._L.art_frames_in_flight(self._ctx, C.byref(f), C.byref(nxt)))
+        return f.value, nxt.value
+
+    def stream_wait_frame(self, hip_stream_ptr):
+        check(self._L.art_stream_wait_frame(self._ctx, C.c_void_p(hip_stream_ptr)))
+
+    def wait_external_event(self, hip_event_ptr):
+        check(self._L.art_wait_external_event(self._ctx, C.c_void_p(hip_event_ptr)))
 
     def collect_timings(self):
         sums = (C.c_float * 5)()
@@ -300,8 +311,9 @@ class Renderer:
         check(self._L.art_shard_tile_count(self._ctx, C.byref(o), C.byref(pd)))
         return o.value, pd.value
 
-    def untile_gathered(self, gathered_dev_ptr, shard_count, frame_dev_ptr=None):
-        check(self._L.art_untile_gathered(self._ctx, C.c_void_p(gathered_dev_ptr), shard_count, C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None))
+    def untile_gathered(self, gathered_dev_ptr, shard_count, frame_dev_ptr=None, hip_stream_ptr=None):
+        check(self._L.art_untile_gathered(self._ctx, C.c_void_p(gathered_dev_ptr), shard_count, C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None,
+                                          C.c_void_p(hip_stream_ptr) if hip_stream_ptr else None))
 
     def stats(self) -> dict:
         st = ArtStats()

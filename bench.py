@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1, choices=[1, 4])
     ap.add_argument("--detail", type=float, default=1.0, help="scene detail (1.0 = the 262k-triangle config)")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="ring of per-frame streams/buffers, like the reference's 3-deep FrameData ring (renderer.rs:135)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
 
     import numpy as np
@@ -56,34 +58,58 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libart has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     W, H = args.width, args.height
     sc = scenes.sponza_like(args.detail)
     lights = scenes.sponza_lights(args.lights)
     sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world))
-    stream = torch.cuda.Stream()      # a real (non-null) stream shared by libart's kernels, torch's events and RCCL's waits
-    torch.cuda.set_stream(stream)
-    r.set_stream(stream.cuda_stream)
+    F = max(1, min(4, args.frames_in_flight))
+    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F)
     r.upload_state()
+    stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
+    torch.cuda.set_stream(stream)
 
-    gathered = tiles = None
+    tiles = gathered = frame = None
+    consumed = [None] * F             # per ring slot: event "the gather that read this slot's tiles has finished"
     if world > 1:
         owned, padded = r.shard_tile_count()
-        tiles = torch.zeros((padded, 32, 32, 4), dtype=torch.float32, device="cuda")
-        r.bind_color_tiles(tiles.data_ptr(), tiles.numel() * 4)
+        tiles = [torch.zeros((padded, 32, 32, 4), dtype=torch.float32, device="cuda") for _ in range(F)]
+        for k in range(F):
+            r.bind_color_tiles(k, tiles[k].data_ptr(), tiles[k].numel() * 4)
         if rank == 0:
-            gathered = torch.empty((world, padded, 32, 32, 4), dtype=torch.float32, device="cuda")
+            gathered = [torch.empty((world, padded, 32, 32, 4), dtype=torch.float32, device="cuda") for _ in range(F)]
+            frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
 
     def step():
+        if world == 1:
+            r.trace()                 # primary + shade + shadow + accumulate on the next ring slot's stream
+            return
+        _, k = r.frames_in_flight()
+        if consumed[k] is not None:
+            r.wait_external_event(consumed[k].cuda_event)   # do not overwrite tiles a gather is still reading
         r.trace()
-        if world > 1:
-            dist.gather(tiles, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+        r.stream_wait_frame(stream.cuda_stream)             # torch's stream (hence RCCL) waits for this frame only
+        if args.backend == "nccl":
+            dist.gather(tiles[k], list(gathered[k].unbind(0)) if rank == 0 else None, dst=0)
+        else:   # rehearsal: same call sequence, payload through host memory
+            host = tiles[k].cpu()
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
             if rank == 0:
-                r.untile_gathered(gathered.data_ptr(), world)
+                gathered[k].copy_(torch.stack(parts))
+        if rank == 0:
+            r.untile_gathered(gathered[k].data_ptr(), world, frame.data_ptr(), stream.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        consumed[k] = ev
 
     def fence():
+        r.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -93,20 +119,29 @@ def main():
         step()
     fence()
     r.collect_timings()  # drop the warm-up frames from the per-stage event sums
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record(stream)
     for _ in range(args.steps):
         step()
-    e1.record(stream)
     fence()
     wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    stage, n_timed = r.collect_timings()  # HIP events on the same stream, over the timed frames (last <= 128)
+    stage, n_timed = r.collect_timings()  # HIP events on the frames' own streams, over the timed frames (last <= 128)
+    # the same kernels with ONE frame on the GPU at a time (not part of the timed region; for the isolated roofline figure)
+    iso = {}
+    for _ in range(8):
+        step()
+        fence()
+    iso, _ = r.collect_timings()
 
     st = r.stats()
     rays_local = st["primary_rays"] + st["shadow_rays"]
-    t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["primary_ms"], stage["shadow_ms"], stage["shade_ms"], stage["frame_ms"]],
+    # outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit
+    frame_ok = None
+    if world > 1 and rank == 0:
+        whole = renderer.renderer_for_scene(sc, (W, H), device=local_rank)
+        whole.render_frame()
+        frame_ok = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), whole.read_color().view(np.uint32)))
+        whole.close()
+    t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["primary_ms"], stage["shadow_ms"], stage["shade_ms"], stage["frame_ms"], iso["primary_ms"], iso["shadow_ms"]],
                      dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone()
@@ -116,6 +151,7 @@ def main():
         wall = float(tmax[0])
         rays_total, shadow_total = float(tsum[1]), float(tsum[2])
         stage_max = dict(primary_ms=float(tmax[3]), shadow_ms=float(tmax[4]), shade_ms=float(tmax[5]), frame_ms=float(tmax[6]))
+        iso = dict(iso, primary_ms=float(tmax[7]), shadow_ms=float(tmax[8]))
     else:
         rays_total, shadow_total = float(rays_local), float(st["shadow_rays"])
         stage_max = stage
@@ -170,8 +206,10 @@ def main():
         dur_ms = stage_max[f"{dom}_ms"]
         per_launch = ab[dom] / world  # each rank's launch handles 1/world of the frame's rays
         achieved = per_launch / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        iso_ms = iso[f"{dom}_ms"]
         roof = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
-                    algorithmic_bytes_per_launch=per_launch, kernel_ms=dur_ms, frames_timed=n_timed,
+                    algorithmic_bytes_per_launch=per_launch, kernel_ms=dur_ms, frames_timed=n_timed, frames_in_flight=F,
+                    kernel_ms_alone=iso_ms, frac_alone=(per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else None,
                     frame_algorithmic_bytes=ab["frame"], frame_frac=ab["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     note="working set (BVH + triangles, ~30 MB) is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes")
 
@@ -181,9 +219,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"sponza_like(seed=0x5A0A, {sc.n_tris} triangles, 25 primitives) {W}x{H}, {args.lights} light(s), "
                                f"{int(shadow_total)} shadow rays/frame", "width": W, "height": H, "lights": args.lights,
-                   "parallelism": "single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather to rank 0"},
-        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "device_ms_per_step_rank0": dev_ms / args.steps,
-        "stage_ms": stage_max, "build_ms": st["build_ms"],
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather to rank 0") + f", {F} frames in flight"},
+        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F,
+        "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "build_ms": st["build_ms"],
+        "gathered_frame_equals_single_gpu_frame": frame_ok,
         "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(line))

@@ -71,7 +71,8 @@ typedef struct ArtConfig {
     uint32_t shard_rank;  /* screen-tile sharding: this context renders the 32x32 tiles owned by shard_rank of */
     uint32_t shard_count; /*   shard_count (0 or 1 = whole frame) */
     uint32_t flags;       /* ART_FLAG_* */
-    uint32_t reserved;
+    uint32_t frames_in_flight; /* 0|1 = one; up to 4: a ring of per-frame streams + buffers like the reference's FrameData
+                                  ring (renderer.rs:135, :300-318); art_trace then returns while up to N-1 older frames run */
 } ArtConfig;
 
 #define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits) */
@@ -98,8 +99,16 @@ int32_t art_device_count(void);
 /* VulkanTempleRayTracedRenderer::new (renderer.rs:140) / Drop */
 int32_t art_create(const ArtConfig *cfg, ArtContext **out);
 int32_t art_destroy(ArtContext *ctx);
-/* use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream */
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream.
+ * Only for one frame in flight: a ring owns its streams, see art_stream_wait_frame / art_wait_external_event. */
 int32_t art_set_stream(ArtContext *ctx, void *hip_stream);
+/* frame ring: number of slots and the slot the NEXT art_trace will use */
+int32_t art_frames_in_flight(ArtContext *ctx, uint32_t *frames, uint32_t *next_slot);
+/* make an external stream wait (on the device) for the most recently traced frame */
+int32_t art_stream_wait_frame(ArtContext *ctx, void *hip_stream);
+/* make the NEXT art_trace wait (on the device) for an external hipEvent_t, e.g. "the gather that read this slot's tiles
+ * three frames ago has finished" */
+int32_t art_wait_external_event(ArtContext *ctx, void *hip_event);
 
 /* add_model (renderer.rs:346) -> VkModel::create_blas geometry contract (vk_model.rs:886-943): one call per glTF
  * primitive.  idx_bytes = 2|4 (vk_model.rs:142-150); rgba8 = 3 layers albedo/ORM/normal of tw x th texels
@@ -138,7 +147,8 @@ int32_t art_sync(ArtContext *ctx);
 
 /* get_color_output_image / get_output_depth_image / get_output_normal_image (vk_rt_lightning_shadows.rs:161-183):
  * fp32 RGBA colour (the value passed to imageStore, before the reference's lossy image formats), fp32 depth,
- * fp32 RGBA normal; row-major full frame.  Host copies (synchronising) and raw device pointers. */
+ * fp32 RGBA normal; row-major full frame, of the most recently traced frame.  Host copies (synchronising) and raw device
+ * pointers (with a frame ring: valid until frames_in_flight - 1 more frames have been traced). */
 int32_t art_read_color(ArtContext *ctx, void *dst, size_t bytes);
 int32_t art_read_depth(ArtContext *ctx, void *dst, size_t bytes);
 int32_t art_read_normal(ArtContext *ctx, void *dst, size_t bytes);
@@ -155,11 +165,12 @@ int32_t art_shard_tile_count(ArtContext *ctx, uint32_t *owned, uint32_t *padded)
 int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t *tiles,
                          uint32_t cap, uint32_t *owned, uint32_t *padded);
 int32_t art_device_color_tiles(ArtContext *ctx, void **dev_ptr, size_t *bytes);
-/* render the compact tiles straight into a caller-owned device buffer (e.g. the tensor handed to the gather);
- * bytes must equal padded * 16 KiB; NULL unbinds */
-int32_t art_bind_color_tiles(ArtContext *ctx, void *dev_ptr, size_t bytes);
+/* render ring slot `slot`'s compact tiles straight into a caller-owned device buffer (e.g. the tensor handed to the
+ * gather); bytes must equal padded * 16 KiB; NULL unbinds */
+int32_t art_bind_color_tiles(ArtContext *ctx, uint32_t slot, void *dev_ptr, size_t bytes);
 int32_t art_read_color_tiles(ArtContext *ctx, void *dst, size_t bytes); /* host copy of the same buffer (tests) */
-int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev);
+/* frame_dev NULL = the context's colour buffer; hip_stream NULL = the latest frame's stream */
+int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream);
 
 int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
 /* device time per stage (HIP events on the context's stream) summed over the frames traced since the previous call

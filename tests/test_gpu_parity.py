@@ -122,6 +122,29 @@ def test_sharded_tiles_gather_to_the_unsharded_frame(R, get_scene):
         s.close()
 
 
+def test_frame_ring_gives_the_same_frames(R, get_scene):
+    """3 frames in flight (the reference's FrameData ring, renderer.rs:135): every frame equals the single-slot render"""
+    sc = get_scene("cornell")
+    one = R.renderer_for_scene(sc, (160, 96))
+    ring = R.renderer_for_scene(sc, (160, 96), frames_in_flight=3)
+    assert ring.frames_in_flight() == (3, 0)
+    for i in range(7):
+        pos = (0.02 * i, 0.0, -0.95)
+        for r in (one, ring):
+            r.camera_mut().set_pos(pos)
+            r.upload_state()
+            r.trace()
+        assert ring.frames_in_flight()[1] == (i + 1) % 3
+        assert np.array_equal(ring.read_color().view(np.uint32), one.read_color().view(np.uint32)), i
+        assert np.array_equal(ring.read_depth().view(np.uint32), one.read_depth().view(np.uint32))
+    for i in range(9):          # same camera, no host sync between frames
+        ring.trace()
+    assert np.array_equal(ring.read_color().view(np.uint32), one.read_color().view(np.uint32))
+    assert ring.stats()["shadow_rays"] == one.stats()["shadow_rays"]
+    one.close()
+    ring.close()
+
+
 def test_single_triangle_known_answers(R):
     """analytic KAT through the GPU: one triangle, hand-computed t/u/v, edge, parallel, behind, range cases"""
     from araytracingjourney_amd import scenes
