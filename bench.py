@@ -56,6 +56,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libart has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()   # rehearsal: ranks may share one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -173,6 +175,12 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import orc
         ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+        try:  # a cgroup CPU quota (e.g. 16 CPUs of a 256-thread host) is the real core budget
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                ncores = max(1, min(ncores, int(int(q) / int(per))))
+        except Exception:
+            pass
         S = orc.Scene(sc.primitives, morton_bits=30)
         cam = orc.camera_from_params(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
         L = orc.make_lights(lights)
@@ -185,13 +193,13 @@ def main():
             cdt = time.perf_counter() - c0
         rays1 = cst["primary_rays"] + cst["shadow_rays"]
         c1 = time.perf_counter()
-        st1 = S.render(cam, L, len(lights), W, H, H // 2 - 16, H // 2 + 16, threads=1)["stats"]   # one thread, a 32-row band
+        st1 = S.render(cam, L, len(lights), W, H, H // 2 - 128, H // 2 + 128, threads=1, reuse=True)["stats"]   # one thread, a 256-row band
         dt1 = time.perf_counter() - c1
         cpu = dict(value=rays1 * reps / cdt / 1e6, unit="Mray/s", cores=ncores, kind="port",
                    value_1thread=(st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6,
                    sample=f"the same {W}x{H} frame x {reps} repetitions ({rays1} rays each, {cdt:.1f} s wall) on {ncores} threads; 1-thread figure "
-                          f"on rows [{H // 2 - 16},{H // 2 + 16}) ({dt1:.1f} s); scalar C oracle (stands in for the scalar Rust tracer: no Rust "
-                          "toolchain in this image), pthreads over 4-row bands")
+                          f"on rows [{H // 2 - 128},{H // 2 + 128}) ({dt1:.1f} s); scalar C oracle (stands in for the scalar Rust tracer: no Rust "
+                          "toolchain in this image), pthreads over 1-row bands")
         if ost is None:
             ost = cst
     if ost is not None and world == 1:

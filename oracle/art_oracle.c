@@ -820,9 +820,9 @@ static void *worker(void *arg) {
     Job *J = (Job *)arg;
     OrcStats st; memset(&st, 0, sizeof(st));
     for (;;) {
-        uint32_t y = __sync_fetch_and_add(J->next_row, 4u);
+        uint32_t y = __sync_fetch_and_add(J->next_row, 1u);
         if (y >= J->y1) break;
-        uint32_t ye = y + 4 < J->y1 ? y + 4 : J->y1;
+        uint32_t ye = y + 1;
         for (uint32_t yy = y; yy < ye; yy++)
             for (uint32_t x = 0; x < J->w; x++) render_pixel(J, &st, x, yy);
     }
