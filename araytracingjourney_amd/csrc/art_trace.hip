@@ -30,7 +30,6 @@ __device__ __forceinline__ V3 cross3(V3 a, V3 b) {
 }
 __device__ __forceinline__ float len3(V3 a) { return sqrtf(dot3(a, a)); }
 __device__ __forceinline__ V3 nrm3(V3 a) { float inv = 1.0f / sqrtf(dot3(a, a)); return a * inv; }
-__device__ __forceinline__ V3 fast_nrm3(V3 a) { return a * __frsqrt_rn(dot3(a, a)); } // radiance-only values
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 __device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
@@ -508,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
         V3 albedo = mk(__powf(tx.x, 2.2f), __powf(tx.y, 2.2f), __powf(tx.z, 2.2f)); // radiance-only from here: fast intrinsics
         tx = sample_tex(a.tex_pool, P, 1, tu, tv);
         float roughness = tx.y, metallic = tx.z;
-        V3 Vv = fast_nrm3(ld3(a.cam.camera_pos) - world_pos);
+        V3 Vv = nrm3(ld3(a.cam.camera_pos) - world_pos); // exact: V + L cancels at grazing angles and would amplify a 1-ulp rsq
         V3 F0 = mk(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
         float alpha = roughness * roughness;
         float nc_NdotV = dot3(N, Vv);
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
             const ArtLight &l = a.lights[i];
             V3 nn_L = get_unnormalized_L_vec(l, world_pos);
             V3 L = nrm3(nn_L);
-            V3 Hh = fast_nrm3(Vv + L);
+            V3 Hh = nrm3(Vv + L);
             float nc_NdotL = dot3(N, L);
             float NdotL = clampf(nc_NdotL, 0.0f, 1.0f);
             float NdotH = clampf(dot3(N, Hh), 0.0f, 1.0f);

@@ -85,6 +85,36 @@ def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights):
     assert ref["stats"]["shadow_rays"] > 10000
 
 
+def test_config2_full_size_frame_matches_oracle(R, orc, get_scene):
+    """BASELINE config 2 at its real size: 262 816 triangles, 1920x1080, one directional light"""
+    import json, os
+    ref = _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1)
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_sponza_like_1080p_1light.stats.json")))
+    for k in ("primary_rays", "shadow_rays", "hit_pixels", "n_int_primary", "n_tri_primary", "n_int_shadow", "n_tri_shadow"):
+        assert ref["stats"][k] == fx[k], k       # the committed visit counters bench.py prices the roofline with
+
+
+def test_config4_bistro_class_scene(R, orc, get_scene):
+    """BASELINE config 4's scene (2.8 M triangles, 120 primitives, 63-bit Morton keys on the device, 30-bit in the oracle):
+    device LBVH invariants at full size, then frame parity at 960x540"""
+    sc = get_scene("bistro_like", 1.0)
+    assert abs(sc.n_tris - 2.8e6) / 2.8e6 < 0.01 and len(sc.primitives) == 120
+    r = R.renderer_for_scene(sc, (64, 64))
+    b = r.get_lbvh()
+    T = sc.n_tris
+    assert np.array_equal(np.sort(b["leaf_gid"]), np.arange(T, dtype=np.uint32))
+    k = b["keys"].astype(np.uint64)
+    assert np.all(k[1:] >= k[:-1]) and np.all((k[1:] > k[:-1]) | (b["leaf_gid"][1:] > b["leaf_gid"][:-1]))
+    child = b["child"]
+    lo = np.concatenate([b["node_lo"], b["leaf_lo"]]); hi = np.concatenate([b["node_hi"], b["leaf_hi"]])
+    idx = np.where(child < 0, (T - 1) + (~child), child)
+    assert np.array_equal(lo[:T - 1], np.minimum(lo[idx[:, 0]], lo[idx[:, 1]])) and np.array_equal(hi[:T - 1], np.maximum(hi[idx[:, 0]], hi[idx[:, 1]]))
+    seen = np.bincount(idx.reshape(-1), minlength=2 * T - 1)
+    assert seen[0] == 0 and np.all(seen[1:] == 1)                # every node and leaf has exactly one parent
+    r.close()
+    _frame_parity(R, orc, sc, 960, 540, None)
+
+
 def test_ragged_extent_and_resize(R, orc, get_scene):
     """extent not a multiple of the 32-pixel tile; then a resize (vk_rt_lightning_shadows.rs:125)"""
     sc = get_scene("cornell")
