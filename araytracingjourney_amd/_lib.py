@@ -42,10 +42,10 @@ class ArtStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("hit_pixels", C.c_uint64), ("ao_rays", C.c_uint64),
                 ("num_triangles", C.c_uint32), ("num_primitives", C.c_uint32), ("num_nodes", C.c_uint32), ("reserved", C.c_uint32),
                 ("build_ms", C.c_float), ("frame_ms", C.c_float), ("trace_primary_ms", C.c_float), ("shade_ms", C.c_float),
-                ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float)]
+                ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float), ("ao_ms", C.c_float), ("reserved2", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
 
 
 assert C.sizeof(ArtVertex) == 48 and C.sizeof(ArtLight) == 80 and C.sizeof(ArtCamera) == 268
@@ -71,6 +71,8 @@ SYMBOLS = {
     "art_resize": (_I32, [_P, _U32, _U32]),
     "art_trace": (_I32, [_P]),
     "art_sync": (_I32, [_P]),
+    "art_trace_ao": (_I32, [_P, _U32, _F]),
+    "art_read_ao": (_I32, [_P, _P, _SZ]),
     "art_read_color": (_I32, [_P, _P, _SZ]),
     "art_read_depth": (_I32, [_P, _P, _SZ]),
     "art_read_normal": (_I32, [_P, _P, _SZ]),

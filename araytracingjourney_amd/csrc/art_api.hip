@@ -46,12 +46,13 @@ struct FrameSlot {
     DevBuf<uint32_t> d_counters, d_shadow_bits;
     DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
     DevBuf<float> d_depth;
+    DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
     hipEvent_t done = nullptr;       // recorded after the slot's last frame
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
-        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release();
+        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release();
     }
 };
 constexpr uint32_t kMaxFrames = 4;
@@ -80,6 +81,7 @@ struct ArtContext {
     hipEvent_t ev[kRing][5] = {};
     uint64_t frame_no = 0, collected_upto = 0;
     bool traced = false;
+    uint32_t ao_spp = 0;
     ArtStats stats{};
     hipStream_t stream_of(uint32_t k) const { return (ext_stream && F == 1) ? ext_stream : slot[k].own; }
     hipStream_t main_stream() const { return stream_of(0); }
@@ -220,6 +222,8 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     for (uint32_t k = 0; k < c->F && e == hipSuccess; k++) {
         e = hipStreamCreateWithFlags(&c->slot[k].own, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&c->slot[k].ao_ev[0]);
+        if (e == hipSuccess) e = hipEventCreate(&c->slot[k].ao_ev[1]);
     }
     for (int f = 0; f < ArtContext::kRing && e == hipSuccess; f++)
         for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[f][i]);
@@ -241,6 +245,7 @@ int32_t art_destroy(ArtContext *c) {
     for (uint32_t k = 0; k < kMaxFrames; k++) {
         c->slot[k].release();
         if (c->slot[k].done) (void)hipEventDestroy(c->slot[k].done);
+        for (int i = 0; i < 2; i++) if (c->slot[k].ao_ev[i]) (void)hipEventDestroy(c->slot[k].ao_ev[i]);
         if (c->slot[k].own) (void)hipStreamDestroy(c->slot[k].own);
     }
     for (int f = 0; f < ArtContext::kRing; f++)
@@ -420,6 +425,20 @@ int32_t art_resize(ArtContext *c, uint32_t w, uint32_t h) {
     return ART_OK;
 }
 
+static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
+    FrameArgs a{};
+    static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
+    std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
+    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local;
+    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
+    a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
+    a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
+    a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
+    a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr;
+    a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
+    return a;
+}
+
 int32_t art_trace(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "art_trace: null context");
     if (!c->built) return fail(ART_E_STATE, "art_trace: scene not built (art_scene_build)");
@@ -431,16 +450,7 @@ int32_t art_trace(ArtContext *c) {
     FrameSlot &S = c->slot[k];
     hipStream_t s = c->stream_of(k);
     if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
-    FrameArgs a{};
-    static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
-    std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
-    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local;
-    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
-    a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
-    a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
-    a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
-    a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr;
-    a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
+    FrameArgs a = make_frame_args(c, S);
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s));
     HIPC(hipEventRecord(ev[0], s));
@@ -466,6 +476,31 @@ int32_t art_sync(ArtContext *c) {
     return sync_all(c);
 }
 
+int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
+    if (!c) return fail(ART_E_INVALID, "art_trace_ao: null context");
+    if (!c->traced || !c->frame_ready) return fail(ART_E_STATE, "art_trace_ao: call art_trace first (AO consumes that frame's depth + normal outputs)");
+    if (spp == 0 || spp > 64 || !(radius > 0.0f)) return fail(ART_E_INVALID, "art_trace_ao: spp must be 1..64 and radius > 0");
+    int32_t r = use_device(c); if (r) return r;
+    FrameSlot &S = c->slot[c->last];
+    hipStream_t s = c->stream_of(c->last);
+    if (S.d_occl.n < (size_t)c->n_local * spp || S.d_ao.n < (size_t)c->W * c->H) {
+        HIPC(hipStreamSynchronize(s));
+        HIPC(S.d_occl.ensure((size_t)c->n_local * spp)); HIPC(S.d_ao.ensure((size_t)c->W * c->H));
+        HIPC(hipMemset(S.d_ao.p, 0, (size_t)c->W * c->H * 4)); HIPC(hipDeviceSynchronize());
+    }
+    uint32_t lut[65] = {0};
+    for (uint32_t k = 0; k <= spp; k++) lut[k] = (uint32_t)(std::pow(1.0 - (double)k / (double)spp, 2.2) * 255.0 + 0.5); // XE_GTAO_DEFAULT_FINAL_VALUE_POWER (vk_xe_gtao.rs:22)
+    FrameArgs a = make_frame_args(c, S);
+    HIPC(hipMemsetAsync(S.d_counters.p + 64 + 16 * 32, 0, 8 * 32 * 4, s)); // the AO launch's work cursors
+    HIPC(hipEventRecord(S.ao_ev[0], s));
+    if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, S.d_ao.p, lut, s);
+    HIPC(hipEventRecord(S.ao_ev[1], s));
+    HIPC(hipEventRecord(S.done, s));
+    HIPC(hipGetLastError());
+    c->stats.ao_rays = 0; c->ao_spp = spp;
+    return ART_OK;
+}
+
 static int32_t read_back(ArtContext *c, const void *src, size_t have, void *dst, size_t bytes, const char *who) {
     if (!c || !dst) return fail(ART_E_INVALID, std::string(who) + ": null argument");
     if (!c->traced) return fail(ART_E_STATE, std::string(who) + ": nothing traced yet");
@@ -485,6 +520,10 @@ static int32_t dev_ptr(ArtContext *c, void *p, size_t n, void **out, size_t *byt
     (void)p;
     *out = nullptr; if (bytes) *bytes = n;
     return ART_OK;
+}
+int32_t art_read_ao(ArtContext *c, void *dst, size_t bytes) {
+    if (c && c->ao_spp == 0) return fail(ART_E_STATE, "art_read_ao: art_trace_ao has not run");
+    return read_back(c, c ? c->slot[c->last].d_ao.p : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_ao");
 }
 int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color"); if (r) return r; *p = c->slot[c->last].d_color.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
@@ -600,6 +639,8 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
             owned += (uint64_t)w * h;
         }
         c->stats.primary_rays = owned; c->stats.shadow_rays = cnt[0]; c->stats.hit_pixels = cnt[1];
+        c->stats.ao_rays = (uint64_t)c->ao_spp * cnt[1];
+        if (c->ao_spp) { float ams = 0; if (hipEventElapsedTime(&ams, c->slot[c->last].ao_ev[0], c->slot[c->last].ao_ev[1]) == hipSuccess) c->stats.ao_ms = ams; }
         float ms = 0;
         if (c->frame_no) {
             hipEvent_t *ev = c->ev[(c->frame_no - 1) % ArtContext::kRing];

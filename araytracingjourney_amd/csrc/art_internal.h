@@ -97,6 +97,8 @@ void launch_primary(const FrameArgs &a, hipStream_t s);
 void launch_shade(const FrameArgs &a, hipStream_t s);
 void launch_shadow(const FrameArgs &a, hipStream_t s);
 void launch_accumulate(const FrameArgs &a, hipStream_t s);
+// ambient occlusion on the frame's depth/normal outputs; occl: n_local*spp bytes; lut: spp+1 output values; cursors at counters[64+512..] are reused (queries never overlap a frame)
+void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, uint32_t *ao, const uint32_t *lut, hipStream_t s);
 struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; int kind; }; // kind: 2 | 4 | 1
 void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);

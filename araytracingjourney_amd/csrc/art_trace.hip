@@ -238,8 +238,56 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
     }
 };
 
+// ---- ray-traced ambient occlusion (BASELINE config 5): XeGTAO's I/O contract on the tracer ------------------------
+// inputs: the frame's depth + view-space normal outputs (vk_xe_gtao.rs:295-333); noise: Hilbert index driving the R2
+// sequence (main_pass.comp.hlsl:48-65, XeGTAO.h:120-142) with index + 288 * sample; cosine-weighted hemisphere.
+__device__ __forceinline__ uint32_t hilbert_index(uint32_t x, uint32_t y) {
+    uint32_t index = 0;
+#pragma unroll
+    for (uint32_t lvl = 32; lvl > 0; lvl /= 2) {
+        uint32_t rx = (x & lvl) > 0, ry = (y & lvl) > 0;
+        index += lvl * lvl * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = 63u - x; y = 63u - y; }
+            uint32_t t = x; x = y; y = t;
+        }
+    }
+    return index;
+}
+// cos/sin of u turns by quadrant reduction + Taylor polynomials in a fixed fmaf order (bit-reproducible, unlike sinf/cosf)
+__device__ __forceinline__ void sincos_turns(float u, float &c, float &s) {
+    float q = u * 4.0f;
+    int k = (int)q;
+    float x = (q - (float)k) * 1.57079632679489662f, x2 = x * x;
+    float sp = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, -2.50521083854417188e-8f, 2.75573192239858907e-6f), -1.98412698412698413e-4f), 8.33333333333333333e-3f), -1.66666666666666667e-1f), 1.0f) * x;
+    float cp = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.08767569878680990e-9f, -2.75573192239858907e-7f), 2.48015873015873016e-5f), -1.38888888888888889e-3f), 4.16666666666666667e-2f), -0.5f), 1.0f);
+    k &= 3;
+    c = k == 0 ? cp : (k == 1 ? -sp : (k == 2 ? -cp : sp));
+    s = k == 0 ? sp : (k == 1 ? cp : (k == 2 ? -sp : -cp));
+}
+__device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float depth, float4 nm, uint32_t smp, V3 &o, V3 &d) {
+    float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    float dx = (px / (float)W) * 2.0f - 1.0f, dy = (py / (float)H) * 2.0f - 1.0f;
+    V3 org = mat4_mul(cam.view_inv, 0.f, 0.f, 0.f, 1.f);
+    V3 tn = nrm3(mat4_mul(cam.proj_inv, dx, dy, 1.f, 1.f));
+    V3 dir = mat4_mul(cam.view_inv, tn.x, tn.y, tn.z, 0.f);
+    float sc = depth / -tn.z;
+    o = mk(org.x + dir.x * sc, org.y + dir.y * sc, org.z + dir.z * sc); // the primary ray scaled to the stored view depth
+    float nx = nm.x * 2.0f - 1.0f, ny = -(nm.y * 2.0f - 1.0f), nz = -(nm.z * 2.0f - 1.0f); // raytrace.rgen.glsl:192-194 inverted
+    const float *VI = cam.view_inv;
+    V3 N = nrm3(mk((VI[0] * nx + VI[4] * ny) + VI[8] * nz, (VI[1] * nx + VI[5] * ny) + VI[9] * nz, (VI[2] * nx + VI[6] * ny) + VI[10] * nz));
+    float sg = copysignf(1.0f, N.z), aa = -1.0f / (sg + N.z), bb = N.x * N.y * aa; // branchless orthonormal basis (Duff et al. 2017)
+    V3 T = mk(1.0f + sg * N.x * N.x * aa, sg * bb, -sg * N.x), B = mk(bb, sg + N.y * N.y * aa, -N.y);
+    float fi = (float)(hilbert_index(x & 63u, y & 63u) + 288u * smp);
+    float v1 = 0.5f + fi * 0.75487766624669276f, v2 = 0.5f + fi * 0.56984029099805327f;
+    float u1 = v1 - floorf(v1), u2 = v2 - floorf(v2);
+    float r = sqrtf(u1), cz = sqrtf(1.0f - u1), cc, ss;
+    sincos_turns(u2, cc, ss);
+    d = (T * (r * cc) + B * (r * ss)) + N * cz;
+}
+
 // what a persistent tracing wave reads its rays from and writes its results to
-enum { MODE_PRIMARY = 0, MODE_SHADOW = 1, MODE_QUERY_CLOSEST = 2, MODE_QUERY_ANY = 3 };
+enum { MODE_PRIMARY = 0, MODE_SHADOW = 1, MODE_QUERY_CLOSEST = 2, MODE_QUERY_ANY = 3, MODE_AO = 4 };
 struct TraceArgs {
     const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris;
     uint32_t total;          // candidate slots
@@ -254,6 +302,8 @@ struct TraceArgs {
     const float4 *rays;
     float4 *contrib; uint32_t n_local; uint32_t *shadow_bits;
     uint32_t *any_out;
+    // MODE_AO: rays are generated from the frame's depth + view-space normal outputs (XeGTAO's inputs); slot = local pixel * spp + sample
+    const float *depth; const float4 *normal; uint32_t spp; float ao_radius; uint8_t *occl;
 };
 
 // Persistent-threads wavefront tracer.  Each wave keeps up to 64 rays in flight; when kRefill or more lanes have
@@ -262,7 +312,7 @@ struct TraceArgs {
 // Every wave exits once all cursors are exhausted and its lanes are idle.
 template <int MODE, int WIDTH>
 __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
-    constexpr bool ANY = MODE == MODE_SHADOW || MODE == MODE_QUERY_ANY;
+    constexpr bool ANY = MODE == MODE_SHADOW || MODE == MODE_QUERY_ANY || MODE == MODE_AO;
     __shared__ int stack[kLdsStack * kBlock];
     int ovf[WIDTH == 4 ? kOvfStack4 : kOvfStack];
     const uint32_t leaf_batch = a.leaf_batch;
@@ -313,6 +363,16 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
                             tr.start(org, dir, 0.001f, 10000.0f);
                             active = true;
                         } else a.hits[sidx] = make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+                    } else if (MODE == MODE_AO) {
+                        uint32_t p = sidx / a.spp, smp = sidx - p * a.spp, x, y;
+                        bool on = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
+                        float depth = on ? a.depth[(size_t)y * a.W + x] : 10000.0f;
+                        if (depth < 10000.0f) {
+                            V3 o, d;
+                            ao_ray(a.cam, a.W, a.H, x, y, depth, a.normal[(size_t)y * a.W + x], smp, o, d);
+                            tr.start(o, d, a.ao_radius * 0.01f, a.ao_radius);
+                            active = true;
+                        } else a.occl[sidx] = 0;
                     } else {
                         float4 r0 = a.rays[2 * (size_t)sidx];
                         if (MODE != MODE_SHADOW || r0.w > 0.0f) {
@@ -351,6 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
                 a.hits[slot] = tr.bpos != kNoHit ? make_float4(tr.tbest, tr.bu, tr.bv, __uint_as_float(tr.bpos))
                                                  : make_float4(MODE == MODE_PRIMARY ? 10000.0f : tr.r.tmax, 0.f, 0.f, __uint_as_float(kNoHit));
             else if (MODE == MODE_QUERY_ANY) a.any_out[slot] = tr.bpos != kNoHit ? 1u : 0u;
+            else if (MODE == MODE_AO) a.occl[slot] = tr.bpos != kNoHit ? 1 : 0;
             else if (tr.bpos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
                 float4 c = a.contrib[slot];
                 a.contrib[slot] = make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w);
@@ -635,6 +696,26 @@ void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t
     TraceArgs a{};
     a.nodes = b.nodes; a.wide = b.wide; a.qnodes = b.qnodes; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
     launch_trace<MODE_QUERY_ANY>(a, b.kind, false, s);
+}
+// AO resolve: occluded count -> uint(pow(visibility, 2.2) * 255 + 0.5) through a host-built table; 255 where nothing was hit
+struct AoLut { uint32_t v[65]; };
+__global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_t *__restrict__ occl, uint32_t spp, AoLut lut, uint32_t *__restrict__ ao) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.n_local) return;
+    uint32_t x, y;
+    if (!local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y)) return;
+    size_t pix = (size_t)y * a.W + x;
+    uint32_t k = 0;
+    for (uint32_t s = 0; s < spp; s++) k += occl[(size_t)p * spp + s];
+    ao[pix] = a.depth[pix] < 10000.0f ? lut.v[k] : 255u;
+}
+void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
+    TraceArgs a{};
+    a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
+    a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
+    launch_trace<MODE_AO>(a, f.trace_kind[1], f.pipelined, s);
+    AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
+    k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
     dim3 g((W + 31) / 32, (H + 7) / 8);

@@ -240,6 +240,16 @@ class Renderer:
         """record + submit of lightning_layer.trace_rays (renderer.rs:679-686); asynchronous."""
         check(self._L.art_trace(self._ctx))
 
+    def trace_ao(self, spp=16, radius=0.2 * 1.457):
+        """ao_layer.compute_ao (renderer.rs:688) replaced by ray-traced AO with XeGTAO's I/O contract"""
+        check(self._L.art_trace_ao(self._ctx, spp, radius))
+
+    def read_ao(self):
+        w, h = self.extent
+        a = np.empty((h, w), np.uint32)
+        check(self._L.art_read_ao(self._ctx, _ptr(a), a.nbytes))
+        return a
+
     def render_frame(self, sync=True):  # renderer.rs:371
         self.upload_state()
         self.trace()

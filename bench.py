@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--lights", type=int, default=1, choices=[1, 4])
     ap.add_argument("--detail", type=float, default=1.0, help="scene detail (1.0 = the 262k-triangle config)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="ring of per-frame streams/buffers, like the reference's 3-deep FrameData ring (renderer.rs:135)")
+    ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
@@ -90,11 +91,15 @@ def main():
     def step():
         if world == 1:
             r.trace()                 # primary + shade + shadow + accumulate on the next ring slot's stream
+            if args.ao:
+                r.trace_ao(args.ao)
             return
         _, k = r.frames_in_flight()
         if consumed[k] is not None:
             r.wait_external_event(consumed[k].cuda_event)   # do not overwrite tiles a gather is still reading
         r.trace()
+        if args.ao:
+            r.trace_ao(args.ao)                             # per tile from the local G-buffer: no extra exchange
         r.stream_wait_frame(stream.cuda_stream)             # torch's stream (hence RCCL) waits for this frame only
         if args.backend == "nccl":
             dist.gather(tiles[k], list(gathered[k].unbind(0)) if rank == 0 else None, dst=0)
@@ -135,7 +140,7 @@ def main():
     iso, _ = r.collect_timings()
 
     st = r.stats()
-    rays_local = st["primary_rays"] + st["shadow_rays"]
+    rays_local = st["primary_rays"] + st["shadow_rays"] + st["ao_rays"]
     # outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit
     frame_ok = None
     if world > 1 and rank == 0:
@@ -167,12 +172,12 @@ def main():
 
     # ---- algorithmic bytes: the oracle's canonical-LBVH visit counters for this exact frame
     tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights))
-    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and args.detail == 1.0 else None
+    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and args.detail == 1.0 and not args.ao else None
     ost = json.load(open(fx)) if fx and os.path.exists(fx) else None
 
     # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and not args.ao:
         from oracle import orc
         ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
         try:  # a cgroup CPU quota (e.g. 16 CPUs of a 256-thread host) is the real core budget
@@ -226,7 +231,7 @@ def main():
         "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"sponza_like(seed=0x5A0A, {sc.n_tris} triangles, 25 primitives) {W}x{H}, {args.lights} light(s), "
-                               f"{int(shadow_total)} shadow rays/frame", "width": W, "height": H, "lights": args.lights,
+                               f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
                    "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather to rank 0") + f", {F} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F,
         "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "build_ms": st["build_ms"],

@@ -89,6 +89,8 @@ typedef struct ArtStats {
     float build_ms;             /* last art_scene_build, device time */
     float frame_ms;             /* last art_trace, device time (events on the context's stream) */
     float trace_primary_ms, shade_ms, trace_shadow_ms, accumulate_ms;
+    float ao_ms;                /* last art_trace_ao (ray generation + any-hit + resolve) */
+    uint32_t reserved2;
 } ArtStats;
 
 typedef struct ArtContext ArtContext;
@@ -142,6 +144,13 @@ int32_t art_resize(ArtContext *ctx, uint32_t width, uint32_t height);
 /* VkRTLightningShadows::trace_rays (vk_rt_lightning_shadows.rs:185-278): raygen + closest hit + light loop +
  * shadow rays + G-buffer stores of raytrace.rgen.glsl:77-200, asynchronous on the context's stream */
 int32_t art_trace(ArtContext *ctx);
+/* ray-traced ambient occlusion replacing VkXeGtao::compute_ao (vk_xe_gtao.rs:416-642) with the same I/O contract:
+ * inputs = the depth + view-space normal outputs of the frame just traced (vk_xe_gtao.rs:295-333), output = one value
+ * 0..255 per pixel in an R32_UINT-like buffer, as tonemap.comp.glsl:33-34 consumes it.  spp (1..64) cosine-weighted
+ * any-hit rays of length `radius` per hit pixel (reference radius: 0.2 * 1.457, vk_xe_gtao.rs:17-18,:261), Hilbert-R2
+ * noise (main_pass.comp.hlsl:48-65), final power 2.2 (vk_xe_gtao.rs:22).  Enqueued behind art_trace on its stream. */
+int32_t art_trace_ao(ArtContext *ctx, uint32_t spp, float radius);
+int32_t art_read_ao(ArtContext *ctx, void *dst, size_t bytes); /* width*height uint32 */
 /* the fence (renderer.rs:451-466) */
 int32_t art_sync(ArtContext *ctx);
 

@@ -852,3 +852,107 @@ void orc_render(const OrcScene *s, const OrcCamera *cam, const OrcLight *lights,
     }
     if (stats) *stats = J.stats;
 }
+
+/* ------------------------------------------------------------------ ray-traced AO (BASELINE config 5) */
+static inline uint32_t hilbert_index(uint32_t x, uint32_t y) { /* XeGTAO.h:120-142, XE_HILBERT_LEVEL 6 */
+    uint32_t index = 0;
+    for (uint32_t lvl = 32; lvl > 0; lvl /= 2) {
+        uint32_t rx = (x & lvl) > 0, ry = (y & lvl) > 0;
+        index += lvl * lvl * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = 63u - x; y = 63u - y; }
+            uint32_t t = x; x = y; y = t;
+        }
+    }
+    return index;
+}
+/* cos/sin of u turns (u in [0,1)) by quadrant reduction + Taylor polynomials in a fixed fmaf order: the same bits on any IEEE machine */
+static inline void sincos_turns(float u, float *c, float *s) {
+    float q = u * 4.0f;
+    int k = (int)q;
+    float x = (q - (float)k) * 1.57079632679489662f, x2 = x * x;
+    float sp = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, -2.50521083854417188e-8f, 2.75573192239858907e-6f), -1.98412698412698413e-4f), 8.33333333333333333e-3f), -1.66666666666666667e-1f), 1.0f) * x;
+    float cp = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 2.08767569878680990e-9f, -2.75573192239858907e-7f), 2.48015873015873016e-5f), -1.38888888888888889e-3f), 4.16666666666666667e-2f), -0.5f), 1.0f);
+    switch (k & 3) {
+        case 0: *c = cp; *s = sp; break;
+        case 1: *c = -sp; *s = cp; break;
+        case 2: *c = -cp; *s = -sp; break;
+        default: *c = sp; *s = -cp; break;
+    }
+}
+
+typedef struct {
+    const OrcScene *s; const OrcCamera *cam; uint32_t w, h, spp; float radius; const float *depth, *normal; uint32_t *out; uint32_t lut[65];
+    volatile uint32_t *next_row; pthread_mutex_t *mu; uint64_t n_rays, n_int, n_tri;
+} AoJob;
+
+static void *ao_worker(void *arg) {
+    AoJob *J = (AoJob *)arg;
+    uint64_t nr = 0, ni = 0, nt = 0;
+    for (;;) {
+        uint32_t y = __sync_fetch_and_add(J->next_row, 1u);
+        if (y >= J->h) break;
+        for (uint32_t x = 0; x < J->w; x++) {
+            size_t pix = (size_t)y * J->w + x;
+            float depth = J->depth[pix];
+            if (!(depth < 10000.0f)) { J->out[pix] = 255u; continue; }
+            /* position from the depth output: the primary ray scaled to view depth */
+            float px = (float)x + 0.5f, py = (float)y + 0.5f;
+            float dx = (px / (float)J->w) * 2.0f - 1.0f, dy = (py / (float)J->h) * 2.0f - 1.0f;
+            float org[4], tg[4], dir[4];
+            mat4_mul4(J->cam->view_inv, 0.0f, 0.0f, 0.0f, 1.0f, org);
+            mat4_mul4(J->cam->proj_inv, dx, dy, 1.0f, 1.0f, tg);
+            v3 tn = nrm3(V3(tg[0], tg[1], tg[2]));
+            mat4_mul4(J->cam->view_inv, tn.x, tn.y, tn.z, 0.0f, dir);
+            float sc = depth / -tn.z;
+            v3 wp = V3(org[0] + dir[0] * sc, org[1] + dir[1] * sc, org[2] + dir[2] * sc);
+            /* world normal from the view-space normal output (raytrace.rgen.glsl:192-194 inverted) */
+            const float *nm = J->normal + pix * 4;
+            float nx = nm[0] * 2.0f - 1.0f, ny = -(nm[1] * 2.0f - 1.0f), nz = -(nm[2] * 2.0f - 1.0f);
+            const float *VI = J->cam->view_inv;
+            v3 N = nrm3(V3((VI[0] * nx + VI[4] * ny) + VI[8] * nz, (VI[1] * nx + VI[5] * ny) + VI[9] * nz, (VI[2] * nx + VI[6] * ny) + VI[10] * nz));
+            /* branchless orthonormal basis (Duff et al. 2017) */
+            float sg = copysignf(1.0f, N.z), a = -1.0f / (sg + N.z), b = N.x * N.y * a;
+            v3 T = V3(1.0f + sg * N.x * N.x * a, sg * b, -sg * N.x), B = V3(b, sg + N.y * N.y * a, -N.y);
+            uint32_t hidx = hilbert_index(x & 63u, y & 63u), occ = 0;
+            for (uint32_t sidx = 0; sidx < J->spp; sidx++) {
+                float fi = (float)(hidx + 288u * sidx);
+                float v1 = 0.5f + fi * 0.75487766624669276f, v2 = 0.5f + fi * 0.56984029099805327f;
+                float u1 = v1 - floorf(v1), u2 = v2 - floorf(v2);
+                float r = sqrtf(u1), cz = sqrtf(1.0f - u1), cc, ss;
+                sincos_turns(u2, &cc, &ss);
+                float lx = r * cc, ly = r * ss;
+                v3 d = add3(add3(scl3(T, lx), scl3(B, ly)), scl3(N, cz));
+                Ray ray; ray_init(&ray, wp, d, J->radius * 0.01f, J->radius);
+                nr++;
+                occ += (uint32_t)any_bvh(J->s, &ray, &ni, &nt);
+            }
+            J->out[pix] = J->lut[occ];
+        }
+    }
+    pthread_mutex_lock(J->mu);
+    J->n_rays += nr; J->n_int += ni; J->n_tri += nt;
+    pthread_mutex_unlock(J->mu);
+    return NULL;
+}
+
+void orc_render_ao(const OrcScene *s, const OrcCamera *cam, uint32_t w, uint32_t h, const float *depth, const float *normal, uint32_t spp,
+                   float radius, uint32_t *out_ao, uint64_t *n_rays, uint64_t *n_int, uint64_t *n_tri, int n_threads) {
+    AoJob J; memset(&J, 0, sizeof(J));
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    volatile uint32_t next = 0;
+    if (spp > 64) spp = 64;
+    J.s = s; J.cam = cam; J.w = w; J.h = h; J.spp = spp; J.radius = radius; J.depth = depth; J.normal = normal; J.out = out_ao; J.next_row = &next; J.mu = &mu;
+    for (uint32_t k = 0; k <= spp; k++) J.lut[k] = (uint32_t)(pow(1.0 - (double)k / (double)spp, 2.2) * 255.0 + 0.5); /* XE_GTAO_DEFAULT_FINAL_VALUE_POWER */
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    if (n_threads == 1) ao_worker(&J);
+    else {
+        pthread_t th[256];
+        for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, ao_worker, &J);
+        for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    }
+    if (n_rays) *n_rays = J.n_rays;
+    if (n_int) *n_int = J.n_int;
+    if (n_tri) *n_tri = J.n_tri;
+}

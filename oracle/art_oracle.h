@@ -88,6 +88,13 @@ void orc_render(const OrcScene *, const OrcCamera *, const OrcLight *, uint32_t 
                 uint32_t y0, uint32_t y1, float *color, float *depth, float *normal, float *hit_tuv, int32_t *hit_id,
                 uint32_t *shadow_bits, OrcStats *stats, int n_threads);
 
+/* ray-traced ambient occlusion with XeGTAO's I/O contract (vk_xe_gtao.rs:17-23, :261-272, :295-333; consumer
+ * tonemap.comp.glsl:33-34): inputs = the frame's depth + view-space normal outputs, output = 0..255 per pixel
+ * (uint(pow(visibility, 2.2) * 255 + 0.5), 255 where nothing was hit).  spp cosine-weighted rays of length `radius`
+ * per hit pixel, directions from the Hilbert-R2 noise of main_pass.comp.hlsl:48-65 with index + 288 * sample. */
+void orc_render_ao(const OrcScene *, const OrcCamera *, uint32_t w, uint32_t h, const float *depth, const float *normal,
+                   uint32_t spp, float radius, uint32_t *out_ao, uint64_t *n_rays, uint64_t *n_int, uint64_t *n_tri, int n_threads);
+
 /* single-point shading for known-answer tests: shades a given hit without tracing the primary ray */
 void orc_brdf_terms(float NdotL, float NdotV, float NdotH, float LdotH, float nc_NdotV, float nc_NdotL, float alpha,
                     float out[4]); /* D, V_fast, pow5 Schlick weight, Burley_local_sss */

@@ -66,6 +66,7 @@ def lib():
         L.orc_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_render_ao.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_brdf_terms.argtypes = [C.c_float] * 7 + [C.c_void_p]
         L.orc_light_eval.argtypes = [C.c_void_p] * 4
         _LIB = L
@@ -193,6 +194,16 @@ class Scene:
         if debug:
             out.update(hit_tuv=tuv, hit_id=ids, shadow_bits=sb)
         return out
+
+
+def render_ao(scene: "Scene", cam: OrcCamera, depth, normal, spp, radius, threads=1):
+    h, w = depth.shape
+    depth = np.ascontiguousarray(depth, np.float32)
+    normal = np.ascontiguousarray(normal, np.float32)
+    out = np.zeros((h, w), np.uint32)
+    nr, ni, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    lib().orc_render_ao(scene.h, C.byref(cam), w, h, _ptr(depth), _ptr(normal), spp, radius, _ptr(out), C.byref(nr), C.byref(ni), C.byref(nt), threads)
+    return out, dict(ao_rays=int(nr.value), n_int_ao=int(ni.value), n_tri_ao=int(nt.value))
 
 
 def gen_primary(cam: OrcCamera, w, h):

@@ -152,6 +152,28 @@ def test_sharded_tiles_gather_to_the_unsharded_frame(R, get_scene):
         s.close()
 
 
+@pytest.mark.parametrize("name,detail,size,spp", [("cornell", 1.0, (256, 256), 16), ("sponza_like", 0.12, (480, 270), 16), ("sponza_like", 0.12, (200, 120), 5)])
+def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp):
+    """BASELINE config 5's pass: AO rays from the frame's depth + normal outputs; the 0..255 output is an integer: bit-exact"""
+    sc = get_scene(name, detail)
+    w, h = size
+    radius = 0.2 * 1.457
+    r = R.renderer_for_scene(sc, (w, h))
+    r.render_frame(sync=False)
+    r.trace_ao(spp, radius)
+    got = r.read_ao()
+    S, L, nl = oracle_for(orc, sc)
+    cam = oracle_camera(orc, sc, w, h)
+    ref = S.render(cam, L, nl, w, h, threads=8)
+    assert np.array_equal(r.read_depth().view(np.uint32), ref["depth"].view(np.uint32))        # the AO inputs themselves are bit-equal
+    assert np.array_equal(r.read_normal().view(np.uint32), ref["normal"].view(np.uint32))
+    want, st = orc.render_ao(S, cam, ref["depth"], ref["normal"], spp, radius, threads=8)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} AO values differ"
+    assert r.stats()["ao_rays"] == st["ao_rays"] == ref["stats"]["hit_pixels"] * spp
+    assert got.min() < 128 and got.max() == 255
+    r.close()
+
+
 def test_frame_ring_gives_the_same_frames(R, get_scene):
     """3 frames in flight (the reference's FrameData ring, renderer.rs:135): every frame equals the single-slot render"""
     sc = get_scene("cornell")
