@@ -48,6 +48,12 @@ class ArtStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
 
 
+class ArtGlbCopyInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("mesh_buffer_offset", "mesh_size", "indices_buffer_offset", "indices_size", "image_buffer_offset", "image_size")] + \
+               [(n, C.c_uint32) for n in ("single_mesh_element_size", "single_index_size", "image_format", "image_width", "image_height", "image_mip_levels",
+                                          "image_layers", "reserved")]
+
+
 assert C.sizeof(ArtVertex) == 48 and C.sizeof(ArtLight) == 80 and C.sizeof(ArtCamera) == 268
 
 # every symbol include/art.h declares: (name, restype, argtypes)
@@ -95,6 +101,14 @@ SYMBOLS = {
     "art_query_closest": (_I32, [_P, _P, _U32, _P, _P]),
     "art_query_any": (_I32, [_P, _P, _U32, _P]),
     "art_get_lbvh": (_I32, [_P] + [_P] * 7),
+    "art_glb_last_error": (C.c_char_p, []),
+    "art_glb_open": (_I32, [C.c_char_p, _I32, _I32, _P]),
+    "art_glb_close": (_I32, [_P]),
+    "art_glb_primitive_count": (_I32, [_P, _P]),
+    "art_glb_copy_model_data": (_I32, [_P, _U32, _U32, _P, _SZ, _P, _U32, _P]),
+    "art_glb_bounding_sphere": (_I32, [_P, _P, _P]),
+    "art_glb_permute_pixels": (_I32, [_P, _SZ, _U32, _P, _U32, _U32, _P, _SZ]),
+    "art_scene_add_glb": (_I32, [_P, _P, _P, _P, _P]),
 }
 
 _lib = None

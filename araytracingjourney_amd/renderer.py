@@ -210,6 +210,17 @@ class Renderer:
         self._models.append(ids)
         return ids
 
+    def add_model_glb(self, reader, model_matrix):
+        """renderer.rs:346 with a GltfModelReader (opened with normalize + B8G8R8A8 coercion like vk_model.rs:498-504)"""
+        first, n = C.c_uint32(), C.c_uint32()
+        m = np.ascontiguousarray(model_matrix, dtype=np.float32)
+        r = self._L.art_scene_add_glb(self._ctx, reader._h, _ptr(m), C.byref(first), C.byref(n))
+        if r != 0:
+            raise _lib.ArtError(r, self._L.art_glb_last_error().decode("utf-8", "replace"))
+        ids = list(range(first.value, first.value + n.value))
+        self._models.append(ids)
+        return ids
+
     def models_mut(self):
         return self._models
 

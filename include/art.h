@@ -199,6 +199,42 @@ int32_t art_query_any(ArtContext *ctx, const float *rays, uint32_t n, uint8_t *h
 int32_t art_get_lbvh(ArtContext *ctx, uint32_t *leaf_gid, uint64_t *keys, int32_t *child, float *node_lo,
                      float *node_hi, float *leaf_lo, float *leaf_hi);
 
+/* ---- GLB ingest: the step right before the path (model_reader/gltf_model_reader.rs), host only ------------------ */
+typedef struct ArtGlb ArtGlb;
+/* MeshAttributeType / TextureType bits (model_reader.rs:5-20) */
+#define ART_ATTR_VERTICES 1u
+#define ART_ATTR_TEX_COORDS 2u
+#define ART_ATTR_NORMALS 4u
+#define ART_ATTR_TANGENTS 8u
+#define ART_ATTR_INDICES 16u
+#define ART_TEX_ALBEDO 1u
+#define ART_TEX_ORM 2u
+#define ART_TEX_NORMAL 4u
+#define ART_TEX_EMISSIVE 8u
+/* PrimitiveCopyInfo (model_reader.rs:52-72); image_format: 0 R8, 1 R8G8, 2 R8G8B8, 3 R8G8B8A8, 4 B8G8R8, 5 B8G8R8A8, 6..9 the R16 family */
+typedef struct ArtGlbCopyInfo {
+    uint64_t mesh_buffer_offset, mesh_size;
+    uint64_t indices_buffer_offset, indices_size;
+    uint64_t image_buffer_offset, image_size;
+    uint32_t single_mesh_element_size, single_index_size;
+    uint32_t image_format, image_width, image_height, image_mip_levels, image_layers, reserved;
+} ArtGlbCopyInfo;
+const char *art_glb_last_error(void);
+/* GltfModelReader::open (gltf_model_reader.rs:55-150): coerce_format 0 none, 1 R8G8B8A8, 2 B8G8R8A8 (what VkModel asks for), 3 B8G8R8 */
+int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce_format, ArtGlb **out);
+int32_t art_glb_close(ArtGlb *glb);
+int32_t art_glb_primitive_count(ArtGlb *glb, uint32_t *n);
+/* copy_model_data_to_ptr (:156-281): dst NULL = sizing pass; *total = bytes the copy needs */
+int32_t art_glb_copy_model_data(ArtGlb *glb, uint32_t attr_mask, uint32_t tex_mask, void *dst, size_t cap, ArtGlbCopyInfo *infos,
+                                uint32_t n_infos, size_t *total);
+/* get_primitives_bounding_sphere (:283-399) */
+int32_t art_glb_bounding_sphere(ArtGlb *glb, float center[3], float *radius);
+/* permute_pixels (:542-573): map[s] = destination byte of source byte s, or -1 */
+int32_t art_glb_permute_pixels(const uint8_t *src, size_t src_len, uint32_t src_texel, const int32_t *map, uint32_t map_len,
+                               uint32_t dst_texel, uint8_t *dst, size_t dst_cap);
+/* add_model (renderer.rs:346 -> vk_model.rs:494-528): every primitive of the GLB into the scene */
+int32_t art_scene_add_glb(ArtContext *ctx, ArtGlb *glb, const float model3x4[12], uint32_t *first_primitive_id, uint32_t *n_primitives);
+
 #ifdef __cplusplus
 }
 #endif

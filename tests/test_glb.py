@@ -1,0 +1,161 @@
+"""GLB ingest: the reference-authored known answers of model_reader/gltf_model_reader.rs:684-856 and
+model_reader.rs:148-175, restated against libart's reader through the C ABI -- the one part of the pipeline for which the
+reference holds real test vectors.  Host only: no GPU needed.  The two .glb fixtures are the reference's own
+assets (assets/models/BoxTextured*.glb, data files its tests use), copied to tests/golden/."""
+import io
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from araytracingjourney_amd import model_reader as mr
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BOX = os.path.join(GOLD, "BoxTextured.glb")
+BOX_T = os.path.join(GOLD, "BoxTexturedWithTangents.glb")
+
+
+# --- gltf_model_reader.rs:690-732
+def test_wide_permute_pixel():
+    assert mr.permute_pixels([0, 1, 2, 3, 4, 5], 3, {0: 0, 1: 1, 2: 2}, 4).tolist() == [0, 1, 2, 0, 3, 4, 5, 0]
+
+
+def test_narrow_permute_pixel():
+    assert mr.permute_pixels([0, 1, 2, 3, 4, 5, 6, 7], 4, {0: 0, 1: 1, 2: 2}, 3).tolist() == [0, 1, 2, 4, 5, 6]
+
+
+def test_mix_and_narrow_permute_pixel():
+    assert mr.permute_pixels([0, 1, 2, 3, 4, 5, 6, 7], 4, {0: 2, 1: 0, 2: 1}, 3).tolist() == [1, 2, 0, 5, 6, 4]
+
+
+def test_mix_and_wide_permute_pixel():
+    assert mr.permute_pixels([0, 1, 2, 3, 4, 5], 3, {0: 2, 1: 0, 2: 1}, 4).tolist() == [1, 2, 0, 0, 4, 5, 3, 0]
+
+
+def test_mix_same_size_permute_pixel():
+    """:734-750 compares the scalar permute with its SSSE3/AVX2 twins; there is one implementation here, checked against numpy"""
+    src = np.arange(128, dtype=np.uint8)
+    got = mr.permute_pixels(src, 4, {0: 2, 1: 0, 2: 1, 3: 3}, 4)
+    want = src.reshape(-1, 4)[:, [1, 2, 0, 3]].reshape(-1)
+    assert np.array_equal(got, want)
+
+
+# --- gltf_model_reader.rs:784-855 test_textured_cube
+def test_textured_cube():
+    r = mr.GltfModelReader(BOX, True, mr.COERCE_B8G8R8A8)
+    centre, radius = r.get_primitives_bounding_sphere()
+    assert (radius - 1.0) < 1e-5 and np.all((centre - 1.0) < 1e-5)                 # the reference's (one-sided) assertions
+    assert abs(radius - math_sqrt(0.75)) < 1e-6 and np.allclose(centre, 0, atol=1e-6)  # what Ritter's sphere of a +-0.5 cube is
+    data, infos = r.copy_model_data_to_ptr(mr.VERTICES | mr.NORMALS | mr.TEX_COORDS | mr.INDICES, mr.ALBEDO)
+    ci = infos[0]
+    assert data.size == ci.mesh_size + ci.indices_size + ci.image_size                # compute_total_size (model_reader.rs:85-93)
+    first_vertex = data[ci.mesh_buffer_offset:ci.mesh_buffer_offset + 32].view(np.float32)
+    assert np.allclose(first_vertex, [-0.5, -0.5, 0.5, 6.0, 0.0, 0.0, 0.0, 1.0], atol=1e-7)   # pos, uv, normal: the bitflag order
+    assert data[ci.indices_buffer_offset:ci.indices_buffer_offset + 8].view(np.uint16).tolist() == [0, 1, 2, 3]
+    assert data[ci.image_buffer_offset:ci.image_buffer_offset + 4].tolist() == [220, 220, 220, 0]  # RGB -> BGRA widened, alpha 0
+    assert (ci.single_mesh_element_size, ci.single_index_size, ci.image_width, ci.image_height, ci.image_layers, ci.image_mip_levels) == (32, 2, 256, 256, 1, 1)
+    assert ci.image_format == 5 and ci.mesh_size == 24 * 32 and ci.indices_size == 72   # B8G8R8A8; 24 vertices, 36 indices
+
+
+def math_sqrt(x):
+    return float(np.sqrt(np.float64(x)))
+
+
+def test_interleave_order_is_the_bitflag_order():
+    """model_reader.rs:148-175: VERTICES, TEX_COORDS, NORMALS, TANGENTS, (INDICES) -- the 48-byte vertex of the ray tracer"""
+    r = mr.GltfModelReader(BOX_T, True, mr.COERCE_B8G8R8A8)
+    data, infos = r.copy_model_data_to_ptr(mr.VERTICES | mr.TEX_COORDS | mr.NORMALS | mr.TANGENTS | mr.INDICES, mr.ALBEDO)
+    ci = infos[0]
+    assert ci.single_mesh_element_size == 48 and ci.mesh_size == 24 * 48
+    v = data[ci.mesh_buffer_offset:ci.mesh_buffer_offset + ci.mesh_size].view(np.float32).reshape(24, 12)
+    doc, bin_ = _parse(BOX_T)
+    acc = {k: _accessor(doc, bin_, i) for k, i in doc["meshes"][0]["primitives"][0]["attributes"].items()}
+    assert np.array_equal(v[:, 0:3], acc["POSITION"]) and np.array_equal(v[:, 3:5], acc["TEXCOORD_0"])
+    assert np.array_equal(v[:, 5:8], acc["NORMAL"]) and np.array_equal(v[:, 8:12], acc["TANGENT"])
+    only_nrm_idx, _ = r.copy_model_data_to_ptr(mr.NORMALS | mr.INDICES, 0)
+    assert only_nrm_idx.size == 24 * 12 + 72
+
+
+def test_png_decode_matches_pillow():
+    """independent pin of the PNG path (palette image): Pillow's decode of the same embedded stream"""
+    from PIL import Image
+    doc, bin_ = _parse(BOX)
+    bv = doc["bufferViews"][doc["images"][0]["bufferView"]]
+    ref = np.asarray(Image.open(io.BytesIO(bin_[bv["byteOffset"]:bv["byteOffset"] + bv["byteLength"]])).convert("RGB"))
+    r = mr.GltfModelReader(BOX, False, mr.COERCE_NONE)
+    data, infos = r.copy_model_data_to_ptr(0, mr.ALBEDO)
+    assert infos[0].image_format == 2 and infos[0].image_size == 256 * 256 * 3          # R8G8B8: palettes expand to RGB
+    assert np.array_equal(data[infos[0].image_buffer_offset:].reshape(256, 256, 3), ref)
+    rgba = mr.GltfModelReader(BOX, False, mr.COERCE_R8G8B8A8).copy_model_data_to_ptr(0, mr.ALBEDO)[0].reshape(256, 256, 4)
+    assert np.array_equal(rgba[..., :3], ref) and (rgba[..., 3] == 0).all()
+    bgra = mr.GltfModelReader(BOX, False, mr.COERCE_B8G8R8A8).copy_model_data_to_ptr(0, mr.ALBEDO)[0].reshape(256, 256, 4)
+    assert np.array_equal(bgra[..., [2, 1, 0]], ref)
+
+
+def test_missing_attributes_and_textures_are_errors_like_the_reference_panics():
+    from araytracingjourney_amd._lib import ArtError
+    r = mr.GltfModelReader(BOX, True, mr.COERCE_B8G8R8A8)
+    with pytest.raises(ArtError, match="not found"):
+        r.copy_model_data_to_ptr(mr.VERTICES | mr.TANGENTS, 0)        # BoxTextured has no tangents
+    with pytest.raises(ArtError, match="not found"):
+        r.copy_model_data_to_ptr(mr.VERTICES, mr.ALBEDO | mr.ORM)      # nor an ORM texture (gltf_model_reader.rs:261-263)
+    with pytest.raises(ArtError, match="Could not read file"):
+        mr.GltfModelReader("/nonexistent.glb")
+
+
+def test_synthetic_glb_round_trip(tmp_path, get_scene):
+    """normalisation (:415-460), strided views, RGB/palette/RGBA PNGs, u16 + u32 indices, several primitives"""
+    from glb_writer import write_glb
+    from araytracingjourney_amd import scenes
+    sc = get_scene("sponza_like", 0.05)
+    prims = [sc.primitives[0], sc.primitives[6], sc.primitives[24]]
+    big = [scenes.Primitive((p.verts * np.array([3.0, 3.0, 3.0] + [1.0] * 9, np.float32)).astype(np.float32), p.indices, p.tex[:, ::8, ::8].copy(), p.model) for p in prims]
+    for interleaved in (False, True):
+        path = tmp_path / f"m{int(interleaved)}.glb"
+        write_glb(str(path), big, png_modes=("RGBA", "RGB", "RGBA"), interleaved=interleaved)
+        r = mr.GltfModelReader(str(path), True, mr.COERCE_B8G8R8A8)
+        assert r.primitive_count() == 3
+        data, infos = r.copy_model_data_to_ptr(mr.VERTICES | mr.TEX_COORDS | mr.NORMALS | mr.TANGENTS | mr.INDICES, mr.ALBEDO | mr.ORM | mr.NORMAL)
+        mx = max(np.sqrt((p.verts[:, :3].astype(np.float32) ** 2).sum(1, dtype=np.float32)).max() for p in big)
+        assert mx > 1
+        for p, ci in zip(big, infos):
+            v = data[ci.mesh_buffer_offset:ci.mesh_buffer_offset + ci.mesh_size].view(np.float32).reshape(-1, 12)
+            assert np.array_equal(v[:, 3:], p.verts[:, 3:])
+            assert np.array_equal(v[:, :3], p.verts[:, :3] / np.float32(mx))                      # every primitive by the global max magnitude
+            assert ci.single_index_size == p.indices.dtype.itemsize
+            assert np.array_equal(data[ci.indices_buffer_offset:ci.indices_buffer_offset + ci.indices_size].view(p.indices.dtype), p.indices)
+            tex = data[ci.image_buffer_offset:ci.image_buffer_offset + ci.image_size].reshape(3, p.tex.shape[1], p.tex.shape[2], 4)
+            assert ci.image_layers == 3 and ci.image_buffer_offset % 4 == 0
+            assert np.array_equal(tex[0][..., [2, 1, 0, 3]], p.tex[0]) and np.array_equal(tex[2][..., [2, 1, 0, 3]], p.tex[2])
+            assert np.array_equal(tex[1][..., [2, 1, 0]], p.tex[1][..., :3]) and (tex[1][..., 3] == 0).all()  # RGB source: alpha 0 after widening
+        c, rad = r.get_primitives_bounding_sphere()
+        allv = np.concatenate([p.verts[:, :3] / np.float32(mx) for p in big])
+        assert (np.linalg.norm(allv - c, axis=1) <= rad * (1 + 1e-5)).all() and rad <= 1.2
+    path = tmp_path / "two_meshes.glb"
+    write_glb(str(path), big[:1], n_meshes=2)
+    from araytracingjourney_amd._lib import ArtError
+    with pytest.raises(ArtError, match="exactly one mesh"):
+        mr.GltfModelReader(str(path))
+
+
+def _parse(path):
+    b = open(path, "rb").read()
+    clen, _ = struct.unpack("<II", b[12:20])
+    doc = json.loads(b[20:20 + clen])
+    off = 20 + clen
+    blen, _ = struct.unpack("<II", b[off:off + 8])
+    return doc, b[off + 8:off + 8 + blen]
+
+
+def _accessor(doc, bin_, i):
+    a = doc["accessors"][i]
+    v = doc["bufferViews"][a["bufferView"]]
+    n = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4}[a["type"]]
+    off = v.get("byteOffset", 0) + a.get("byteOffset", 0)
+    stride = v.get("byteStride", n * 4)
+    out = np.zeros((a["count"], n), np.float32)
+    for k in range(a["count"]):
+        out[k] = np.frombuffer(bin_, np.float32, n, off + k * stride)
+    return out
