@@ -1,0 +1,54 @@
+// host_mirror_demo.cpp -- the reference's main.rs:15-66 call sequence on the C++ host mirror.
+//   host_mirror_demo check            host-only checks (no GPU): light order, camera block, panic-on-error behaviour
+//   host_mirror_demo render <file.glb> [W H]   add_model + lights of main.rs + one frame; prints ray counts and a colour checksum
+#include <cstdio>
+#include <cstring>
+#include "../araytracingjourney_amd/host/art_renderer.hpp"
+
+static int host_checks() {
+    using namespace art;
+    Lights lights;
+    lights.get_area_lights_mut().push_back(AreaLight({-0.70f, 0.77f, 0.08f}, {-0.70f, 0.77f, -0.16f}, {-0.70f, 0.90f, -0.16f}, false, {5.88f, 0.18f, 1.23f}, 3.0f, {1.5708f, 1.5708f}, true)); // main.rs:55-64
+    lights.get_spot_lights_mut().push_back(SpotLight({0.0f, 1.5f, 0.0f}, {0.0f, -1.0f, 0.0f}, {13.6f, 1.6f, 22.2f}, 3.0f, {0.5236f, 0.7854f}, true));                                   // main.rs:42-49
+    lights.get_point_lights_mut().push_back(PointLight({0, 1, 0}, {8, 8, 8}, 3.0f, true));
+    lights.get_directional_lights_mut().push_back(DirectionalLight({-0.3f, -1.0f, -0.2f}, {3, 3, 3}, true));
+    std::vector<ArtLight> recs = lights.copy_lights_shader_data();
+    if (recs.size() != 4 || recs[0].type != 0 || recs[1].type != 1 || recs[2].type != 2 || recs[3].type != 3) { std::puts("FAIL light order"); return 1; } // lights.rs:24-47
+    if (std::fabs(recs[3].dir[0] + 1.0f) > 1e-6f) { std::puts("FAIL area normal"); return 1; }                                                                // lights.rs:385-389
+    Camera cam({0, 0, 0}, {0, 0, 1}, 1.0f, 1.57079632679f, 0.1f, 1000.0f);
+    const ArtCamera &b = cam.update_host_buffer();
+    if (std::fabs(b.view[0] - 1) > 1e-6f || std::fabs(b.view[5] + 1) > 1e-6f || std::fabs(b.view[10] + 1) > 1e-6f) { std::puts("FAIL view matrix"); return 1; } // up = -Y, looks down +Z
+    bool panicked = false;
+    try { GltfModelReader::open("/nonexistent.glb", true, GltfModelReader::B8G8R8A8_UNORM); } catch (const Panic &p) { panicked = std::strstr(p.what(), "Could not read file") != nullptr; }
+    if (!panicked) { std::puts("FAIL missing file must panic"); return 1; }
+    std::puts("HOST_MIRROR_OK");
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    try {
+        if (argc >= 2 && !std::strcmp(argv[1], "check")) return host_checks();
+        if (argc >= 3 && !std::strcmp(argv[1], "render")) {
+            uint32_t W = argc >= 5 ? (uint32_t)std::atoi(argv[3]) : 800, H = argc >= 5 ? (uint32_t)std::atoi(argv[4]) : 800; // main.rs:18
+            art::Renderer renderer(W, H);
+            renderer.add_model(argv[2], {2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 2, 0});                                              // main.rs:30-36: Similarity3::from_scaling(2.0)
+            renderer.lights_mut().get_spot_lights_mut().push_back(art::SpotLight({0.0f, 1.5f, 0.0f}, {0.0f, -1.0f, 0.0f}, {13.6f, 1.6f, 22.2f}, 3.0f, {0.5236f, 0.7854f}, true));
+            renderer.lights_mut().get_point_lights_mut().push_back(art::PointLight({0.0f, 0.5f, -1.5f}, {8, 8, 8}, 6.0f, true));
+            renderer.camera_mut().set_pos({0.0f, 0.3f, -2.5f});
+            renderer.prepare_first_frame();
+            renderer.render_frame();
+            renderer.compute_ao();
+            ArtStats st = renderer.stats();
+            std::vector<float> c = renderer.color_output();
+            double sum = 0; for (float v : c) sum += v;
+            std::printf("RENDER_OK tris=%u primary=%llu shadow=%llu hit=%llu ao=%llu frame_ms=%.3f colour_sum=%.6e\n", st.num_triangles, (unsigned long long)st.primary_rays,
+                        (unsigned long long)st.shadow_rays, (unsigned long long)st.hit_pixels, (unsigned long long)st.ao_rays, st.frame_ms, sum);
+            return 0;
+        }
+        std::puts("usage: host_mirror_demo check | render <file.glb> [W H]");
+        return 2;
+    } catch (const art::Panic &p) {
+        std::printf("PANIC(%d): %s\n", p.code, p.what());
+        return 3;
+    }
+}

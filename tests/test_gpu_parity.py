@@ -199,6 +199,22 @@ def test_glb_ingest_feeds_the_same_frame(R, get_scene, tmp_path):
     g.close(); direct.close()
 
 
+def test_cpp_host_mirror_renders_a_glb(R, get_scene, tmp_path):
+    """main.rs:15-66 on the C++ mirror: add_model(.glb) + lights + prepare_first_frame + render_frame + compute_ao"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from glb_writer import write_glb
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    sc = get_scene("cornell")
+    path = tmp_path / "cornell.glb"
+    write_glb(str(path), sc.primitives, png_modes=("RGBA", "RGBA", "RGBA"))
+    out = subprocess.run([os.path.join(root, "examples", "host_mirror_demo"), "render", str(path), "160", "96"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "RENDER_OK" in out.stdout, out.stdout + out.stderr
+    f = dict(kv.split("=") for kv in out.stdout.split("RENDER_OK")[1].split())
+    assert int(f["tris"]) == 34 and int(f["primary"]) == 160 * 96 and int(f["hit"]) > 1000 and int(f["ao"]) == 16 * int(f["hit"]) and float(f["colour_sum"]) > 0
+
+
 def test_frame_ring_gives_the_same_frames(R, get_scene):
     """3 frames in flight (the reference's FrameData ring, renderer.rs:135): every frame equals the single-slot render"""
     sc = get_scene("cornell")

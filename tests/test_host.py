@@ -68,6 +68,13 @@ def test_host_maths_behind_the_abi_matches_the_oracle(orc):
         assert bytes(arr[i]) == bytes(ref[i])
 
 
+def test_cpp_host_mirror_builds_and_passes_its_host_checks():
+    """araytracingjourney_amd/host/art_renderer.hpp: the C++ twin of renderer.rs / lights.rs / vk_camera.rs over the C ABI"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    r = subprocess.run([os.path.join(ROOT, "examples", "host_mirror_demo"), "check"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "HOST_MIRROR_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_scene_generators(get_scene):
     c = get_scene("cornell")
     assert c.n_tris == 34 and len(c.primitives) == 3 and all(p.indices.dtype == np.uint16 for p in c.primitives)
