@@ -89,6 +89,7 @@ SYMBOLS = {
     "art_shard_tile_count": (_I32, [_P, _P, _P]),
     "art_device_color_tiles": (_I32, [_P, _P, _P]),
     "art_bind_color_tiles": (_I32, [_P, _U32, _P, _SZ]),
+    "art_set_graph_mode": (_I32, [_P, _I32]),
     "art_frames_in_flight": (_I32, [_P, _P, _P]),
     "art_stream_wait_frame": (_I32, [_P, _P]),
     "art_wait_external_event": (_I32, [_P, _P]),

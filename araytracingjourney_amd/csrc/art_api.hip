@@ -49,6 +49,7 @@ struct FrameSlot {
     DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
     hipEvent_t done = nullptr;       // recorded after the slot's last frame
+    hipGraphExec_t graph = nullptr;  // the frame's launch sequence captured once (graph mode); dropped whenever an input changes
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
@@ -81,6 +82,7 @@ struct ArtContext {
     hipEvent_t ev[kRing][5] = {};
     uint64_t frame_no = 0, collected_upto = 0;
     bool traced = false;
+    bool graph_mode = false; // replay a captured hipGraph per slot instead of 5 launches + 6 event records (host-bound multi-GPU runs)
     uint32_t ao_spp = 0;
     ArtStats stats{};
     hipStream_t stream_of(uint32_t k) const { return (ext_stream && F == 1) ? ext_stream : slot[k].own; }
@@ -106,6 +108,11 @@ void affine_inverse(const float *m, float *o) { // row-major 3x4
 int32_t use_device(ArtContext *c) {
     HIPC(hipSetDevice(c->device));
     return ART_OK;
+}
+
+void drop_graphs(ArtContext *c) {
+    for (uint32_t k = 0; k < kMaxFrames; k++)
+        if (c->slot[k].graph) { (void)hipStreamSynchronize(c->stream_of(k)); (void)hipGraphExecDestroy(c->slot[k].graph); c->slot[k].graph = nullptr; } // never destroy a graph in flight
 }
 
 int32_t sync_all(ArtContext *c) {
@@ -145,6 +152,7 @@ int32_t setup_frame(ArtContext *c) {
         if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * 16) { S.ext_tiles = nullptr; S.ext_tiles_bytes = 0; }
     }
     HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
+    drop_graphs(c);
     c->frame_ready = true;
     return ART_OK;
 }
@@ -239,6 +247,7 @@ int32_t art_destroy(ArtContext *c) {
     if (!c) return ART_OK;
     (void)hipSetDevice(c->device);
     for (uint32_t k = 0; k < c->F; k++) (void)hipStreamSynchronize(c->stream_of(k));
+    drop_graphs(c);
     lbvh_free(c->bvh);
     c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release();
     c->d_lights[0].release(); c->d_lights[1].release(); c->d_tile_list.release();
@@ -299,7 +308,7 @@ int32_t art_scene_build(ArtContext *c) {
     if (c->prims.empty()) return fail(ART_E_STATE, "art_scene_build: no primitives");
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
-    lbvh_free(c->bvh); c->built = false;
+    lbvh_free(c->bvh); c->built = false; drop_graphs(c);
     size_t nv = 0, ib = 0, nt = 0; uint32_t T = 0;
     for (auto &p : c->prims) { nv += p.verts.size(); ib += (p.indices.size() + 15) & ~(size_t)15; nt += (size_t)3 * p.tw * p.th; }
     HIPC(c->d_verts.ensure(nv * 12)); HIPC(c->d_indices.ensure(ib)); HIPC(c->d_tex.ensure(nt));
@@ -339,6 +348,7 @@ int32_t art_scene_build(ArtContext *c) {
 
 int32_t art_set_camera(ArtContext *c, const ArtCamera *cam) {
     if (!c || !cam) return fail(ART_E_INVALID, "art_set_camera: null argument");
+    if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) drop_graphs(c); // the camera block is a kernel argument
     c->camera = *cam; c->have_camera = true;
     return ART_OK;
 }
@@ -378,6 +388,7 @@ int32_t art_set_lights(ArtContext *c, const ArtLight *lights, uint32_t n) {
     if (same) return ART_OK; // like VkLights' dirty flag (vk_lights.rs:81-139)
     c->lights.assign(lights, lights + n);
     if (resized) { r = sync_all(c); if (r) return r; } // the per-frame buffers are resized with the light count
+    drop_graphs(c);
     c->lights_cur ^= 1; // frames in flight keep reading the previous buffer
     HIPC(c->d_lights[c->lights_cur].ensure(n));
     if (n) HIPC(hipMemcpy(c->d_lights[c->lights_cur].p, lights, (size_t)n * sizeof(ArtLight), hipMemcpyHostToDevice));
@@ -452,6 +463,25 @@ int32_t art_trace(ArtContext *c) {
     if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
     FrameArgs a = make_frame_args(c, S);
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
+    if (c->graph_mode) {
+        if (!S.graph) { // capture the frame once per slot; stage events are not part of it
+            hipGraph_t g = nullptr;
+            HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            hipError_t e = hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s);
+            if (e == hipSuccess && a.n_local) { launch_primary(a, s); launch_shade(a, s); launch_shadow(a, s); launch_accumulate(a, s); e = hipGetLastError(); }
+            hipError_t e2 = hipStreamEndCapture(s, &g);
+            if (e != hipSuccess || e2 != hipSuccess) { if (g) (void)hipGraphDestroy(g); return hipfail(e != hipSuccess ? e : e2, "art_trace: graph capture"); }
+            e = hipGraphInstantiate(&S.graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { S.graph = nullptr; return hipfail(e, "hipGraphInstantiate"); }
+        }
+        for (int i = 0; i < 4; i++) HIPC(hipEventRecord(ev[i], s));
+        HIPC(hipGraphLaunch(S.graph, s));
+        HIPC(hipEventRecord(ev[4], s));
+        HIPC(hipEventRecord(S.done, s));
+        c->last = k; c->frame_no++; c->traced = true;
+        return ART_OK;
+    }
     HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s));
     HIPC(hipEventRecord(ev[0], s));
     if (a.n_local) launch_primary(a, s);
@@ -569,6 +599,14 @@ int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t byt
     if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * 16) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
     HIPC(hipStreamSynchronize(c->stream_of(slot)));
     c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
+    drop_graphs(c);
+    return ART_OK;
+}
+int32_t art_set_graph_mode(ArtContext *c, int32_t on) {
+    if (!c) return fail(ART_E_INVALID, "art_set_graph_mode: null context");
+    if (on && c->ext_stream) return fail(ART_E_STATE, "art_set_graph_mode: not with an external stream");
+    c->graph_mode = on != 0;
+    if (!on) drop_graphs(c);
     return ART_OK;
 }
 int32_t art_frames_in_flight(ArtContext *c, uint32_t *frames, uint32_t *next_slot) {

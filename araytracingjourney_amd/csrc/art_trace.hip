@@ -136,13 +136,15 @@ template <bool ANY, int OVF> struct TravBase {
         tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; cur = 0; sp = 0;
     }
     __device__ __forceinline__ void push(int ref, int *lds, int *ovf) {
-        if (sp < kLdsStack) lds[sp * kBlock] = ref; else if (sp < kLdsStack + OVF) ovf[sp - kLdsStack] = ref;
+        // the spill accesses are volatile so that the compiler keeps them apart from the LDS ones: merged, they become flat_load
+        // / flat_store on a selected pointer, which waits on vmcnt AND lgkmcnt at every pop
+        if (sp < kLdsStack) lds[sp * kBlock] = ref; else if (sp < kLdsStack + OVF) *(volatile int *)&ovf[sp - kLdsStack] = ref;
         sp = min(sp + 1, kLdsStack + OVF); // the tree cannot need more (see the bounds above); never index past the spill area
     }
     __device__ __forceinline__ bool pop(int *lds, int *ovf) { // true: stack empty, the ray is finished
         if (sp == 0) return true;
         sp--;
-        cur = sp < kLdsStack ? lds[sp * kBlock] : ovf[sp - kLdsStack];
+        if (sp < kLdsStack) cur = lds[sp * kBlock]; else cur = *(volatile int *)&ovf[sp - kLdsStack];
         return false;
     }
     // accept() of DESIGN.md 1.1 for the triangle in `cur`: exact triangle-AABB slab, then Moeller-Trumbore

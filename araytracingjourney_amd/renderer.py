@@ -302,6 +302,9 @@ class Renderer:
     def bind_color_tiles(self, slot, dev_ptr, nbytes):
         check(self._L.art_bind_color_tiles(self._ctx, slot, C.c_void_p(dev_ptr) if dev_ptr else None, nbytes))
 
+    def set_graph_mode(self, on):
+        check(self._L.art_set_graph_mode(self._ctx, int(bool(on))))
+
     def frames_in_flight(self):
         f, nxt = C.c_uint32(), C.c_uint32()
         check(self._L.art_frames_in_flight(self._ctx, C.byref(f), C.byref(nxt)))

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0, help="scene detail (1.0 = the 262k-triangle config)")
     ap.add_argument("--frames-in-flight", type=int, default=3, help="ring of per-frame streams/buffers, like the reference's 3-deep FrameData ring (renderer.rs:135)")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
+    ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
@@ -122,6 +123,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = (world > 1) if args.graph < 0 else bool(args.graph)
+    r.set_graph_mode(use_graph)
     for _ in range(args.warmup):
         step()
     fence()
@@ -134,6 +137,7 @@ def main():
     stage, n_timed = r.collect_timings()  # HIP events on the frames' own streams, over the timed frames (last <= 128)
     # the same kernels with ONE frame on the GPU at a time (not part of the timed region; for the isolated roofline figure)
     iso = {}
+    r.set_graph_mode(False)   # per-stage events need the individual launches
     for _ in range(8):
         step()
         fence()
@@ -162,6 +166,8 @@ def main():
     else:
         rays_total, shadow_total = float(rays_local), float(st["shadow_rays"])
         stage_max = stage
+    if use_graph:   # no per-stage events inside a replayed graph: price the roofline with the one-frame-alone launches
+        stage_max = dict(iso, frame_ms=stage_max["frame_ms"])
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -233,7 +239,7 @@ def main():
         "config": {"workload": f"sponza_like(seed=0x5A0A, {sc.n_tris} triangles, 25 primitives) {W}x{H}, {args.lights} light(s), "
                                f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
                    "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather to rank 0") + f", {F} frames in flight"},
-        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F,
+        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F, "hip_graph_replay": use_graph,
         "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "build_ms": st["build_ms"],
         "gathered_frame_equals_single_gpu_frame": frame_ok,
         "roofline": roof, "cpu_baseline": cpu,

@@ -104,6 +104,10 @@ int32_t art_destroy(ArtContext *ctx);
 /* use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream.
  * Only for one frame in flight: a ring owns its streams, see art_stream_wait_frame / art_wait_external_event. */
 int32_t art_set_stream(ArtContext *ctx, void *hip_stream);
+/* graph mode: art_trace replays one captured hipGraph per ring slot (memset + 4 launches) instead of issuing them one by
+ * one -- for host-bound runs (small per-GPU frames).  The capture is redone after a camera / light / extent / scene change;
+ * per-stage timings are not available in this mode (only the whole frame). */
+int32_t art_set_graph_mode(ArtContext *ctx, int32_t on);
 /* frame ring: number of slots and the slot the NEXT art_trace will use */
 int32_t art_frames_in_flight(ArtContext *ctx, uint32_t *frames, uint32_t *next_slot);
 /* make an external stream wait (on the device) for the most recently traced frame */

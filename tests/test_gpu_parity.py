@@ -233,6 +233,15 @@ def test_frame_ring_gives_the_same_frames(R, get_scene):
     for i in range(9):          # same camera, no host sync between frames
         ring.trace()
     assert np.array_equal(ring.read_color().view(np.uint32), one.read_color().view(np.uint32))
+    ring.set_graph_mode(True)   # replayed hipGraphs: same frames; a camera change re-captures
+    for i in range(7):
+        ring.trace()
+    assert np.array_equal(ring.read_color().view(np.uint32), one.read_color().view(np.uint32))
+    for r in (one, ring):
+        r.camera_mut().set_pos((0.11, 0.02, -0.9))
+        r.upload_state()
+        r.trace()
+    assert np.array_equal(ring.read_color().view(np.uint32), one.read_color().view(np.uint32))
     assert ring.stats()["shadow_rays"] == one.stats()["shadow_rays"]
     one.close()
     ring.close()
