@@ -18,6 +18,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # a shard's frame is small: many frames must be in flight to keep a GPU busy, and each ring slot's stream needs a hardware
+    # queue of its own (the runtime's default is 4).  Must be set before the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 
@@ -39,7 +43,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1, choices=[1, 4])
     ap.add_argument("--detail", type=float, default=1.0, help="scene detail (1.0 = the 262k-triangle config)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="ring of per-frame streams/buffers, like the reference's 3-deep FrameData ring (renderer.rs:135)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="ring of per-frame streams/buffers; default 3 like the reference's FrameData ring (renderer.rs:135) on one GPU, 12 when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -71,7 +75,7 @@ def main():
     sc = scenes.sponza_like(args.detail)
     lights = scenes.sponza_lights(args.lights)
     sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    F = max(1, min(4, args.frames_in_flight))
+    F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else (3 if world == 1 else 12)
     r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F)
     r.upload_state()
     stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
