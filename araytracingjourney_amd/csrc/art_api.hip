@@ -67,7 +67,7 @@ struct ArtContext {
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
-    int kind_primary = 2, kind_shadow = 4; // structure walked: 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
+    int kind_primary = 8, kind_shadow = 4; // primary: 8 = packet walk over the binary nodes; per-ray walks: 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
     // device scene
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
     Lbvh bvh{};
@@ -238,7 +238,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
     c->W = cfg->width; c->H = cfg->height;
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
-        if (ok(w[0])) { c->kind_primary = w[0] - '0'; c->kind_shadow = ok(w[1]) ? w[1] - '0' : c->kind_primary; } }
+        if (ok(w[0]) || w[0] == '8') { c->kind_primary = w[0] - '0'; c->kind_shadow = ok(w[1]) ? w[1] - '0' : (w[0] == '8' ? 4 : c->kind_primary); } }
     *out = c;
     return ART_OK;
 }
@@ -752,7 +752,7 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     if (e == hipSuccess && sync_all(c) != ART_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
-    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_primary}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_primary == 8 ? 2 : c->kind_primary}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);

@@ -240,6 +240,78 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
     }
 };
 
+// ---- packet traversal for primary rays -------------------------------------------------------------------------------
+// The 64 rays of a wave are the pixels of one 8x8 block: almost the same path through the tree.  The wave walks ONE shared
+// path (the union of its rays' paths): the node index is wave-uniform, so the node and triangle records come through the
+// scalar cache instead of a 64-lane gather, there is no per-lane stack and no divergence outside the triangle test; each lane
+// still tests its own ray against both child boxes with its own t_best.  A lane that would accept a triangle passes the slab
+// test of every enclosing box (monotone slab), so the packet finds exactly the per-ray answer, bit for bit.
+constexpr int kPacketStack = 96; // a shared stack of node references per wave; the radix tree is at most 95 levels deep
+__global__ __launch_bounds__(kBlock) void k_primary_packet(FrameArgs a) {
+    __shared__ int wstack[(kBlock / 64) * kPacketStack];
+    int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t x = 0, y = 0;
+    bool on = p < a.n_local && local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
+    Ray r;
+    {
+        float px = (float)x + 0.5f, py = (float)y + 0.5f;
+        float dx = (px / (float)a.W) * 2.0f - 1.0f, dy = (py / (float)a.H) * 2.0f - 1.0f;
+        V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
+        V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
+        V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
+        ray_init(r, org, dir, 0.001f, 10000.0f);
+    }
+    float tbest = r.tmax, bu = 0.f, bv = 0.f;
+    uint32_t bpos = kNoHit, bgid = kNoHit;
+    int cur = 0, sp = 0; // wave-uniform
+    if (__ballot(on) != 0ull) {
+        for (;;) {
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            bool popit = false;
+            if (cur >= 0) {
+                const float4 *nq = reinterpret_cast<const float4 *>(a.nodes + cur);
+                float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+                int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+                float te0, te1;
+                bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0) && on;
+                bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1) && on;
+                uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+                if (m0 != 0ull && m1 != 0ull) { // both: go where most rays that hit both enter first, stack the other
+                    uint64_t f0 = __ballot(h0 && (!h1 || te0 <= te1)), f1 = __ballot(h1 && (!h0 || te1 < te0));
+                    bool first0 = __popcll(f0) >= __popcll(f1);
+                    if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = first0 ? c1 : c0;
+                    sp = min(sp + 1, kPacketStack);
+                    cur = first0 ? c0 : c1;
+                } else if (m0 != 0ull) cur = c0;
+                else if (m1 != 0ull) cur = c1;
+                else popit = true;
+            } else {
+                uint32_t pos = (uint32_t)~cur;
+                const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
+                float4 va = tq[0], vb = tq[1], vc = tq[2];
+                float te;
+                if (on && slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+                               fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
+                    float t, u, v;
+                    if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
+                        float teff = fmaxf(t, te);
+                        uint32_t gid = __float_as_uint(vc.w);
+                        if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
+                    }
+                }
+                popit = true;
+            }
+            if (popit) {
+                if (sp == 0) break;
+                sp--;
+                cur = stk[sp]; // same address in every lane: one broadcast LDS read (lane 0's write is ordered before it within the wave)
+            }
+        }
+    }
+    if (p < a.n_local) a.hits[p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+}
+
 // ---- ray-traced ambient occlusion (BASELINE config 5): XeGTAO's I/O contract on the tracer ------------------------
 // inputs: the frame's depth + view-space normal outputs (vk_xe_gtao.rs:295-333); noise: Hilbert index driving the R2
 // sequence (main_pass.comp.hlsl:48-65, XeGTAO.h:120-142) with index + 288 * sample; cosine-weighted hemisphere.
@@ -672,6 +744,7 @@ template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipeli
     else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);
 }
 void launch_primary(const FrameArgs &f, hipStream_t s) {
+    if (f.trace_kind[0] == 8) { k_primary_packet<<<blocks_for(f.n_local), kBlock, 0, s>>>(f); return; } // packet walk over the binary nodes
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;

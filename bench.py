@@ -18,10 +18,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    # a shard's frame is small: many frames must be in flight to keep a GPU busy, and each ring slot's stream needs a hardware
-    # queue of its own (the runtime's default is 4).  Must be set before the HIP runtime starts.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Several frames are kept in flight (the reference keeps 3: renderer.rs:135); each ring slot's stream needs a hardware queue of
+# its own to overlap with the others, and the runtime's default is 4.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 
@@ -75,7 +74,7 @@ def main():
     sc = scenes.sponza_like(args.detail)
     lights = scenes.sponza_lights(args.lights)
     sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else (3 if world == 1 else 12)
+    F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else (12 if world == 1 else 16)
     r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F)
     r.upload_state()
     stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
