@@ -90,19 +90,18 @@ __device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v
 constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], conflict-free); deeper entries spill to scratch
 constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (63 key bits + 32 index bits)
 constexpr int kBlock = 256;
-// tunables of the persistent tracer: {chunk, refill, blocks, leaf_batch}.  Measured on config 2 (profiles/README.md):
+// tunables of the persistent tracer: {chunk, refill, blocks}.  Measured on config 2 (profiles/README.md):
 // one frame at a time is bound by the slowest wave's critical path -> small chunks, more waves; several frames in flight
-// are throughput-bound -> fewer cursor atomics, fewer resident waves.  ART_CHUNK / ART_REFILL / ART_BLOCKS / ART_LEAF_BATCH
+// are throughput-bound -> fewer cursor atomics, fewer resident waves.  ART_CHUNK / ART_REFILL / ART_BLOCKS
 // in the environment override both presets (sweeps).
-struct Tune { uint32_t chunk, refill, blocks, leaf_batch; };
-static Tune g_tune[2] = {{64, 12, 1536, 1}, {128, 24, 1024, 1}};
+struct Tune { uint32_t chunk, refill, blocks; };
+static Tune g_tune[2] = {{64, 12, 1536}, {128, 24, 1024}};
 static bool g_tune_init = false;
 static const Tune &tune(bool pipelined) {
     if (!g_tune_init) {
         for (int k = 0; k < 2; k++) {
             if (const char *e = getenv("ART_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) g_tune[k].chunk = (uint32_t)v; }
             if (const char *e = getenv("ART_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) g_tune[k].refill = (uint32_t)v; }
-            if (const char *e = getenv("ART_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) g_tune[k].leaf_batch = (uint32_t)v; }
             if (const char *e = getenv("ART_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 16384) g_tune[k].blocks = (uint32_t)v; }
         }
         g_tune_init = true;
@@ -738,7 +737,7 @@ static inline uint32_t persistent_blocks(uint32_t total, bool pipelined) {
 template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipelined, hipStream_t s) {
     uint32_t nb = persistent_blocks(a.total, pipelined);
     const Tune &t = tune(pipelined);
-    a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = t.leaf_batch;
+    a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = 1; // batching was measured slower at every threshold (profiles/README.md)
     if (kind == 4) k_trace<MODE, 4><<<nb, kBlock, 0, s>>>(a);
     else if (kind == 1) k_trace<MODE, 1><<<nb, kBlock, 0, s>>>(a);
     else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);

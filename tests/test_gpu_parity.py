@@ -269,3 +269,67 @@ def test_single_triangle_known_answers(R):
     assert np.allclose(tuv[0, :3], [2, .25, .25]) and np.allclose(tuv[6, :3], [2, .25, .25]) and np.allclose(tuv[7, :3], [2, .5, .5])
     assert r.query_any(rays).tolist() == [1, 0, 0, 0, 0, 0, 1, 1]
     r.close()
+
+
+def test_api_state_and_argument_errors(R, get_scene):
+    """the reference panics on misuse (unwrap/expect); the C ABI returns ART_E_* with a message"""
+    from araytracingjourney_amd import _lib
+    import ctypes as C
+    sc = get_scene("cornell")
+    r = R.Renderer((64, 64))
+    with pytest.raises(_lib.ArtError) as e:
+        r.prepare_first_frame()                       # no primitives
+    assert e.value.code == _lib.ART_E_STATE
+    r.add_model(sc.primitives)
+    with pytest.raises(_lib.ArtError) as e:
+        r.trace()                                     # scene not built
+    assert e.value.code == _lib.ART_E_STATE
+    r.prepare_first_frame()
+    with pytest.raises(_lib.ArtError) as e:
+        r.trace()                                     # no camera yet
+    assert e.value.code == _lib.ART_E_STATE and "camera" in str(e.value)
+    with pytest.raises(_lib.ArtError):
+        r.read_color()                                # nothing traced
+    with pytest.raises(_lib.ArtError):
+        r.trace_ao(16)                                # AO before a frame
+    r.upload_state()                                  # zero lights: every hit pixel is black, misses too
+    r.trace()
+    c = r.read_color()
+    assert np.array_equal(c[..., :3], np.zeros_like(c[..., :3])) and (c[..., 3] == 1).all() and r.stats()["shadow_rays"] == 0
+    with pytest.raises(_lib.ArtError) as e:
+        r.resize((0, 10))
+    assert e.value.code == _lib.ART_E_INVALID
+    with pytest.raises(_lib.ArtError):
+        r.trace_ao(65)                                # spp out of range
+    p = sc.primitives[0]
+    bad = p.indices.copy(); bad[0] = p.verts.shape[0]  # index out of range is rejected on the host, never reaches a kernel
+    with pytest.raises(_lib.ArtError) as e:
+        R.Renderer((8, 8)).add_model([type(p)(p.verts, bad, p.tex, p.model)])
+    assert "index out of range" in str(e.value)
+    cfg = _lib.ArtConfig(device=99, width=8, height=8)
+    ctx = C.c_void_p()
+    assert _lib.load().art_create(C.byref(cfg), C.byref(ctx)) == _lib.ART_E_INVALID
+    r.close()
+
+
+def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
+    """the light table's upper bound (16) and a light change between frames (VkLights dirty flag, vk_lights.rs:81-139)"""
+    import math
+    sc = get_scene("cornell")
+    lights = [dict(kind="point", pos=(0.3 * math.cos(k), 0.3, 0.3 * math.sin(k)), color=(0.5 + 0.1 * k, 0.6, 0.9 - 0.05 * k), falloff=3.0, casts_shadows=(k % 3 != 0))
+              for k in range(16)]
+    sc16 = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
+    ref = _frame_parity(R, orc, sc16, 96, 64, None)
+    assert ref["stats"]["shadow_rays"] > 96 * 64 * 5
+    r = R.renderer_for_scene(sc, (96, 64))
+    r.render_frame()
+    a = r.read_color()
+    r.lights_mut().get_point_lights_mut()[0].color = (0.0, 4.0, 0.0)
+    r.render_frame()
+    b = r.read_color()
+    assert not np.array_equal(a, b) and b[..., 0].max() == 0 and b[..., 2].max() == 0 and b[..., 1].max() > 0
+    with pytest.raises(Exception):
+        for k in range(17):
+            r.lights_mut().get_point_lights_mut().append(R.PointLight((0, 0.5, 0), (1, 1, 1), 3.0, False))
+        r.upload_state()
+    r.close()
