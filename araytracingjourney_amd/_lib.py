@@ -77,6 +77,10 @@ SYMBOLS = {
     "art_resize": (_I32, [_P, _U32, _U32]),
     "art_trace": (_I32, [_P]),
     "art_sync": (_I32, [_P]),
+    "art_present": (_I32, [_P]),
+    "art_read_present": (_I32, [_P, _P, _SZ]),
+    "art_read_packed": (_I32, [_P, _P, _P, _P]),
+    "art_lpm_control_block": (_I32, [_I32, _F, _F, _F, _F, _F, _P, _P, _P]),
     "art_trace_ao": (_I32, [_P, _U32, _F]),
     "art_read_ao": (_I32, [_P, _P, _SZ]),
     "art_read_color": (_I32, [_P, _P, _SZ]),

@@ -46,14 +46,15 @@ struct FrameSlot {
     DevBuf<uint32_t> d_counters, d_shadow_bits;
     DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
     DevBuf<float> d_depth;
-    DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; hipEvent_t ao_ev[2] = {nullptr, nullptr};
+    DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; bool ao_valid = false;
+    DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
     hipEvent_t done = nullptr;       // recorded after the slot's last frame
     hipGraphExec_t graph = nullptr;  // the frame's launch sequence captured once (graph mode); dropped whenever an input changes
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
-        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release();
+        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
     }
 };
 constexpr uint32_t kMaxFrames = 16;
@@ -479,6 +480,7 @@ int32_t art_trace(ArtContext *c) {
         HIPC(hipGraphLaunch(S.graph, s));
         HIPC(hipEventRecord(ev[4], s));
         HIPC(hipEventRecord(S.done, s));
+        S.ao_valid = false; S.presented = false;
         c->last = k; c->frame_no++; c->traced = true;
         return ART_OK;
     }
@@ -494,6 +496,7 @@ int32_t art_trace(ArtContext *c) {
     HIPC(hipEventRecord(ev[4], s));
     HIPC(hipEventRecord(S.done, s));
     HIPC(hipGetLastError());
+    S.ao_valid = false; S.presented = false;
     c->last = k;
     c->frame_no++;
     c->traced = true;
@@ -527,7 +530,31 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     HIPC(hipEventRecord(S.ao_ev[1], s));
     HIPC(hipEventRecord(S.done, s));
     HIPC(hipGetLastError());
-    c->stats.ao_rays = 0; c->ao_spp = spp;
+    c->stats.ao_rays = 0; c->ao_spp = spp; S.ao_valid = true;
+    return ART_OK;
+}
+
+int32_t art_present(ArtContext *c) {
+    if (!c) return fail(ART_E_INVALID, "art_present: null context");
+    if (!c->traced || !c->frame_ready) return fail(ART_E_STATE, "art_present: call art_trace first");
+    int32_t r = use_device(c); if (r) return r;
+    FrameSlot &S = c->slot[c->last];
+    hipStream_t s = c->stream_of(c->last);
+    size_t npix = (size_t)c->W * c->H;
+    if (S.d_bgra.n < npix) { HIPC(hipStreamSynchronize(s)); HIPC(S.d_pcolor.ensure(npix)); HIPC(S.d_pnormal.ensure(npix)); HIPC(S.d_bgra.ensure(npix)); HIPC(S.d_pdepth.ensure(npix)); }
+    uint32_t ctl[96];
+    const float sat[3] = {0.0f, 0.0f, 0.0f}, ct[3] = {1.0f, 0.5f, 1.0f / 32.0f};
+    lpm_control_block(false, 0.0f, 256.0f, 8.0f, 0.25f, 1.0f, sat, ct, ctl); // the parameters of vk_tonemap.rs:417-426
+    launch_present((uint32_t)npix, S.d_color.p, S.d_normal.p, S.d_depth.p, S.ao_valid ? S.d_ao.p : nullptr, ctl, S.d_pcolor.p, S.d_pnormal.p, S.d_pdepth.p, S.d_bgra.p, s);
+    HIPC(hipEventRecord(S.done, s));
+    HIPC(hipGetLastError());
+    S.presented = true;
+    return ART_OK;
+}
+int32_t art_lpm_control_block(int32_t shoulder, float soft_gap, float hdr_max, float exposure, float contrast, float shoulder_contrast, const float saturation[3],
+                              const float crosstalk[3], uint32_t ctl[96]) {
+    if (!saturation || !crosstalk || !ctl) return fail(ART_E_INVALID, "art_lpm_control_block: null argument");
+    lpm_control_block(shoulder != 0, soft_gap, hdr_max, exposure, contrast, shoulder_contrast, saturation, crosstalk, ctl);
     return ART_OK;
 }
 
@@ -554,6 +581,23 @@ static int32_t dev_ptr(ArtContext *c, void *p, size_t n, void **out, size_t *byt
 int32_t art_read_ao(ArtContext *c, void *dst, size_t bytes) {
     if (c && c->ao_spp == 0) return fail(ART_E_STATE, "art_read_ao: art_trace_ao has not run");
     return read_back(c, c ? c->slot[c->last].d_ao.p : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_ao");
+}
+static int32_t need_present(ArtContext *c, const char *who) {
+    if (c && !c->slot[c->last].presented) return fail(ART_E_STATE, std::string(who) + ": art_present has not run for the latest frame");
+    return ART_OK;
+}
+int32_t art_read_present(ArtContext *c, void *dst, size_t bytes) {
+    int32_t r = need_present(c, "art_read_present"); if (r) return r;
+    return read_back(c, c ? c->slot[c->last].d_bgra.p : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_present");
+}
+int32_t art_read_packed(ArtContext *c, void *color_b10g11r11, void *normal_b10g11r11, void *depth_f16) {
+    int32_t r = need_present(c, "art_read_packed"); if (r) return r;
+    if (!c) return fail(ART_E_INVALID, "art_read_packed: null context");
+    size_t npix = (size_t)c->W * c->H;
+    if (color_b10g11r11) { r = read_back(c, c->slot[c->last].d_pcolor.p, npix * 4, color_b10g11r11, npix * 4, "art_read_packed"); if (r) return r; }
+    if (normal_b10g11r11) { r = read_back(c, c->slot[c->last].d_pnormal.p, npix * 4, normal_b10g11r11, npix * 4, "art_read_packed"); if (r) return r; }
+    if (depth_f16) { r = read_back(c, c->slot[c->last].d_pdepth.p, npix * 2, depth_f16, npix * 2, "art_read_packed"); if (r) return r; }
+    return ART_OK;
 }
 int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color"); if (r) return r; *p = c->slot[c->last].d_color.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }

@@ -107,6 +107,11 @@ void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t
 // (32 640 waves on one address cost the shading kernel 0.3 ms)
 constexpr uint32_t kCounterWords = 8192;
 constexpr uint32_t kHitSlots = 1024, kShadowSlots = 1024 + 64 * 32, kSlotStride = 32, kSlotCount = 64;
+// output packing + LPM tonemap (art_present.hip)
+void lpm_control_block(bool shoulder, float soft_gap, float hdr_max, float exposure, float contrast, float shoulder_contrast, const float saturation[3],
+                       const float crosstalk[3], uint32_t ctl[96]);
+void launch_present(uint32_t n, const float4 *color, const float4 *normal, const float *depth, const uint32_t *ao, const uint32_t ctl[96], uint32_t *pcolor,
+                    uint32_t *pnormal, uint16_t *pdepth, uint32_t *bgra, hipStream_t s);
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s);
 
 // shard tile ownership: 32x32 tile (tx,ty) belongs to shard (tx + 5*ty) % count -- a diagonal interleave, so that

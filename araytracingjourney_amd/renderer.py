@@ -261,6 +261,22 @@ class Renderer:
         check(self._L.art_read_ao(self._ctx, _ptr(a), a.nbytes))
         return a
 
+    def present(self):
+        """tonemap_layer.present (renderer.rs:566-615): pack like the reference's images, then LPM tonemap to BGRA8"""
+        check(self._L.art_present(self._ctx))
+
+    def read_present(self):
+        w, h = self.extent
+        a = np.empty((h, w, 4), np.uint8)
+        check(self._L.art_read_present(self._ctx, _ptr(a), a.nbytes))
+        return a
+
+    def read_packed(self):
+        w, h = self.extent
+        c, n, d = np.empty((h, w), np.uint32), np.empty((h, w), np.uint32), np.empty((h, w), np.uint16)
+        check(self._L.art_read_packed(self._ctx, _ptr(c), _ptr(n), _ptr(d)))
+        return c, n, d
+
     def render_frame(self, sync=True):  # renderer.rs:371
         self.upload_state()
         self.trace()

@@ -155,6 +155,16 @@ int32_t art_trace(ArtContext *ctx);
  * noise (main_pass.comp.hlsl:48-65), final power 2.2 (vk_xe_gtao.rs:22).  Enqueued behind art_trace on its stream. */
 int32_t art_trace_ao(ArtContext *ctx, uint32_t spp, float radius);
 int32_t art_read_ao(ArtContext *ctx, void *dst, size_t bytes); /* width*height uint32 */
+/* the step after the path (tonemap_layer.present, renderer.rs:566-615 / vk_tonemap.rs:469-552): packs the latest frame's
+ * outputs as the reference stores them (colour + normal B10G11R11_UFLOAT_PACK32: renderer.rs:268, vk_rt_lightning_shadows.rs:152;
+ * depth R16_SFLOAT: :142) and tonemaps like tonemap.comp.glsl:29-40 -- packed colour * ao/255 (255 if art_trace_ao has not run for
+ * this frame) -> LpmFilter(LPM_CONFIG_709_709, control block of vk_tonemap.rs:417-426) -> pow(1/2.2) -> B8G8R8A8_UNORM. */
+int32_t art_present(ArtContext *ctx);
+int32_t art_read_present(ArtContext *ctx, void *dst_bgra8, size_t bytes);                       /* width*height*4 */
+int32_t art_read_packed(ArtContext *ctx, void *color_b10g11r11, void *normal_b10g11r11, void *depth_f16); /* any may be NULL */
+/* LpmData::new (vk_tonemap.rs:54-325): the 24 x uvec4 control block, host only */
+int32_t art_lpm_control_block(int32_t shoulder, float soft_gap, float hdr_max, float exposure, float contrast, float shoulder_contrast,
+                              const float saturation[3], const float crosstalk[3], uint32_t ctl[96]);
 /* the fence (renderer.rs:451-466) */
 int32_t art_sync(ArtContext *ctx);
 

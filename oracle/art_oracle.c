@@ -956,3 +956,126 @@ void orc_render_ao(const OrcScene *s, const OrcCamera *cam, uint32_t w, uint32_t
     if (n_int) *n_int = J.n_int;
     if (n_tri) *n_tri = J.n_tri;
 }
+
+/* ------------------------------------------------------------------ output packing + LPM tonemap */
+/* float32 -> unsigned small float with 5 exponent bits and `mb` mantissa bits, round to nearest even; negatives -> 0, overflow -> +Inf */
+static uint32_t pack_ufloat(float f, int mb) {
+    uint32_t u; memcpy(&u, &f, 4);
+    uint32_t e8 = (u >> 23) & 255u, m = u & 0x7FFFFFu;
+    if (e8 == 255u && m) return (31u << mb) | 1u;               /* NaN */
+    if (u >> 31) return 0;                                       /* negative (incl. -0, -Inf) */
+    if (e8 == 255u) return 31u << mb;                            /* +Inf */
+    int e = (int)e8 - 127 + 15;
+    if (e >= 31) return 31u << mb;
+    int shift = 23 - mb;
+    uint32_t full = m | (e8 ? 0x800000u : 0u);
+    if (e <= 0) { shift += 1 - e; e = 0; if (shift > 31) return 0; }
+    else full &= 0x7FFFFFu;
+    uint32_t q = full >> shift, rem = full & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    uint32_t out = ((uint32_t)e << mb) + q;                      /* a mantissa carry rolls into the exponent */
+    return out > (31u << mb) ? (31u << mb) : out;
+}
+static float unpack_ufloat(uint32_t v, int mb) {
+    uint32_t e = v >> mb, m = v & ((1u << mb) - 1u);
+    if (e == 31u) return m ? NAN : INFINITY;
+    if (e == 0) return ldexpf((float)m, -14 - mb);
+    return ldexpf((float)(m | (1u << mb)), (int)e - 15 - mb);
+}
+uint32_t orc_pack_b10g11r11(const float rgb[3]) { return pack_ufloat(rgb[0], 6) | (pack_ufloat(rgb[1], 6) << 11) | (pack_ufloat(rgb[2], 5) << 22); }
+void orc_unpack_b10g11r11(uint32_t v, float rgb[3]) { rgb[0] = unpack_ufloat(v & 0x7FFu, 6); rgb[1] = unpack_ufloat((v >> 11) & 0x7FFu, 6); rgb[2] = unpack_ufloat(v >> 22, 5); }
+uint16_t orc_pack_f16(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    uint32_t sign = (u >> 16) & 0x8000u, e8 = (u >> 23) & 255u, m = u & 0x7FFFFFu;
+    if (e8 == 255u) return (uint16_t)(sign | 0x7C00u | (m ? 0x200u : 0u));
+    int e = (int)e8 - 127 + 15;
+    if (e >= 31) return (uint16_t)(sign | 0x7C00u);
+    int shift = 13; uint32_t full = m | (e8 ? 0x800000u : 0u);
+    if (e <= 0) { shift += 1 - e; e = 0; if (shift > 31) return (uint16_t)sign; } else full &= 0x7FFFFFu;
+    uint32_t q = full >> shift, rem = full & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    return (uint16_t)(sign | (((uint32_t)e << 10) + q));
+}
+
+/* LpmColRgbToXyz with the reference's LpmColXyToZ (vk_tonemap.rs:12-47; z = 1 - x + y as written there) */
+static void mat3_inverse(const float m[9], float o[9]) { /* row-major */
+    float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g, det = a * A + b * B + c * C, id = 1.0f / det;
+    o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+    o[3] = B * id; o[4] = (a * i - c * g) * id; o[5] = -(a * f - c * d) * id;
+    o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+}
+static void lpm_rgb_to_xyz(const float r[2], const float g[2], const float b[2], const float w[2], float out[9]) {
+    float rz[3] = {r[0], r[1], 1.0f - r[0] + r[1]}, gz[3] = {g[0], g[1], 1.0f - g[0] + g[1]}, bz[3] = {b[0], b[1], 1.0f - b[0] + b[1]};
+    float rgb3[9] = {rz[0], gz[0], bz[0], rz[1], gz[1], bz[1], rz[2], gz[2], bz[2]}; /* columns r g b */
+    float rw = 1.0f / w[1];
+    float w3[3] = {w[0] * rw, w[1] * rw, (1.0f - w[0] + w[1]) * rw};
+    float inv[9]; mat3_inverse(rgb3, inv);
+    float sc[3];
+    for (int k = 0; k < 3; k++) sc[k] = inv[3 * k] * w3[0] + inv[3 * k + 1] * w3[1] + inv[3 * k + 2] * w3[2];
+    for (int rrow = 0; rrow < 3; rrow++) for (int k = 0; k < 3; k++) out[3 * rrow + k] = rgb3[3 * rrow + k] * sc[k];
+}
+void orc_lpm_control_block(int shoulder, float soft_gap, float hdr_max, float exposure, float contrast, float shoulder_contrast,
+                           const float saturation[3], const float crosstalk[3], uint32_t ctl[96]) { /* vk_tonemap.rs:122-325, LPM_CONFIG/COLORS_709_709 */
+    (void)shoulder; (void)soft_gap;
+    memset(ctl, 0, 96 * 4);
+    contrast += 1.0f;
+    float sat[3] = {saturation[0] + contrast, saturation[1] + contrast, saturation[2] + contrast};
+    float mid_in = hdr_max * 0.18f * exp2f(-exposure), mid_out = 0.18f;
+    float cs = contrast * shoulder_contrast;
+    float z0 = -powf(mid_in, contrast), z1 = powf(hdr_max, cs) * powf(mid_in, contrast), z2 = powf(hdr_max, contrast) * powf(mid_in, cs) * mid_out;
+    float z3 = powf(hdr_max, cs) * mid_out, z4 = powf(mid_in, cs) * mid_out;
+    float tsb0 = -((z0 + (mid_out * (z1 - z2)) * (1.0f / (z3 - z4))) * (1.0f / z4));
+    float tsb1 = (z1 - z2) * (1.0f / (z3 - z4));
+    const float R[2] = {0.64f, 0.33f}, G[2] = {0.30f, 0.60f}, B[2] = {0.15f, 0.06f}, W[2] = {0.3127f, 0.3290f};
+    float m[9]; lpm_rgb_to_xyz(R, G, B, W, m);
+    float rs = 1.0f / (m[3] + m[4] + m[5]);
+    float lumaW[3] = {m[3] * rs, m[4] * rs, m[5] * rs};
+    float lumaT[3] = {m[3], m[4], m[5]};
+    float rt = 1.0f / (lumaT[0] + lumaT[1] + lumaT[2]);
+    for (int k = 0; k < 3; k++) lumaT[k] *= rt;
+    float f[40]; memset(f, 0, sizeof f);
+    f[0] = sat[0]; f[1] = sat[1]; f[2] = sat[2]; f[3] = contrast;
+    f[4] = tsb0; f[5] = tsb1; f[6] = lumaT[0]; f[7] = lumaT[1];
+    f[8] = lumaT[2]; f[9] = crosstalk[0]; f[10] = crosstalk[1]; f[11] = crosstalk[2];
+    f[12] = 1.0f / lumaT[0]; f[13] = 1.0f / lumaT[1]; f[14] = 1.0f / lumaT[2];
+    f[24] = shoulder_contrast; f[25] = lumaW[0]; f[26] = lumaW[1]; f[27] = lumaW[2];
+    memcpy(ctl, f, 40 * 4);   /* ctl[0..9]; the fp16 half of the block (ctl[16..20]) is not used by the 32-bit LpmFilter */
+}
+static void lpm_filter_709(float *cr, float *cg, float *cb, const uint32_t ctl[96]) { /* LpmMap, ffx_lpm.h:727-832, all path flags false */
+    float f[40]; memcpy(f, ctl, 40 * 4);
+    float satR = f[0], satG = f[1], satB = f[2], contrast = f[3], tsbx = f[4], tsby = f[5], lT0 = f[6], lT1 = f[7], lT2 = f[8];
+    float ctR = f[9], ctG = f[10], ctB = f[11], rl0 = f[12], rl1 = f[13], rl2 = f[14];
+    float R = *cr, G = *cg, B = *cb;
+    float rcpMax = 1.0f / fmaxf(fmaxf(R, G), B);
+    float ratioR = powf(R * rcpMax, satR), ratioG = powf(G * rcpMax, satG), ratioB = powf(B * rcpMax, satB);
+    float luma = G * lT1 + (R * lT0 + (B * lT2));
+    luma = powf(luma, contrast);
+    luma = luma * (1.0f / (luma * tsbx + tsby));
+    float lumaRatio = ratioR * lT0 + ratioG * lT1 + ratioB * lT2;
+    float ratioScale = clampf(luma * (1.0f / lumaRatio), 0.0f, 1.0f);
+    R = clampf(ratioR * ratioScale, 0.0f, 1.0f); G = clampf(ratioG * ratioScale, 0.0f, 1.0f); B = clampf(ratioB * ratioScale, 0.0f, 1.0f);
+    float capR = -ctR * R + ctR, capG = -ctG * G + ctG, capB = -ctB * B + ctB;
+    float lumaAdd = clampf((-B) * lT2 + ((-R) * lT0 + ((-G) * lT1 + luma)), 0.0f, 1.0f);
+    float t = lumaAdd * (1.0f / (capG * lT1 + (capR * lT0 + (capB * lT2))));
+    R = clampf(t * capR + R, 0.0f, 1.0f); G = clampf(t * capG + G, 0.0f, 1.0f); B = clampf(t * capB + B, 0.0f, 1.0f);
+    lumaAdd = clampf((-B) * lT2 + ((-R) * lT0 + ((-G) * lT1 + luma)), 0.0f, 1.0f);
+    *cr = clampf(lumaAdd * rl0 + R, 0.0f, 1.0f); *cg = clampf(lumaAdd * rl1 + G, 0.0f, 1.0f); *cb = clampf(lumaAdd * rl2 + B, 0.0f, 1.0f);
+}
+void orc_present(const float *color, const uint32_t *ao, uint32_t n, uint32_t *packed_color, uint8_t *bgra8) {
+    uint32_t ctl[96];
+    const float sat[3] = {0.0f, 0.0f, 0.0f}, ct[3] = {1.0f, 0.5f, 1.0f / 32.0f};
+    orc_lpm_control_block(0, 0.0f, 256.0f, 8.0f, 0.25f, 1.0f, sat, ct, ctl); /* vk_tonemap.rs:417-426 */
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t pk = orc_pack_b10g11r11(color + 4 * (size_t)i);
+        if (packed_color) packed_color[i] = pk;
+        float c[3]; orc_unpack_b10g11r11(pk, c);                         /* tonemap.comp.glsl:32 reads the stored image */
+        float a = (float)(ao ? ao[i] : 255u) / 255.0f;
+        c[0] *= a; c[1] *= a; c[2] *= a;
+        if (fmaxf(fmaxf(c[0], c[1]), c[2]) > 0.0f) lpm_filter_709(&c[0], &c[1], &c[2], ctl); else c[0] = c[1] = c[2] = 0.0f; /* 0/0 in LpmMap: black stays black */
+        for (int k = 0; k < 3; k++) { float v = powf(c[k], 1.0f / 2.2f); c[k] = v; }
+        uint8_t *o = bgra8 + 4 * (size_t)i;                               /* swapchain B8G8R8A8_UNORM (renderer.rs:191-199) */
+        o[0] = (uint8_t)(clampf(c[2], 0.0f, 1.0f) * 255.0f + 0.5f); o[1] = (uint8_t)(clampf(c[1], 0.0f, 1.0f) * 255.0f + 0.5f);
+        o[2] = (uint8_t)(clampf(c[0], 0.0f, 1.0f) * 255.0f + 0.5f); o[3] = 255;
+    }
+}

@@ -95,6 +95,17 @@ void orc_render(const OrcScene *, const OrcCamera *, const OrcLight *, uint32_t 
 void orc_render_ao(const OrcScene *, const OrcCamera *, uint32_t w, uint32_t h, const float *depth, const float *normal,
                    uint32_t spp, float radius, uint32_t *out_ao, uint64_t *n_rays, uint64_t *n_int, uint64_t *n_tri, int n_threads);
 
+/* output packing + presentation: what the reference stores and shows.
+ * pack: colour and normal as B10G11R11_UFLOAT_PACK32 (renderer.rs:268, vk_rt_lightning_shadows.rs:152), depth as R16_SFLOAT (:142);
+ * present: tonemap.comp.glsl:29-40 = colour(from the packed image) * ao/255 -> LpmFilter(LPM_CONFIG_709_709) with the control
+ * block of vk_tonemap.rs:122-325,:417-426 -> pow(1/2.2) -> B8G8R8A8_UNORM. */
+uint32_t orc_pack_b10g11r11(const float rgb[3]);
+void     orc_unpack_b10g11r11(uint32_t v, float rgb[3]);
+uint16_t orc_pack_f16(float f);
+void orc_lpm_control_block(int shoulder, float soft_gap, float hdr_max, float exposure, float contrast, float shoulder_contrast,
+                           const float saturation[3], const float crosstalk[3], uint32_t ctl[96]);
+void orc_present(const float *color, const uint32_t *ao /* may be NULL: 255 */, uint32_t n_pixels, uint32_t *packed_color, uint8_t *bgra8);
+
 /* single-point shading for known-answer tests: shades a given hit without tracing the primary ray */
 void orc_brdf_terms(float NdotL, float NdotV, float NdotH, float LdotH, float nc_NdotV, float nc_NdotL, float alpha,
                     float out[4]); /* D, V_fast, pow5 Schlick weight, Burley_local_sss */

@@ -67,6 +67,11 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_render_ao.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_pack_b10g11r11.argtypes = [C.c_void_p]; L.orc_pack_b10g11r11.restype = C.c_uint32
+        L.orc_unpack_b10g11r11.argtypes = [C.c_uint32, C.c_void_p]
+        L.orc_pack_f16.argtypes = [C.c_float]; L.orc_pack_f16.restype = C.c_uint16
+        L.orc_lpm_control_block.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_present.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_brdf_terms.argtypes = [C.c_float] * 7 + [C.c_void_p]
         L.orc_light_eval.argtypes = [C.c_void_p] * 4
         _LIB = L
@@ -204,6 +209,38 @@ def render_ao(scene: "Scene", cam: OrcCamera, depth, normal, spp, radius, thread
     nr, ni, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
     lib().orc_render_ao(scene.h, C.byref(cam), w, h, _ptr(depth), _ptr(normal), spp, radius, _ptr(out), C.byref(nr), C.byref(ni), C.byref(nt), threads)
     return out, dict(ao_rays=int(nr.value), n_int_ao=int(ni.value), n_tri_ao=int(nt.value))
+
+
+def present(color, ao=None):
+    """-> (packed B10G11R11 colour [h,w] u32, BGRA8 [h,w,4])"""
+    color = np.ascontiguousarray(color, np.float32)
+    h, w = color.shape[:2]
+    packed = np.zeros((h, w), np.uint32)
+    bgra = np.zeros((h, w, 4), np.uint8)
+    aop = np.ascontiguousarray(ao, np.uint32) if ao is not None else None
+    lib().orc_present(_ptr(color), _ptr(aop), w * h, _ptr(packed), _ptr(bgra))
+    return packed, bgra
+
+
+def pack_b10g11r11(rgb):
+    a = np.ascontiguousarray(rgb, np.float32)
+    return int(lib().orc_pack_b10g11r11(_ptr(a)))
+
+
+def unpack_b10g11r11(v):
+    out = np.zeros(3, np.float32)
+    lib().orc_unpack_b10g11r11(int(v), _ptr(out))
+    return out
+
+
+def pack_f16(f):
+    return int(lib().orc_pack_f16(float(f)))
+
+
+def lpm_control_block(shoulder, soft_gap, hdr_max, exposure, contrast, shoulder_contrast, saturation, crosstalk):
+    ctl = np.zeros(96, np.uint32)
+    lib().orc_lpm_control_block(int(shoulder), soft_gap, hdr_max, exposure, contrast, shoulder_contrast, _f3(saturation), _f3(crosstalk), _ptr(ctl))
+    return ctl
 
 
 def gen_primary(cam: OrcCamera, w, h):

@@ -333,3 +333,30 @@ def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
             r.lights_mut().get_point_lights_mut().append(R.PointLight((0, 0.5, 0), (1, 1, 1), 3.0, False))
         r.upload_state()
     r.close()
+
+
+def test_packing_and_tonemap_match_oracle(R, orc, get_scene):
+    """art_present: the reference's storage formats (bit-exact integer packing) and tonemap.comp.glsl's output (BGRA8, <= 1 LSB)"""
+    sc = get_scene("sponza_like", 0.12)
+    w, h = 480, 270
+    r = R.renderer_for_scene(sc, (w, h))
+    r.render_frame(sync=False)
+    r.trace_ao(16)
+    r.present()
+    color, normal, depth, ao = r.read_color(), r.read_normal(), r.read_depth(), r.read_ao()
+    pc, pn, pd = r.read_packed()
+    want_pc, want_bgra = orc.present(color, ao)
+    assert np.array_equal(pc, want_pc)
+    assert np.array_equal(pn, orc.present(normal)[0])
+    with np.errstate(over="ignore"):
+        assert np.array_equal(pd, depth.astype(np.float16).view(np.uint16))      # R16_SFLOAT; the 10000 of misses is representable
+    got = r.read_present()
+    diff = np.abs(got.astype(int) - want_bgra.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01 and (got[..., 3] == 255).all()
+    assert got[..., :3].max() > 100 and (got[..., :3].reshape(-1, 3).max(1) == 0).mean() > 0.01   # lit and unlit pixels both present
+    r.render_frame(sync=False)                                                     # no AO for this frame: ao = 255
+    r.present()
+    assert np.abs(r.read_present().astype(int) - orc.present(r.read_color())[1].astype(int)).max() <= 1
+    with pytest.raises(Exception):
+        R.renderer_for_scene(sc, (32, 32)).read_present()
+    r.close()
