@@ -83,7 +83,7 @@ struct FrameArgs {
     uint32_t n_local;          // n_tiles_owned * 1024
     const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
-    int trace_kind[2];         // structure walked by primary / shadow rays: 2 binary, 4 wide quantised, 1 binary quantised
+    int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised, 1 binary quantised
     const ArtLight *lights; uint32_t n_lights;
     float4 *hits;              // [n_local] t,u,v,gid
     float4 *contrib;           // [n_lights][n_local]

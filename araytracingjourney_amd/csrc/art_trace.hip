@@ -246,21 +246,48 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
 // still tests its own ray against both child boxes with its own t_best.  A lane that would accept a triangle passes the slab
 // test of every enclosing box (monotone slab), so the packet finds exactly the per-ray answer, bit for bit.
 constexpr int kPacketStack = 96; // a shared stack of node references per wave; the radix tree is at most 95 levels deep
-__global__ __launch_bounds__(kBlock) void k_primary_packet(FrameArgs a) {
+enum { PK_PRIMARY = 0, PK_SHADOW = 1, PK_AO = 2 };
+struct PacketArgs { const uint8_t *dummy; uint32_t spp; float ao_radius; uint8_t *occl; }; // AO extras
+
+__device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float depth, float4 nm, uint32_t smp, V3 &o, V3 &d);
+
+// MODE PK_PRIMARY: slot = local pixel (a wave = one 8x8 block), closest hit -> hits[].
+// MODE PK_SHADOW:  slot = light * n_local + local pixel (the dense shadow-ray slots of k_shade: the same 8x8 block, rays towards
+//                  one light), any hit -> the slot's contribution keeps 0.05.  A lane leaves the packet at its first hit.
+// MODE PK_AO:      slot = local pixel * spp + sample (short rays around a few neighbouring points), any hit -> occl[].
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
+    constexpr bool ANY = MODE != PK_PRIMARY;
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
-    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t x = 0, y = 0;
-    bool on = p < a.n_local && local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
+    const uint32_t total = MODE == PK_PRIMARY ? a.n_local : (MODE == PK_SHADOW ? a.n_local * a.n_lights : a.n_local * x.spp);
+    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    bool on = false;
     Ray r;
-    {
-        float px = (float)x + 0.5f, py = (float)y + 0.5f;
-        float dx = (px / (float)a.W) * 2.0f - 1.0f, dy = (py / (float)a.H) * 2.0f - 1.0f;
+    if (MODE == PK_PRIMARY) {
+        uint32_t px = 0, py = 0;
+        on = slot < total && local_to_xy(slot, a.tile_list, a.tiles_x, a.W, a.H, px, py);
+        float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+        float dx = (fx / (float)a.W) * 2.0f - 1.0f, dy = (fy / (float)a.H) * 2.0f - 1.0f;
         V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
         V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
         V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
         ray_init(r, org, dir, 0.001f, 10000.0f);
+    } else if (MODE == PK_SHADOW) {
+        float4 r0 = slot < total ? a.shadow_rays[2 * (size_t)slot] : make_float4(0.f, 0.f, 0.f, -1.f);
+        on = r0.w > 0.0f;
+        float4 r1 = on ? a.shadow_rays[2 * (size_t)slot + 1] : make_float4(0.f, 0.f, 1.f, 0.f);
+        ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), 0.01f, on ? r0.w : 1.0f);
+    } else {
+        uint32_t p = slot / x.spp, smp = slot - p * x.spp, px = 0, py = 0;
+        bool in = slot < total && local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, px, py);
+        float depth = in ? a.depth[(size_t)py * a.W + px] : 10000.0f;
+        on = depth < 10000.0f;
+        V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
+        if (on) ao_ray(a.cam, a.W, a.H, px, py, depth, a.normal[(size_t)py * a.W + px], smp, o, d);
+        ray_init(r, o, d, x.ao_radius * 0.01f, x.ao_radius);
     }
+    const bool traced = on;
     float tbest = r.tmax, bu = 0.f, bv = 0.f;
     uint32_t bpos = kNoHit, bgid = kNoHit;
     int cur = 0, sp = 0; // wave-uniform
@@ -276,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(FrameArgs a) {
                 bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0) && on;
                 bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1) && on;
                 uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
-                if (m0 != 0ull && m1 != 0ull) { // both: go where most rays that hit both enter first, stack the other
+                if (m0 != 0ull && m1 != 0ull) { // both: go where most rays enter first, stack the other
                     uint64_t f0 = __ballot(h0 && (!h1 || te0 <= te1)), f1 = __ballot(h1 && (!h0 || te1 < te0));
                     bool first0 = __popcll(f0) >= __popcll(f1);
                     if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = first0 ? c1 : c0;
@@ -294,12 +321,16 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(FrameArgs a) {
                                fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
                     float t, u, v;
                     if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
-                        float teff = fmaxf(t, te);
-                        uint32_t gid = __float_as_uint(vc.w);
-                        if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
+                        if (ANY) { bpos = pos; on = false; } // first accepted triangle: this lane is done
+                        else {
+                            float teff = fmaxf(t, te);
+                            uint32_t gid = __float_as_uint(vc.w);
+                            if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
+                        }
                     }
                 }
                 popit = true;
+                if (ANY && __ballot(on) == 0ull) break; // every ray of the packet is occluded
             }
             if (popit) {
                 if (sp == 0) break;
@@ -308,7 +339,19 @@ __global__ __launch_bounds__(kBlock) void k_primary_packet(FrameArgs a) {
             }
         }
     }
-    if (p < a.n_local) a.hits[p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+    if (MODE == PK_PRIMARY) {
+        if (slot < total) a.hits[slot] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+    } else if (MODE == PK_SHADOW) {
+        if (traced && bpos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
+            float4 c = a.contrib[slot];
+            a.contrib[slot] = make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w);
+            if (a.shadow_bits) { uint32_t i = slot / a.n_local; if (i < 16) atomicOr(&a.shadow_bits[slot - i * a.n_local], 1u << i); }
+        }
+        uint64_t tm = __ballot(traced);
+        if ((threadIdx.x & 63u) == 0 && tm) atomicAdd(&a.counters[kShadowSlots + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlotCount) * kSlotStride], (uint32_t)__popcll(tm));
+    } else {
+        if (slot < total) x.occl[slot] = (traced && bpos != kNoHit) ? 1 : 0;
+    }
 }
 
 // ---- ray-traced ambient occlusion (BASELINE config 5): XeGTAO's I/O contract on the tracer ------------------------
@@ -743,7 +786,7 @@ template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipeli
     else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);
 }
 void launch_primary(const FrameArgs &f, hipStream_t s) {
-    if (f.trace_kind[0] == 8) { k_primary_packet<<<blocks_for(f.n_local), kBlock, 0, s>>>(f); return; } // packet walk over the binary nodes
+    if (f.trace_kind[0] == 8) { k_packet<PK_PRIMARY><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); return; } // packet walk over the binary nodes
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
@@ -752,6 +795,7 @@ void launch_primary(const FrameArgs &f, hipStream_t s) {
 void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 void launch_shadow(const FrameArgs &f, hipStream_t s) {
     if (f.n_lights == 0) return;
+    if (f.trace_kind[1] == 8) { k_packet<PK_SHADOW><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); return; }
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
@@ -784,11 +828,17 @@ __global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_
     ao[pix] = a.depth[pix] < 10000.0f ? lut.v[k] : 255u;
 }
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
+    AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
+    if (f.trace_kind[1] == 8 || f.trace_kind[2] == 8) {
+        PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl;
+        k_packet<PK_AO><<<blocks_for(f.n_local * spp), kBlock, 0, s>>>(f, x);
+        k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
+        return;
+    }
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
-    launch_trace<MODE_AO>(a, f.trace_kind[1], f.pipelined, s);
-    AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
+    launch_trace<MODE_AO>(a, f.trace_kind[1] == 8 ? 4 : f.trace_kind[1], f.pipelined, s);
     k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
