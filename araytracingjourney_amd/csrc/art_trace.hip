@@ -829,7 +829,7 @@ __global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_
 }
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
     AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
-    if (f.trace_kind[1] == 8 || f.trace_kind[2] == 8) {
+    if (f.trace_kind[2] == 8) { // measured 2x slower than the per-ray walk (incoherent directions): off by default
         PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl;
         k_packet<PK_AO><<<blocks_for(f.n_local * spp), kBlock, 0, s>>>(f, x);
         k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
@@ -838,7 +838,7 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, ui
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
-    launch_trace<MODE_AO>(a, f.trace_kind[1] == 8 ? 4 : f.trace_kind[1], f.pipelined, s);
+    launch_trace<MODE_AO>(a, f.trace_kind[2], f.pipelined, s);
     k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
