@@ -68,6 +68,7 @@ struct ArtContext {
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
+    bool packet_wide = false; // ART_PACKET_WIDE=1: packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
     // device scene
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
@@ -238,6 +239,10 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
         for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[f][i]);
     if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
     c->W = cfg->width; c->H = cfg->height;
+    // one frame at a time is bound by the slowest wave: per-ray walks (binary for primary, 4-wide for shadow) have the shorter
+    // critical path; with several frames in flight the packet walks' lower instruction count wins (profiles/README.md)
+    if (c->F == 1) { c->kind_primary = 2; c->kind_shadow = 4; }
+    if (const char *pw = std::getenv("ART_PACKET_WIDE")) c->packet_wide = std::atoi(pw) != 0;
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
         if (ok(w[0]) || w[0] == '8') { c->kind_primary = w[0] - '0'; c->kind_shadow = (ok(w[1]) || w[1] == '8') ? w[1] - '0' : (w[0] == '8' ? 4 : c->kind_primary);
             c->kind_ao = (w[1] && (ok(w[2]) || w[2] == '8')) ? w[2] - '0' : (c->kind_shadow == 8 ? 4 : c->kind_shadow); } }
@@ -443,7 +448,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local;
-    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
+    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
     a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
@@ -477,9 +482,10 @@ int32_t art_trace(ArtContext *c) {
             (void)hipGraphDestroy(g);
             if (e != hipSuccess) { S.graph = nullptr; return hipfail(e, "hipGraphInstantiate"); }
         }
-        for (int i = 0; i < 4; i++) HIPC(hipEventRecord(ev[i], s));
+        static const bool lean = std::getenv("ART_LEAN_EVENTS") != nullptr; // experiment: fewer packets per frame
+        if (!lean) for (int i = 0; i < 4; i++) HIPC(hipEventRecord(ev[i], s));
         HIPC(hipGraphLaunch(S.graph, s));
-        HIPC(hipEventRecord(ev[4], s));
+        if (!lean) HIPC(hipEventRecord(ev[4], s));
         HIPC(hipEventRecord(S.done, s));
         S.ao_valid = false; S.presented = false;
         c->last = k; c->frame_no++; c->traced = true;

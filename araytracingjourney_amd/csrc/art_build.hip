@@ -241,6 +241,7 @@ static hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
         return BoxRef{nlo.data() + 3 * (size_t)ref, nhi.data() + 3 * (size_t)ref};
     };
     std::vector<DevNode4> wide;
+    std::vector<DevNodeW> widef;
     std::vector<int32_t> todo; // binary node behind each wide node, in wide-index order (BFS)
     wide.reserve(NI / 2 + 2);
     if (NI == 0) todo.push_back(~0); // single triangle: a root with one leaf child
@@ -261,6 +262,7 @@ static hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
             }
         }
         DevNode4 d; std::memset(&d, 0, sizeof(d));
+        DevNodeW dw; std::memset(&dw, 0, sizeof(dw));
         float org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int i = 0; i < nc; i++) { BoxRef b = box(cand[i]); for (int k = 0; k < 3; k++) { org[k] = std::fmin(org[k], b.lo[k]); top[k] = std::fmax(top[k], b.hi[k]); } }
         d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
@@ -275,7 +277,7 @@ static hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
         }
         uint32_t mask = 0;
         for (int i = 0; i < 4; i++) {
-            if (i >= nc) { d.child[i] = 0x7FFFFFFF; continue; }
+            if (i >= nc) { d.child[i] = 0x7FFFFFFF; dw.child[i] = 0x7FFFFFFF; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = -3.0e38f; } continue; }
             mask |= 1u << i;
             BoxRef b = box(cand[i]);
             for (int k = 0; k < 3; k++) {
@@ -287,15 +289,21 @@ static hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
                 d.q[k] |= (uint32_t)ql << (8 * i);
                 d.q[3 + k] |= (uint32_t)qh << (8 * i);
             }
+            for (int k = 0; k < 3; k++) { dw.box[i][k] = b.lo[k]; dw.box[i][3 + k] = b.hi[k]; }
             if (cand[i] < 0) d.child[i] = cand[i];
             else { d.child[i] = (int32_t)todo.size(); todo.push_back(cand[i]); }
+            dw.child[i] = d.child[i];
         }
         d.exps = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (mask << 24);
+        dw.valid = mask;
         wide.push_back(d);
+        widef.push_back(dw);
     }
     l.n_wide = (uint32_t)wide.size();
     HIPQ(hipMalloc(&l.wide, wide.size() * sizeof(DevNode4)));
     HIPQ(hipMemcpy(l.wide, wide.data(), wide.size() * sizeof(DevNode4), hipMemcpyHostToDevice));
+    HIPQ(hipMalloc(&l.widef, widef.size() * sizeof(DevNodeW)));
+    HIPQ(hipMemcpy(l.widef, widef.data(), widef.size() * sizeof(DevNodeW), hipMemcpyHostToDevice));
     return hipSuccess;
 }
 
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t T, const int32_t *
 }
 
 void lbvh_free(Lbvh &l) {
-    hipFree(l.wide); hipFree(l.qnodes); hipFree(l.shade_tris);
+    hipFree(l.wide); hipFree(l.widef); hipFree(l.qnodes); hipFree(l.shade_tris);
     hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
     hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim);
     l = Lbvh{};

@@ -40,6 +40,11 @@ static_assert(sizeof(DevNode4) == 64, "DevNode4 layout");
 //   Karras' children are gamma and gamma+1 (as node indices or leaf positions), so one word addresses both.
 struct alignas(16) DevNodeQ { float ox, oy, oz; uint32_t exps; uint32_t q[3]; uint32_t gamma; };
 static_assert(sizeof(DevNodeQ) == 32, "DevNodeQ layout");
+// 128-byte 4-wide node with full-precision child boxes, for the packet walk: a wave's iteration is bound by the latency of one
+// dependent (scalar) node fetch, so halving the number of iterations matters more than the bytes.
+//   box[c] = lo.xyz hi.xyz of child c (an absent child has lo = +3e38, hi = -3e38 and is masked by `valid`)
+struct alignas(16) DevNodeW { float box[4][6]; int32_t child[4]; uint32_t valid; uint32_t pad[3]; };
+static_assert(sizeof(DevNodeW) == 128, "DevNodeW layout");
 // 48-byte triangle in leaf order: v0.xyz|prim  v1.xyz|tri-in-prim  v2.xyz|gid
 struct alignas(16) DevTri { float4 v[3]; };
 // 144-byte shading record in leaf order: everything raytrace.rgen.glsl:107-114 fetches through PrimitiveInfo -> indices ->
@@ -69,6 +74,7 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevNode *nodes;         // [max(T-1,1)]
     uint32_t *tri_prim;     // [T] gid -> primitive
     DevNode4 *wide;         // [n_wide] collapsed + quantised traversal structure
+    DevNodeW *widef;        // [n_wide] the same topology with float boxes (packet walk)
     uint32_t n_wide;
     DevNodeQ *qnodes;       // [max(T-1,1)] quantised binary nodes
     DevShadeTri *shade_tris; // [T] leaf order
@@ -81,7 +87,8 @@ struct FrameArgs {
     uint32_t W, H;
     const uint32_t *tile_list; uint32_t n_tiles_owned; uint32_t tiles_x; // owned 32x32 tiles
     uint32_t n_local;          // n_tiles_owned * 1024
-    const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
+    const DevNode *nodes; const DevNode4 *wide; const DevNodeW *widef; const DevNodeQ *qnodes; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
+    bool packet_wide;          // packet walks use the 128-byte 4-wide nodes (else the binary nodes)
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
     int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised, 1 binary quantised
     const ArtLight *lights; uint32_t n_lights;

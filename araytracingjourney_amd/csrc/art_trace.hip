@@ -245,7 +245,7 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
 // scalar cache instead of a 64-lane gather, there is no per-lane stack and no divergence outside the triangle test; each lane
 // still tests its own ray against both child boxes with its own t_best.  A lane that would accept a triangle passes the slab
 // test of every enclosing box (monotone slab), so the packet finds exactly the per-ray answer, bit for bit.
-constexpr int kPacketStack = 96; // a shared stack of node references per wave; the radix tree is at most 95 levels deep
+constexpr int kPacketStack = 288; // shared stack of node references per wave: >= 3 pending siblings per level * 95 levels // a shared stack of node references per wave; the radix tree is at most 95 levels deep
 enum { PK_PRIMARY = 0, PK_SHADOW = 1, PK_AO = 2 };
 struct PacketArgs { const uint8_t *dummy; uint32_t spp; float ao_radius; uint8_t *occl; }; // AO extras
 
@@ -255,7 +255,7 @@ __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_
 // MODE PK_SHADOW:  slot = light * n_local + local pixel (the dense shadow-ray slots of k_shade: the same 8x8 block, rays towards
 //                  one light), any hit -> the slot's contribution keeps 0.05.  A lane leaves the packet at its first hit.
 // MODE PK_AO:      slot = local pixel * spp + sample (short rays around a few neighbouring points), any hit -> occl[].
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
     constexpr bool ANY = MODE != PK_PRIMARY;
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
@@ -295,7 +295,36 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
         for (;;) {
             cur = __builtin_amdgcn_readfirstlane(cur);
             bool popit = false;
-            if (cur >= 0) {
+            if (cur >= 0 && WIDE) {
+                const float4 *nq = reinterpret_cast<const float4 *>(a.widef + cur);
+                float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
+                int cr[4] = {__float_as_int(w6.x), __float_as_int(w6.y), __float_as_int(w6.z), __float_as_int(w6.w)};
+                uint32_t valid = __float_as_uint(w7.x);
+                float te[4]; bool h[4];
+                h[0] = slab(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, tbest, te[0]) && on && (valid & 1u);
+                h[1] = slab(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, tbest, te[1]) && on && (valid & 2u);
+                h[2] = slab(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, tbest, te[2]) && on && (valid & 4u);
+                h[3] = slab(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, tbest, te[3]) && on && (valid & 8u);
+                float tnear = fminf(fminf(h[0] ? te[0] : 3.0e38f, h[1] ? te[1] : 3.0e38f), fminf(h[2] ? te[2] : 3.0e38f, h[3] ? te[3] : 3.0e38f));
+                int best = -1, bestn = -1; // continue with the hit child that is the first one for most rays; stack the others
+                uint64_t m[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    m[i] = __ballot(h[i]);
+                    int cnt = m[i] ? (int)__popcll(__ballot(h[i] && te[i] == tnear)) : -1;
+                    if (cnt > bestn) { bestn = cnt; best = i; }
+                }
+                if (best < 0) popit = true;
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (m[i] != 0ull && i != best) {
+                            if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = cr[i];
+                            sp = min(sp + 1, kPacketStack);
+                        }
+                    cur = best == 0 ? cr[0] : (best == 1 ? cr[1] : (best == 2 ? cr[2] : cr[3]));
+                }
+            } else if (cur >= 0) {
                 const float4 *nq = reinterpret_cast<const float4 *>(a.nodes + cur);
                 float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
                 int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
@@ -786,7 +815,7 @@ template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipeli
     else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);
 }
 void launch_primary(const FrameArgs &f, hipStream_t s) {
-    if (f.trace_kind[0] == 8) { k_packet<PK_PRIMARY><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); return; } // packet walk over the binary nodes
+    if (f.trace_kind[0] == 8) { if (f.packet_wide) k_packet<PK_PRIMARY, true><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); else k_packet<PK_PRIMARY, false><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); return; } // packet walk over the binary nodes
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
@@ -795,7 +824,7 @@ void launch_primary(const FrameArgs &f, hipStream_t s) {
 void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 void launch_shadow(const FrameArgs &f, hipStream_t s) {
     if (f.n_lights == 0) return;
-    if (f.trace_kind[1] == 8) { k_packet<PK_SHADOW><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); return; }
+    if (f.trace_kind[1] == 8) { if (f.packet_wide) k_packet<PK_SHADOW, true><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); else k_packet<PK_SHADOW, false><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); return; }
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
@@ -831,7 +860,7 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, ui
     AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
     if (f.trace_kind[2] == 8) { // measured 2x slower than the per-ray walk (incoherent directions): off by default
         PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl;
-        k_packet<PK_AO><<<blocks_for(f.n_local * spp), kBlock, 0, s>>>(f, x);
+        if (f.packet_wide) k_packet<PK_AO, true><<<blocks_for(f.n_local * spp), kBlock, 0, s>>>(f, x); else k_packet<PK_AO, false><<<blocks_for(f.n_local * spp), kBlock, 0, s>>>(f, x);
         k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
         return;
     }

@@ -50,8 +50,9 @@ def test_ray_queries_match_oracle_bitwise(R, orc, get_scene, name, detail):
     r.close()
 
 
-def _frame_parity(R, orc, sc, w, h, n_lights):
-    r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True)
+def _frame_parity(R, orc, sc, w, h, n_lights, frames_in_flight=1):
+    # frames_in_flight 1: per-ray walks (latency preset); > 1: packet walks for primary and shadow rays (throughput preset)
+    r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True, frames_in_flight=frames_in_flight)
     r.render_frame()
     S, L, nl = oracle_for(orc, sc, n_lights)
     ref = S.render(oracle_camera(orc, sc, w, h), L, nl, w, h, threads=8, debug=True)
@@ -71,24 +72,27 @@ def _frame_parity(R, orc, sc, w, h, n_lights):
     return ref
 
 
-def test_cornell_frame_matches_oracle(R, orc, get_scene):
-    ref = _frame_parity(R, orc, get_scene("cornell"), 256, 256, None)
+@pytest.mark.parametrize("frames_in_flight", [1, 3])
+def test_cornell_frame_matches_oracle(R, orc, get_scene, frames_in_flight):
+    ref = _frame_parity(R, orc, get_scene("cornell"), 256, 256, None, frames_in_flight)
     assert ref["stats"]["shadow_rays"] > 1000
 
 
+@pytest.mark.parametrize("frames_in_flight", [1, 3])
 @pytest.mark.parametrize("n_lights", [1, 4])
-def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights):
+def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights, frames_in_flight):
     sc = get_scene("sponza_like", 0.12)
     if n_lights == 4:
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, scenes.sponza_lights(4))
-    ref = _frame_parity(R, orc, sc, 480, 270, None)
+    ref = _frame_parity(R, orc, sc, 480, 270, None, frames_in_flight)
     assert ref["stats"]["shadow_rays"] > 10000
 
 
 def test_config2_full_size_frame_matches_oracle(R, orc, get_scene):
     """BASELINE config 2 at its real size: 262 816 triangles, 1920x1080, one directional light"""
     import json, os
-    ref = _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1)
+    _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, frames_in_flight=1)
+    ref = _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, frames_in_flight=4)   # the packet walks, as bench.py runs them
     fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_sponza_like_1080p_1light.stats.json")))
     for k in ("primary_rays", "shadow_rays", "hit_pixels", "n_int_primary", "n_tri_primary", "n_int_shadow", "n_tri_shadow"):
         assert ref["stats"][k] == fx[k], k       # the committed visit counters bench.py prices the roofline with
@@ -112,7 +116,7 @@ def test_config4_bistro_class_scene(R, orc, get_scene):
     seen = np.bincount(idx.reshape(-1), minlength=2 * T - 1)
     assert seen[0] == 0 and np.all(seen[1:] == 1)                # every node and leaf has exactly one parent
     r.close()
-    _frame_parity(R, orc, sc, 960, 540, None)
+    _frame_parity(R, orc, sc, 960, 540, None, frames_in_flight=2)
 
 
 def test_ragged_extent_and_resize(R, orc, get_scene):
