@@ -117,6 +117,24 @@ void drop_graphs(ArtContext *c) {
         if (c->slot[k].graph) { (void)hipStreamSynchronize(c->stream_of(k)); (void)hipGraphExecDestroy(c->slot[k].graph); c->slot[k].graph = nullptr; } // never destroy a graph in flight
 }
 
+int32_t sync_all(ArtContext *c);
+// the wide collapse is host work on the finished binary tree: done lazily, the first time a walk that needs it is launched
+int32_t ensure_wide(ArtContext *c, bool needed) {
+    if (!needed || c->bvh.wide) return ART_OK;
+    int32_t r = sync_all(c); if (r) return r;
+    hipEvent_t e0, e1; float ms = 0;
+    HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, c->main_stream()));
+    hipError_t e = wide_build(c->bvh, c->T, c->main_stream());
+    if (e == hipSuccess) e = hipEventRecord(e1, c->main_stream());
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return hipfail(e, "wide_build");
+    c->stats.build_ms += ms;
+    return ART_OK;
+}
+
 int32_t sync_all(ArtContext *c) {
     for (uint32_t k = 0; k < c->F; k++) HIPC(hipStreamSynchronize(c->stream_of(k)));
     return ART_OK;
@@ -464,6 +482,7 @@ int32_t art_trace(ArtContext *c) {
     if (c->W == 0 || c->H == 0) return fail(ART_E_STATE, "art_trace: zero extent (art_resize)");
     int32_t r = use_device(c); if (r) return r;
     if (!c->frame_ready) { r = sync_all(c); if (r) return r; r = setup_frame(c); if (r) return r; }
+    r = ensure_wide(c, c->kind_primary == 4 || c->kind_shadow == 4 || c->packet_wide); if (r) return r;
     const uint32_t k = (uint32_t)(c->frame_no % c->F);
     FrameSlot &S = c->slot[k];
     hipStream_t s = c->stream_of(k);
@@ -521,6 +540,7 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     if (!c->traced || !c->frame_ready) return fail(ART_E_STATE, "art_trace_ao: call art_trace first (AO consumes that frame's depth + normal outputs)");
     if (spp == 0 || spp > 64 || !(radius > 0.0f)) return fail(ART_E_INVALID, "art_trace_ao: spp must be 1..64 and radius > 0");
     int32_t r = use_device(c); if (r) return r;
+    r = ensure_wide(c, c->kind_ao == 4 || (c->kind_ao == 8 && c->packet_wide)); if (r) return r;
     FrameSlot &S = c->slot[c->last];
     hipStream_t s = c->stream_of(c->last);
     if (S.d_occl.n < (size_t)c->n_local * spp || S.d_ao.n < (size_t)c->W * c->H) {
@@ -800,7 +820,7 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     std::vector<float4> h(n);
     std::vector<DevTri> tris(c->T);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && sync_all(c) != ART_OK) e = hipErrorUnknown;
+    if (e == hipSuccess && (sync_all(c) != ART_OK || ensure_wide(c, true) != ART_OK)) e = hipErrorUnknown;
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
     if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_primary == 8 ? 2 : c->kind_primary}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
@@ -829,7 +849,7 @@ int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit
     if (e != hipSuccess) { (void)hipFree(d_r); return hipfail(e, "hipMalloc"); }
     std::vector<uint32_t> h(n);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && sync_all(c) != ART_OK) e = hipErrorUnknown;
+    if (e == hipSuccess && (sync_all(c) != ART_OK || ensure_wide(c, true) != ART_OK)) e = hipErrorUnknown;
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
     if (e == hipSuccess) { launch_query_any(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_shadow == 8 ? 4 : c->kind_shadow}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }

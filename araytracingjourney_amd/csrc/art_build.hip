@@ -224,7 +224,8 @@ inline float half_area(const float *lo, const float *hi) {
 }
 } // namespace
 
-static hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
+hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
+    if (l.wide) return hipSuccess; // already built for this tree
     const uint32_t NI = T > 1 ? T - 1 : 0;
     std::vector<int32_t> child(NI ? (size_t)NI * 2 : 2);
     std::vector<float> nlo(NI ? (size_t)NI * 3 : 3), nhi(NI ? (size_t)NI * 3 : 3), llo((size_t)T * 3), lhi((size_t)T * 3);
@@ -399,7 +400,6 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
     };
     err = body();
     hipFree(triw); hipFree(tlo); hipFree(thi); hipFree(cb); hipFree(gid_in); hipFree(keys_in); hipFree(arrive); hipFree(parent_int); hipFree(parent_leaf); hipFree(tmp);
-    if (err == hipSuccess) err = wide_build(out, T, s);
     if (err != hipSuccess) lbvh_free(out);
     return err;
 }

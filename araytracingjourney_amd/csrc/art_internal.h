@@ -80,6 +80,8 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevShadeTri *shade_tris; // [T] leaf order
 };
 hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s); // allocates out.*, frees temporaries
+// the 4-wide collapses (DevNode4, DevNodeW): built on first use -- only the per-ray shadow/AO walks and ART_PACKET_WIDE need them
+hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s);
 void lbvh_free(Lbvh &l);
 
 struct FrameArgs {
