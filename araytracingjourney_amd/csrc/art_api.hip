@@ -68,6 +68,7 @@ struct ArtContext {
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
+    bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD / ART_SAH=0: keep the Karras tree)
     bool packet_wide = false; // ART_PACKET_WIDE=1: packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
     // device scene
@@ -261,6 +262,8 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     // critical path; with several frames in flight the packet walks' lower instruction count wins (profiles/README.md)
     if (c->F == 1) { c->kind_primary = 2; c->kind_shadow = 4; }
     if (const char *pw = std::getenv("ART_PACKET_WIDE")) c->packet_wide = std::atoi(pw) != 0;
+    c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
+    if (const char *sh = std::getenv("ART_SAH")) c->fast_trace = std::atoi(sh) != 0;
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
         if (ok(w[0]) || w[0] == '8') { c->kind_primary = w[0] - '0'; c->kind_shadow = (ok(w[1]) || w[1] == '8') ? w[1] - '0' : (w[0] == '8' ? 4 : c->kind_primary);
             c->kind_ao = (w[1] && (ok(w[2]) || w[2] == '8')) ? w[2] - '0' : (c->kind_shadow == 8 ? 4 : c->kind_shadow); } }
@@ -363,6 +366,10 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(hipEventRecord(e0, c->main_stream()));
     hipError_t e = lbvh_build(in, c->bvh, c->main_stream());
     if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "lbvh_build"); }
+    if (c->fast_trace) { // PREFER_FAST_TRACE (vk_model.rs:968): the traversal nodes get a SAH topology over the same leaves
+        e = sah_build(c->bvh, T, c->main_stream());
+        if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "sah_build"); }
+    }
     HIPC(hipEventRecord(e1, c->main_stream())); HIPC(hipEventSynchronize(e1));
     float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);

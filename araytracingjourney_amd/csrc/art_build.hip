@@ -231,9 +231,9 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
     std::vector<float> nlo(NI ? (size_t)NI * 3 : 3), nhi(NI ? (size_t)NI * 3 : 3), llo((size_t)T * 3), lhi((size_t)T * 3);
     HIPQ(hipStreamSynchronize(s));
     if (NI) {
-        HIPQ(hipMemcpy(child.data(), l.child, (size_t)NI * 8, hipMemcpyDeviceToHost));
-        HIPQ(hipMemcpy(nlo.data(), l.node_lo, (size_t)NI * 12, hipMemcpyDeviceToHost));
-        HIPQ(hipMemcpy(nhi.data(), l.node_hi, (size_t)NI * 12, hipMemcpyDeviceToHost));
+        HIPQ(hipMemcpy(child.data(), l.trav_child ? l.trav_child : l.child, (size_t)NI * 8, hipMemcpyDeviceToHost)); // collapse the tree the binary walks use
+        HIPQ(hipMemcpy(nlo.data(), l.trav_child ? l.trav_lo : l.node_lo, (size_t)NI * 12, hipMemcpyDeviceToHost));
+        HIPQ(hipMemcpy(nhi.data(), l.trav_child ? l.trav_hi : l.node_hi, (size_t)NI * 12, hipMemcpyDeviceToHost));
     }
     HIPQ(hipMemcpy(llo.data(), l.leaf_lo, (size_t)T * 12, hipMemcpyDeviceToHost));
     HIPQ(hipMemcpy(lhi.data(), l.leaf_hi, (size_t)T * 12, hipMemcpyDeviceToHost));
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t T, const int32_t *
 void lbvh_free(Lbvh &l) {
     hipFree(l.wide); hipFree(l.widef); hipFree(l.qnodes); hipFree(l.shade_tris);
     hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
-    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim);
+    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim); hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi);
     l = Lbvh{};
 }
 

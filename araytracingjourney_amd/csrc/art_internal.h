@@ -78,10 +78,14 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     uint32_t n_wide;
     DevNodeQ *qnodes;       // [max(T-1,1)] quantised binary nodes
     DevShadeTri *shade_tris; // [T] leaf order
+    int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
+    float *trav_lo, *trav_hi; // [(T-1)*3]
 };
 hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s); // allocates out.*, frees temporaries
 // the 4-wide collapses (DevNode4, DevNodeW): built on first use -- only the per-ray shadow/AO walks and ART_PACKET_WIDE need them
 hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s);
+// PREFER_FAST_TRACE: rebuilds l.nodes as a binned-SAH tree over the same leaves (host threads); frames are unchanged by construction
+hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s);
 void lbvh_free(Lbvh &l);
 
 struct FrameArgs {

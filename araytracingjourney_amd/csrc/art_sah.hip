@@ -1,0 +1,162 @@
+// Traversal-tree rebuild for PREFER_FAST_TRACE (vk_model.rs:968, vk_tlas_builder.rs:138): a binned surface-area-heuristic
+// binary tree over the SAME leaves (one triangle each, canonical LBVH leaf order) replaces the Karras topology in the
+// traversal nodes.  Results cannot change: accept() and t_eff are defined per triangle and every node box
+// here is an exact min/max union of leaf boxes, so any tree over the leaves returns the same hits -- only fewer node visits.
+// Host build (threads over subtrees); the canonical LBVH arrays (art_get_lbvh) stay as they are.
+#include "art_internal.h"
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <thread>
+#include <vector>
+
+namespace art {
+namespace {
+
+#define HIPS(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+constexpr int kBins = 32;
+
+struct Box3 {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    void grow(const float *l, const float *h) { for (int k = 0; k < 3; k++) { lo[k] = std::fmin(lo[k], l[k]); hi[k] = std::fmax(hi[k], h[k]); } }
+    void grow(const Box3 &b) { grow(b.lo, b.hi); }
+    double half_area() const {
+        double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    const float *llo, *lhi;     // leaf boxes [T*3]
+    std::vector<uint32_t> idx;  // leaf positions, partitioned in place
+    std::vector<int32_t> child; // [2*NI]
+    std::vector<float> nlo, nhi; // [NI*3]
+
+    // Subtree over idx[b,e) rooted at internal node k.  Pre-order layout: the left subtree (nl leaves -> nl-1 nodes) follows its
+    // parent, the right one starts at k + nl, so every node index is known before its subtree exists: subtrees build independently.
+    struct Task { uint32_t b, e, k; };
+
+    // choose the split of idx[b,e), partition, return the middle; also writes node k's box
+    uint32_t split(uint32_t b, uint32_t e, uint32_t k) {
+        Box3 nb, cb;
+        for (uint32_t i = b; i < e; i++) {
+            const float *l = llo + 3 * (size_t)idx[i], *h = lhi + 3 * (size_t)idx[i];
+            nb.grow(l, h);
+            float c[3] = {0.5f * l[0] + 0.5f * h[0], 0.5f * l[1] + 0.5f * h[1], 0.5f * l[2] + 0.5f * h[2]};
+            cb.grow(c, c);
+        }
+        for (int a = 0; a < 3; a++) { nlo[3 * (size_t)k + a] = nb.lo[a]; nhi[3 * (size_t)k + a] = nb.hi[a]; }
+        const uint32_t n = e - b;
+        if (n == 2) return b + 1;
+        int best_axis = -1, best_bin = 0;
+        double best_cost = INFINITY;
+        for (int a = 0; a < 3; a++) {
+            float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0.0f)) continue;
+            Box3 bins[kBins]; uint32_t cnt[kBins] = {};
+            float sc = (float)kBins / ext;
+            for (uint32_t i = b; i < e; i++) {
+                const float *l = llo + 3 * (size_t)idx[i], *h = lhi + 3 * (size_t)idx[i];
+                int bi = (int)(((0.5f * l[a] + 0.5f * h[a]) - cb.lo[a]) * sc);
+                bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+                bins[bi].grow(l, h); cnt[bi]++;
+            }
+            double right_area[kBins]; uint32_t right_cnt[kBins];
+            Box3 acc; uint32_t c = 0;
+            for (int i = kBins - 1; i > 0; i--) { acc.grow(bins[i]); c += cnt[i]; right_area[i] = acc.half_area(); right_cnt[i] = c; }
+            acc = Box3{}; c = 0;
+            for (int i = 0; i < kBins - 1; i++) {
+                acc.grow(bins[i]); c += cnt[i];
+                if (c == 0 || right_cnt[i + 1] == 0) continue;
+                double cost = acc.half_area() * c + right_area[i + 1] * right_cnt[i + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = i; }
+            }
+        }
+        if (best_axis < 0) return b + n / 2; // coincident centroids: any split is as good
+        float ext = cb.hi[best_axis] - cb.lo[best_axis], sc = (float)kBins / ext, c0 = cb.lo[best_axis];
+        const int a = best_axis;
+        auto mid = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t p) {
+            const float *l = llo + 3 * (size_t)p, *h = lhi + 3 * (size_t)p;
+            int bi = (int)(((0.5f * l[a] + 0.5f * h[a]) - c0) * sc);
+            bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+            return bi <= best_bin;
+        });
+        uint32_t m = (uint32_t)(mid - idx.begin());
+        if (m == b || m == e) m = b + n / 2;
+        return m;
+    }
+    // one node; pushes the child subtrees that still need nodes
+    template <class Push> void node(const Task &t, Push &&push) {
+        uint32_t m = split(t.b, t.e, t.k);
+        uint32_t nl = m - t.b, nr = t.e - m;
+        if (nl == 1) child[2 * (size_t)t.k] = ~(int32_t)idx[t.b];
+        else { child[2 * (size_t)t.k] = (int32_t)(t.k + 1); push(Task{t.b, m, t.k + 1}); }
+        if (nr == 1) child[2 * (size_t)t.k + 1] = ~(int32_t)idx[m];
+        else { child[2 * (size_t)t.k + 1] = (int32_t)(t.k + nl); push(Task{m, t.e, t.k + nl}); }
+    }
+    void subtree(Task root) {
+        std::vector<Task> st; st.push_back(root);
+        while (!st.empty()) { Task t = st.back(); st.pop_back(); node(t, [&](Task c) { st.push_back(c); }); }
+    }
+    void build(uint32_t T, unsigned threads) {
+        idx.resize(T); for (uint32_t i = 0; i < T; i++) idx[i] = i;
+        child.assign((size_t)(T - 1) * 2, 0); nlo.assign((size_t)(T - 1) * 3, 0.f); nhi.assign((size_t)(T - 1) * 3, 0.f);
+        // the top of the tree on this thread until there are enough independent subtrees, largest first
+        std::vector<Task> open; open.push_back(Task{0, T, 0});
+        const size_t want = threads > 1 ? (size_t)threads * 8 : 1;
+        while (threads > 1 && open.size() < want) {
+            size_t big = 0;
+            for (size_t i = 1; i < open.size(); i++) if (open[i].e - open[i].b > open[big].e - open[big].b) big = i;
+            if (open[big].e - open[big].b < 4096) break;
+            Task t = open[big]; open.erase(open.begin() + (long)big);
+            node(t, [&](Task c) { open.push_back(c); });
+        }
+        if (threads <= 1 || open.size() < 2) { for (const Task &t : open) subtree(t); return; }
+        std::sort(open.begin(), open.end(), [](const Task &x, const Task &y) { return x.e - x.b > y.e - y.b; });
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < threads; w++)
+            pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < open.size();) subtree(open[i]); });
+        for (auto &th : pool) th.join();
+    }
+};
+
+} // namespace
+
+hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s) {
+    if (T < 3) return hipSuccess; // one node at most: nothing to choose
+    const uint32_t NI = T - 1;
+    std::vector<float> llo((size_t)T * 3), lhi((size_t)T * 3);
+    HIPS(hipStreamSynchronize(s));
+    HIPS(hipMemcpy(llo.data(), l.leaf_lo, (size_t)T * 12, hipMemcpyDeviceToHost));
+    HIPS(hipMemcpy(lhi.data(), l.leaf_hi, (size_t)T * 12, hipMemcpyDeviceToHost));
+    Builder B; B.llo = llo.data(); B.lhi = lhi.data();
+    unsigned hw = std::thread::hardware_concurrency();
+    B.build(T, T < 20000 ? 1u : std::min(hw ? hw : 1u, 16u));
+    std::vector<DevNode> nodes(NI);
+    auto box = [&](int32_t ref, const float *&lo, const float *&hi) {
+        if (ref < 0) { lo = llo.data() + 3 * (size_t)(~ref); hi = lhi.data() + 3 * (size_t)(~ref); }
+        else { lo = B.nlo.data() + 3 * (size_t)ref; hi = B.nhi.data() + 3 * (size_t)ref; }
+    };
+    for (uint32_t n = 0; n < NI; n++) { // the layout k_emit_nodes writes
+        int32_t c0 = B.child[2 * (size_t)n], c1 = B.child[2 * (size_t)n + 1];
+        const float *l0, *h0, *l1, *h1; box(c0, l0, h0); box(c1, l1, h1);
+        DevNode &d = nodes[n];
+        d.q[0] = make_float4(l0[0], l0[1], l0[2], h0[0]);
+        d.q[1] = make_float4(h0[1], h0[2], l1[0], l1[1]);
+        d.q[2] = make_float4(l1[2], h1[0], h1[1], h1[2]);
+        int32_t cc[2] = {c0, c1}; float cf[2]; std::memcpy(cf, cc, 8);
+        d.q[3] = make_float4(cf[0], cf[1], 0.f, 0.f);
+    }
+    HIPS(hipMemcpy(l.nodes, nodes.data(), (size_t)NI * sizeof(DevNode), hipMemcpyHostToDevice));
+    if (!l.trav_child) {
+        HIPS(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPS(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPS(hipMalloc(&l.trav_hi, (size_t)NI * 12));
+    }
+    HIPS(hipMemcpy(l.trav_child, B.child.data(), (size_t)NI * 8, hipMemcpyHostToDevice));
+    HIPS(hipMemcpy(l.trav_lo, B.nlo.data(), (size_t)NI * 12, hipMemcpyHostToDevice));
+    HIPS(hipMemcpy(l.trav_hi, B.nhi.data(), (size_t)NI * 12, hipMemcpyHostToDevice));
+    return hipSuccess;
+}
+
+} // namespace art

@@ -251,6 +251,9 @@ struct PacketArgs { const uint8_t *dummy; uint32_t spp; float ao_radius; uint8_t
 
 __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float depth, float4 nm, uint32_t smp, V3 &o, V3 &d);
 
+// v_cmp straight into an SGPR pair (HIP's __ballot(int) goes through v_cndmask + v_cmp_ne)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // MODE PK_PRIMARY: slot = local pixel (a wave = one 8x8 block), closest hit -> hits[].
 // MODE PK_SHADOW:  slot = light * n_local + local pixel (the dense shadow-ray slots of k_shade: the same 8x8 block, rays towards
 //                  one light), any hit -> the slot's contribution keeps 0.05.  A lane leaves the packet at its first hit.
@@ -288,13 +291,12 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
         ray_init(r, o, d, x.ao_radius * 0.01f, x.ao_radius);
     }
     const bool traced = on;
-    float tbest = r.tmax, bu = 0.f, bv = 0.f;
+    float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f; // -1: below every tmin, no box test passes (lanes without a ray, occluded lanes)
     uint32_t bpos = kNoHit, bgid = kNoHit;
     int cur = 0, sp = 0; // wave-uniform
-    if (__ballot(on) != 0ull) {
+    if (ballot64(on) != 0ull) {
+        constexpr int kPop = (int)0x80000000; // "take the next node from the stack" (no leaf has position 2^31 - 1)
         for (;;) {
-            cur = __builtin_amdgcn_readfirstlane(cur);
-            bool popit = false;
             if (cur >= 0 && WIDE) {
                 const float4 *nq = reinterpret_cast<const float4 *>(a.widef + cur);
                 float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
@@ -310,11 +312,11 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
                 uint64_t m[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    m[i] = __ballot(h[i]);
-                    int cnt = m[i] ? (int)__popcll(__ballot(h[i] && te[i] == tnear)) : -1;
+                    m[i] = ballot64(h[i]);
+                    int cnt = m[i] ? (int)__popcll(ballot64(h[i] && te[i] == tnear)) : -1;
                     if (cnt > bestn) { bestn = cnt; best = i; }
                 }
-                if (best < 0) popit = true;
+                if (best < 0) cur = kPop;
                 else {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
@@ -329,28 +331,30 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
                 float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
                 int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
                 float te0, te1;
-                bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0) && on;
-                bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1) && on;
-                uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+                // lanes that are off carry tbest = -1: their slab tests fail by themselves, so each ballot is one v_cmp into an SGPR pair
+                uint64_t m0 = ballot64(slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0));
+                uint64_t m1 = ballot64(slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1));
                 if (m0 != 0ull && m1 != 0ull) { // both: go where most rays enter first, stack the other
-                    uint64_t f0 = __ballot(h0 && (!h1 || te0 <= te1)), f1 = __ballot(h1 && (!h0 || te1 < te0));
-                    bool first0 = __popcll(f0) >= __popcll(f1);
+                    uint64_t fl = ballot64(te0 <= te1), both = m0 & m1;
+                    uint64_t f0 = (m0 & ~m1) | (both & fl), f1 = (m1 & ~m0) | (both & ~fl);
+                    bool first0 = (int)__popcll(f0) >= (int)__popcll(f1);
                     if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = first0 ? c1 : c0;
                     sp = min(sp + 1, kPacketStack);
                     cur = first0 ? c0 : c1;
                 } else if (m0 != 0ull) cur = c0;
                 else if (m1 != 0ull) cur = c1;
-                else popit = true;
+                else cur = kPop;
             } else {
                 uint32_t pos = (uint32_t)~cur;
                 const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
                 float4 va = tq[0], vb = tq[1], vc = tq[2];
-                float te;
-                if (on && slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
-                               fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
-                    float t, u, v;
-                    if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
-                        if (ANY) { bpos = pos; on = false; } // first accepted triangle: this lane is done
+                float te, t, u, v;
+                // accept() = slab(AABB(tri)) AND Moeller-Trumbore: the conjunction is evaluated triangle test first -- the parent already
+                // tested this very box for the packet, so nearly every wave would pay for the slab, while few lanes survive the triangle test
+                if (on && moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
+                    if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+                             fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
+                        if (ANY) { bpos = pos; on = false; tbest = -1.0f; } // first accepted triangle: this lane is done
                         else {
                             float teff = fmaxf(t, te);
                             uint32_t gid = __float_as_uint(vc.w);
@@ -358,13 +362,13 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
                         }
                     }
                 }
-                popit = true;
-                if (ANY && __ballot(on) == 0ull) break; // every ray of the packet is occluded
+                cur = kPop;
+                if (ANY && ballot64(on) == 0ull) break; // every ray of the packet is occluded
             }
-            if (popit) {
+            if (cur == kPop) {
                 if (sp == 0) break;
                 sp--;
-                cur = stk[sp]; // same address in every lane: one broadcast LDS read (lane 0's write is ordered before it within the wave)
+                cur = __builtin_amdgcn_readfirstlane(stk[sp]); // same address in every lane: one broadcast LDS read (lane 0's write is ordered before it within the wave)
             }
         }
     }
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
             a.contrib[slot] = make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w);
             if (a.shadow_bits) { uint32_t i = slot / a.n_local; if (i < 16) atomicOr(&a.shadow_bits[slot - i * a.n_local], 1u << i); }
         }
-        uint64_t tm = __ballot(traced);
+        uint64_t tm = ballot64(traced);
         if ((threadIdx.x & 63u) == 0 && tm) atomicAdd(&a.counters[kShadowSlots + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlotCount) * kSlotStride], (uint32_t)__popcll(tm));
     } else {
         if (slot < total) x.occl[slot] = (traced && bpos != kNoHit) ? 1 : 0;

@@ -75,6 +75,7 @@ typedef struct ArtConfig {
                                   ring (renderer.rs:135, :300-318); art_trace then returns while up to N-1 older frames run */
 } ArtConfig;
 
+#define ART_FLAG_FAST_BUILD 2u /* traversal nodes keep the LBVH topology (PREFER_FAST_BUILD); default: binned-SAH rebuild = PREFER_FAST_TRACE, vk_model.rs:968 */
 #define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits) */
 
 typedef struct ArtStats {
