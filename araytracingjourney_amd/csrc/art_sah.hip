@@ -35,10 +35,13 @@ struct Builder {
 
     // Subtree over idx[b,e) rooted at internal node k.  Pre-order layout: the left subtree (nl leaves -> nl-1 nodes) follows its
     // parent, the right one starts at k + nl, so every node index is known before its subtree exists: subtrees build independently.
-    struct Task { uint32_t b, e, k; };
+    struct Task { uint32_t b, e, k, depth; };
+    // the walks' stacks are sized for the radix tree's 95 levels: past this depth the splits are medians, which bounds the
+    // tree at kSahDepth + ceil(log2 T) <= 80 levels
+    static constexpr uint32_t kSahDepth = 48;
 
     // choose the split of idx[b,e), partition, return the middle; also writes node k's box
-    uint32_t split(uint32_t b, uint32_t e, uint32_t k) {
+    uint32_t split(uint32_t b, uint32_t e, uint32_t k, uint32_t depth) {
         Box3 nb, cb;
         for (uint32_t i = b; i < e; i++) {
             const float *l = llo + 3 * (size_t)idx[i], *h = lhi + 3 * (size_t)idx[i];
@@ -49,6 +52,7 @@ struct Builder {
         for (int a = 0; a < 3; a++) { nlo[3 * (size_t)k + a] = nb.lo[a]; nhi[3 * (size_t)k + a] = nb.hi[a]; }
         const uint32_t n = e - b;
         if (n == 2) return b + 1;
+        if (depth >= kSahDepth) return b + n / 2;
         int best_axis = -1, best_bin = 0;
         double best_cost = INFINITY;
         for (int a = 0; a < 3; a++) {
@@ -88,12 +92,12 @@ struct Builder {
     }
     // one node; pushes the child subtrees that still need nodes
     template <class Push> void node(const Task &t, Push &&push) {
-        uint32_t m = split(t.b, t.e, t.k);
+        uint32_t m = split(t.b, t.e, t.k, t.depth);
         uint32_t nl = m - t.b, nr = t.e - m;
         if (nl == 1) child[2 * (size_t)t.k] = ~(int32_t)idx[t.b];
-        else { child[2 * (size_t)t.k] = (int32_t)(t.k + 1); push(Task{t.b, m, t.k + 1}); }
+        else { child[2 * (size_t)t.k] = (int32_t)(t.k + 1); push(Task{t.b, m, t.k + 1, t.depth + 1}); }
         if (nr == 1) child[2 * (size_t)t.k + 1] = ~(int32_t)idx[m];
-        else { child[2 * (size_t)t.k + 1] = (int32_t)(t.k + nl); push(Task{m, t.e, t.k + nl}); }
+        else { child[2 * (size_t)t.k + 1] = (int32_t)(t.k + nl); push(Task{m, t.e, t.k + nl, t.depth + 1}); }
     }
     void subtree(Task root) {
         std::vector<Task> st; st.push_back(root);
@@ -103,7 +107,7 @@ struct Builder {
         idx.resize(T); for (uint32_t i = 0; i < T; i++) idx[i] = i;
         child.assign((size_t)(T - 1) * 2, 0); nlo.assign((size_t)(T - 1) * 3, 0.f); nhi.assign((size_t)(T - 1) * 3, 0.f);
         // the top of the tree on this thread until there are enough independent subtrees, largest first
-        std::vector<Task> open; open.push_back(Task{0, T, 0});
+        std::vector<Task> open; open.push_back(Task{0, T, 0, 0});
         const size_t want = threads > 1 ? (size_t)threads * 8 : 1;
         while (threads > 1 && open.size() < want) {
             size_t big = 0;

@@ -254,6 +254,101 @@ __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_
 // v_cmp straight into an SGPR pair (HIP's __ballot(int) goes through v_cndmask + v_cmp_ne)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// The walk of one packet: `cur` (node reference) and the stack are wave-uniform.  OCT 0..7: every ray of the packet has the
+// direction signs (x: bit 0, y: bit 1, z: bit 2; set = negative) -- the entry plane of each axis is then known at compile time
+// (fma is monotone in the plane coordinate, so min(t0, t1) IS the chosen one, bit for bit) and a box costs 6 fma + 4 min/max
+// instead of 6 + 10.  OCT 8: mixed signs, the general slab.
+template <int OCT> __device__ __forceinline__ bool slab_oct(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float tlimit, float &tn) {
+    if (OCT >= 8) return slab(r, lx, ly, lz, hx, hy, hz, tlimit, tn);
+    float nx = fmaf((OCT & 1) ? hx : lx, r.inv.x, -r.ood.x), fx = fmaf((OCT & 1) ? lx : hx, r.inv.x, -r.ood.x);
+    float ny = fmaf((OCT & 2) ? hy : ly, r.inv.y, -r.ood.y), fy = fmaf((OCT & 2) ? ly : hy, r.inv.y, -r.ood.y);
+    float nz = fmaf((OCT & 4) ? hz : lz, r.inv.z, -r.ood.z), fz = fmaf((OCT & 4) ? lz : hz, r.inv.z, -r.ood.z);
+    tn = fmaxf(fmaxf(nx, ny), nz);
+    float tf = fminf(fminf(fx, fy), fz);
+    return fmaxf(tn, r.tmin) <= fminf(tf, tlimit);
+}
+
+template <bool ANY, bool WIDE, int OCT>
+__device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid) {
+    int cur = 0, sp = 0; // wave-uniform
+    constexpr int kPop = (int)0x80000000; // "take the next node from the stack" (no leaf has position 2^31 - 1)
+    for (;;) {
+        if (cur >= 0 && WIDE) {
+            const float4 *nq = reinterpret_cast<const float4 *>(a.widef + cur);
+            float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
+            int cr[4] = {__float_as_int(w6.x), __float_as_int(w6.y), __float_as_int(w6.z), __float_as_int(w6.w)};
+            uint32_t valid = __float_as_uint(w7.x);
+            float te[4]; bool h[4];
+            h[0] = slab(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, tbest, te[0]) && on && (valid & 1u);
+            h[1] = slab(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, tbest, te[1]) && on && (valid & 2u);
+            h[2] = slab(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, tbest, te[2]) && on && (valid & 4u);
+            h[3] = slab(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, tbest, te[3]) && on && (valid & 8u);
+            float tnear = fminf(fminf(h[0] ? te[0] : 3.0e38f, h[1] ? te[1] : 3.0e38f), fminf(h[2] ? te[2] : 3.0e38f, h[3] ? te[3] : 3.0e38f));
+            int best = -1, bestn = -1; // continue with the hit child that is the first one for most rays; stack the others
+            uint64_t m[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                m[i] = ballot64(h[i]);
+                int cnt = m[i] ? (int)__popcll(ballot64(h[i] && te[i] == tnear)) : -1;
+                if (cnt > bestn) { bestn = cnt; best = i; }
+            }
+            if (best < 0) cur = kPop;
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (m[i] != 0ull && i != best) {
+                        if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = cr[i];
+                        sp = min(sp + 1, kPacketStack);
+                    }
+                cur = best == 0 ? cr[0] : (best == 1 ? cr[1] : (best == 2 ? cr[2] : cr[3]));
+            }
+        } else if (cur >= 0) {
+            const float4 *nq = reinterpret_cast<const float4 *>(a.nodes + cur);
+            float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+            int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            float te0, te1;
+            // lanes that are off carry tbest = -1: their slab tests fail by themselves, so each ballot is one v_cmp into an SGPR pair
+            uint64_t m0 = ballot64(slab_oct<OCT>(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0));
+            uint64_t m1 = ballot64(slab_oct<OCT>(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1));
+            if (m0 != 0ull && m1 != 0ull) { // both: go where most rays enter first, stack the other
+                uint64_t fl = ballot64(te0 <= te1), both = m0 & m1;
+                uint64_t f0 = (m0 & ~m1) | (both & fl), f1 = (m1 & ~m0) | (both & ~fl);
+                bool first0 = (int)__popcll(f0) >= (int)__popcll(f1);
+                if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = first0 ? c1 : c0;
+                sp = min(sp + 1, kPacketStack);
+                cur = first0 ? c0 : c1;
+            } else if (m0 != 0ull) cur = c0;
+            else if (m1 != 0ull) cur = c1;
+            else cur = kPop;
+        } else {
+            uint32_t pos = (uint32_t)~cur;
+            const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
+            float4 va = tq[0], vb = tq[1], vc = tq[2];
+            float te, t, u, v;
+            // accept() = slab(AABB(tri)) AND Moeller-Trumbore: the conjunction is evaluated triangle test first -- the parent already
+            // tested this very box for the packet, so nearly every wave would pay for the slab, while few lanes survive the triangle test
+            if (on && moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
+                if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+                         fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
+                    if (ANY) { bpos = pos; on = false; tbest = -1.0f; } // first accepted triangle: this lane is done
+                    else {
+                        float teff = fmaxf(t, te);
+                        uint32_t gid = __float_as_uint(vc.w);
+                        if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
+                    }
+                }
+            }
+            cur = kPop;
+            if (ANY && ballot64(on) == 0ull) break; // every ray of the packet is occluded
+        }
+        if (cur == kPop) {
+            if (sp == 0) break;
+            sp--;
+            cur = __builtin_amdgcn_readfirstlane(stk[sp]); // same address in every lane: one broadcast LDS read (lane 0's write is ordered before it within the wave)
+        }
+    }
+}
+
 // MODE PK_PRIMARY: slot = local pixel (a wave = one 8x8 block), closest hit -> hits[].
 // MODE PK_SHADOW:  slot = light * n_local + local pixel (the dense shadow-ray slots of k_shade: the same 8x8 block, rays towards
 //                  one light), any hit -> the slot's contribution keeps 0.05.  A lane leaves the packet at its first hit.
@@ -293,83 +388,22 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
     const bool traced = on;
     float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f; // -1: below every tmin, no box test passes (lanes without a ray, occluded lanes)
     uint32_t bpos = kNoHit, bgid = kNoHit;
-    int cur = 0, sp = 0; // wave-uniform
-    if (ballot64(on) != 0ull) {
-        constexpr int kPop = (int)0x80000000; // "take the next node from the stack" (no leaf has position 2^31 - 1)
-        for (;;) {
-            if (cur >= 0 && WIDE) {
-                const float4 *nq = reinterpret_cast<const float4 *>(a.widef + cur);
-                float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
-                int cr[4] = {__float_as_int(w6.x), __float_as_int(w6.y), __float_as_int(w6.z), __float_as_int(w6.w)};
-                uint32_t valid = __float_as_uint(w7.x);
-                float te[4]; bool h[4];
-                h[0] = slab(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, tbest, te[0]) && on && (valid & 1u);
-                h[1] = slab(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, tbest, te[1]) && on && (valid & 2u);
-                h[2] = slab(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, tbest, te[2]) && on && (valid & 4u);
-                h[3] = slab(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, tbest, te[3]) && on && (valid & 8u);
-                float tnear = fminf(fminf(h[0] ? te[0] : 3.0e38f, h[1] ? te[1] : 3.0e38f), fminf(h[2] ? te[2] : 3.0e38f, h[3] ? te[3] : 3.0e38f));
-                int best = -1, bestn = -1; // continue with the hit child that is the first one for most rays; stack the others
-                uint64_t m[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    m[i] = ballot64(h[i]);
-                    int cnt = m[i] ? (int)__popcll(ballot64(h[i] && te[i] == tnear)) : -1;
-                    if (cnt > bestn) { bestn = cnt; best = i; }
-                }
-                if (best < 0) cur = kPop;
-                else {
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (m[i] != 0ull && i != best) {
-                            if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = cr[i];
-                            sp = min(sp + 1, kPacketStack);
-                        }
-                    cur = best == 0 ? cr[0] : (best == 1 ? cr[1] : (best == 2 ? cr[2] : cr[3]));
-                }
-            } else if (cur >= 0) {
-                const float4 *nq = reinterpret_cast<const float4 *>(a.nodes + cur);
-                float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
-                int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-                float te0, te1;
-                // lanes that are off carry tbest = -1: their slab tests fail by themselves, so each ballot is one v_cmp into an SGPR pair
-                uint64_t m0 = ballot64(slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tbest, te0));
-                uint64_t m1 = ballot64(slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tbest, te1));
-                if (m0 != 0ull && m1 != 0ull) { // both: go where most rays enter first, stack the other
-                    uint64_t fl = ballot64(te0 <= te1), both = m0 & m1;
-                    uint64_t f0 = (m0 & ~m1) | (both & fl), f1 = (m1 & ~m0) | (both & ~fl);
-                    bool first0 = (int)__popcll(f0) >= (int)__popcll(f1);
-                    if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = first0 ? c1 : c0;
-                    sp = min(sp + 1, kPacketStack);
-                    cur = first0 ? c0 : c1;
-                } else if (m0 != 0ull) cur = c0;
-                else if (m1 != 0ull) cur = c1;
-                else cur = kPop;
-            } else {
-                uint32_t pos = (uint32_t)~cur;
-                const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
-                float4 va = tq[0], vb = tq[1], vc = tq[2];
-                float te, t, u, v;
-                // accept() = slab(AABB(tri)) AND Moeller-Trumbore: the conjunction is evaluated triangle test first -- the parent already
-                // tested this very box for the packet, so nearly every wave would pay for the slab, while few lanes survive the triangle test
-                if (on && moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
-                    if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
-                             fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
-                        if (ANY) { bpos = pos; on = false; tbest = -1.0f; } // first accepted triangle: this lane is done
-                        else {
-                            float teff = fmaxf(t, te);
-                            uint32_t gid = __float_as_uint(vc.w);
-                            if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
-                        }
-                    }
-                }
-                cur = kPop;
-                if (ANY && ballot64(on) == 0ull) break; // every ray of the packet is occluded
-            }
-            if (cur == kPop) {
-                if (sp == 0) break;
-                sp--;
-                cur = __builtin_amdgcn_readfirstlane(stk[sp]); // same address in every lane: one broadcast LDS read (lane 0's write is ordered before it within the wave)
-            }
+    uint64_t act = ballot64(on);
+    if (act != 0ull) {
+        // direction signs per axis: all set, none set, or mixed over the packet's rays
+        uint64_t nx = ballot64(on && r.inv.x < 0.0f), ny = ballot64(on && r.inv.y < 0.0f), nz = ballot64(on && r.inv.z < 0.0f);
+        bool uniform = (nx == 0ull || nx == act) && (ny == 0ull || ny == act) && (nz == 0ull || nz == act);
+        int oct = !uniform || WIDE ? 8 : (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
+        switch (oct) {
+        case 0: packet_walk<ANY, WIDE, WIDE ? 8 : 0>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        case 1: packet_walk<ANY, WIDE, WIDE ? 8 : 1>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        case 2: packet_walk<ANY, WIDE, WIDE ? 8 : 2>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        case 3: packet_walk<ANY, WIDE, WIDE ? 8 : 3>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        case 4: packet_walk<ANY, WIDE, WIDE ? 8 : 4>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        case 5: packet_walk<ANY, WIDE, WIDE ? 8 : 5>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        case 6: packet_walk<ANY, WIDE, WIDE ? 8 : 6>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        case 7: packet_walk<ANY, WIDE, WIDE ? 8 : 7>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+        default: packet_walk<ANY, WIDE, 8>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
         }
     }
     if (MODE == PK_PRIMARY) {
