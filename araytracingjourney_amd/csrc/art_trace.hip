@@ -87,6 +87,21 @@ __device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v
     return true;
 }
 
+// the same arithmetic without the early exits: in a packet some lane nearly always survives each test, so the wave pays for
+// every stage anyway and the exits only add exec-mask bookkeeping (det == 0 lanes compute inf/NaN that the flag discards)
+__device__ __forceinline__ bool moller_trumbore_flat(const Ray &r, V3 v0, V3 v1, V3 v2, float &t, float &u, float &v) {
+    V3 e1 = v1 - v0, e2 = v2 - v0;
+    V3 p = cross3(r.d, e2);
+    float det = dot3(e1, p);
+    float inv = 1.0f / det;
+    V3 tv = r.o - v0;
+    u = dot3(tv, p) * inv;
+    V3 q = cross3(tv, e1);
+    v = dot3(r.d, q) * inv;
+    t = dot3(e2, q) * inv;
+    return (det != 0.0f) & (u >= -ART_BARY_EPS) & (u <= 1.0f + ART_BARY_EPS) & (v >= -ART_BARY_EPS) & (u + v <= 1.0f + ART_BARY_EPS) & (t > r.tmin) & (t < r.tmax);
+}
+
 constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], conflict-free); deeper entries spill to scratch
 constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (63 key bits + 32 index bits)
 constexpr int kBlock = 256;
@@ -324,19 +339,19 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             uint32_t pos = (uint32_t)~cur;
             const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
             float4 va = tq[0], vb = tq[1], vc = tq[2];
-            float te, t, u, v;
+            float te = 0.f, t = 0.f, u = 0.f, v = 0.f;
             // accept() = slab(AABB(tri)) AND Moeller-Trumbore: the conjunction is evaluated triangle test first -- the parent already
             // tested this very box for the packet, so nearly every wave would pay for the slab, while few lanes survive the triangle test
-            if (on && moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
-                if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
-                         fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
-                    if (ANY) { bpos = pos; on = false; tbest = -1.0f; } // first accepted triangle: this lane is done
-                    else {
-                        float teff = fmaxf(t, te);
-                        uint32_t gid = __float_as_uint(vc.w);
-                        if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
-                    }
-                }
+            bool acc = moller_trumbore_flat(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v) && on;
+            if (acc) acc = slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+                                fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te);
+            // the ray state changes through selects, outside the divergent branches (no register copies around them)
+            if (ANY) { bpos = acc ? pos : bpos; on = on && !acc; tbest = acc ? -1.0f : tbest; } // first accepted triangle: this lane is done
+            else {
+                float teff = fmaxf(t, te);
+                uint32_t gid = __float_as_uint(vc.w);
+                bool better = acc && (teff < tbest || (teff == tbest && gid < bgid));
+                tbest = better ? teff : tbest; bu = better ? u : bu; bv = better ? v : bv; bpos = better ? pos : bpos; bgid = better ? gid : bgid;
             }
             cur = kPop;
             if (ANY && ballot64(on) == 0ull) break; // every ray of the packet is occluded
