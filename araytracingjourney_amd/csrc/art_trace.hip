@@ -166,11 +166,12 @@ template <bool ANY, int OVF> struct TravBase {
         uint32_t pos = (uint32_t)~cur;
         const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
         float4 va = tq[0], vb = tq[1], vc = tq[2];
-        float te;
-        if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
-                 fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
-            float t, u, v;
-            if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
+        float te, t, u, v;
+        // triangle test first: the lane is here because this very box passed in the parent, so the slab (needed for t_eff and for
+        // the conjunction) would nearly always run; after the triangle test it runs for the few hits only.  Same accept().
+        if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
+            if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+                     fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
                 if (ANY) { bpos = pos; tbest = t; return true; }
                 float teff = fmaxf(t, te);
                 uint32_t gid = __float_as_uint(vc.w);
@@ -268,6 +269,13 @@ __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_
 
 // v_cmp straight into an SGPR pair (HIP's __ballot(int) goes through v_cndmask + v_cmp_ne)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// streaming records (hits, shadow rays, contributions, frame outputs) are written once and read once: non-temporal accesses keep
+// them from pushing the BVH out of the 4 MB L2s that the walks of all the frames in flight live in
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_nt(float4 *p, float4 v) { __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v *>(p)); }
+__device__ __forceinline__ void st_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ float4 ld_nt(const float4 *p) { f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 
 // The walk of one packet: `cur` (node reference) and the stack are wave-uniform.  OCT 0..7: every ray of the packet has the
 // direction signs (x: bit 0, y: bit 1, z: bit 2; set = negative) -- the entry plane of each axis is then known at compile time
@@ -387,9 +395,9 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
         V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
         ray_init(r, org, dir, 0.001f, 10000.0f);
     } else if (MODE == PK_SHADOW) {
-        float4 r0 = slot < total ? a.shadow_rays[2 * (size_t)slot] : make_float4(0.f, 0.f, 0.f, -1.f);
+        float4 r0 = slot < total ? ld_nt(&a.shadow_rays[2 * (size_t)slot]) : make_float4(0.f, 0.f, 0.f, -1.f);
         on = r0.w > 0.0f;
-        float4 r1 = on ? a.shadow_rays[2 * (size_t)slot + 1] : make_float4(0.f, 0.f, 1.f, 0.f);
+        float4 r1 = on ? ld_nt(&a.shadow_rays[2 * (size_t)slot + 1]) : make_float4(0.f, 0.f, 1.f, 0.f);
         ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), 0.01f, on ? r0.w : 1.0f);
     } else {
         uint32_t p = slot / x.spp, smp = slot - p * x.spp, px = 0, py = 0;
@@ -422,11 +430,11 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
         }
     }
     if (MODE == PK_PRIMARY) {
-        if (slot < total) a.hits[slot] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+        if (slot < total) st_nt(&a.hits[slot], bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit)));
     } else if (MODE == PK_SHADOW) {
         if (traced && bpos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
-            float4 c = a.contrib[slot];
-            a.contrib[slot] = make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w);
+            float4 c = ld_nt(&a.contrib[slot]);
+            st_nt(&a.contrib[slot], make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w));
             if (a.shadow_bits) { uint32_t i = slot / a.n_local; if (i < 16) atomicOr(&a.shadow_bits[slot - i * a.n_local], 1u << i); }
         }
         uint64_t tm = ballot64(traced);
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
     uint32_t x, y;
     bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
     size_t pix = (size_t)y * a.W + x;
-    float4 h = a.hits[p];
+    float4 h = ld_nt(&a.hits[p]);
     uint32_t pos = in ? __float_as_uint(h.w) : kNoHit;
     float out_depth = 10000.0f;
     V3 out_normal = mk(0.5f, 0.5f, 0.5f);
@@ -740,8 +748,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
     if (pos == kNoHit) {
         for (uint32_t i = 0; i < a.n_lights; i++) {
             size_t slot = (size_t)i * a.n_local + p;
-            a.contrib[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-            a.shadow_rays[2 * slot] = make_float4(0.f, 0.f, 0.f, -1.0f); // no shadow ray in this slot
+            st_nt(&a.contrib[slot], make_float4(0.f, 0.f, 0.f, 0.f));
+            st_nt(&a.shadow_rays[2 * slot], make_float4(0.f, 0.f, 0.f, -1.0f)); // no shadow ray in this slot
         }
     } else {
         // one dependent fetch: the shading record holds what get_indices + three vertex reads would return (rgen:107-114)
@@ -789,12 +797,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
             V3 rad = get_light_radiance(l, world_pos, L);
             V3 c = (rho_s + rho_d) * rad;
             size_t slot = (size_t)i * a.n_local + p;
-            a.contrib[slot] = make_float4(c.x, c.y, c.z, NdotL);
+            st_nt(&a.contrib[slot], make_float4(c.x, c.y, c.z, NdotL));
             if (l.casts_shadows && nc_NdotL > 0.0f) { // raytrace.rgen.glsl:165: origin world_pos, dir L, tmax length(nn_L)
-                a.shadow_rays[2 * slot] = make_float4(world_pos.x, world_pos.y, world_pos.z, len3(nn_L));
-                a.shadow_rays[2 * slot + 1] = make_float4(L.x, L.y, L.z, 0.f);
+                st_nt(&a.shadow_rays[2 * slot], make_float4(world_pos.x, world_pos.y, world_pos.z, len3(nn_L)));
+                st_nt(&a.shadow_rays[2 * slot + 1], make_float4(L.x, L.y, L.z, 0.f));
                 if (i < 16) sbits |= 1u << (16 + i);
-            } else a.shadow_rays[2 * slot] = make_float4(0.f, 0.f, 0.f, -1.0f);
+            } else st_nt(&a.shadow_rays[2 * slot], make_float4(0.f, 0.f, 0.f, -1.0f));
         }
         V3 vp = mat4_mul(a.cam.view, world_pos.x, world_pos.y, world_pos.z, 1.0f);
         out_depth = -vp.z;
@@ -805,8 +813,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
         out_normal = mk(on.x * 0.5f + 0.5f, on.y * 0.5f + 0.5f, on.z * 0.5f + 0.5f);
     }
     if (in) {
-        a.depth[pix] = out_depth;
-        a.normal[pix] = make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f);
+        st_nt(&a.depth[pix], out_depth);
+        st_nt(&a.normal[pix], make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f));
     }
     if (a.shadow_bits) a.shadow_bits[p] = sbits;
     uint64_t hitmask = __ballot(pos != kNoHit); // hit-pixel count: one atomic per wave, off the critical path
@@ -822,15 +830,15 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
     float rx = 0.f, ry = 0.f, rz = 0.f;
     if (in)
         for (uint32_t i = 0; i < a.n_lights; i++) {
-            float4 c = a.contrib[(size_t)i * a.n_local + p];
+            float4 c = ld_nt(&a.contrib[(size_t)i * a.n_local + p]);
             rx += c.x * c.w; ry += c.y * c.w; rz += c.z * c.w;
         }
     float4 o = make_float4(rx, ry, rz, 1.0f);
-    if (in) a.color[(size_t)y * a.W + x] = o;
+    if (in) st_nt(&a.color[(size_t)y * a.W + x], o);
     if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
         uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
         uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
-        a.color_tiles[(size_t)(p >> 10) * kTilePixels + ly * kTile + lx] = o;
+        st_nt(&a.color_tiles[(size_t)(p >> 10) * kTilePixels + ly * kTile + lx], o);
     }
 }
 
