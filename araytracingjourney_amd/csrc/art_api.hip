@@ -81,6 +81,7 @@ struct ArtContext {
     // frame
     std::vector<uint32_t> tile_list; uint32_t tiles_x = 0, tiles_y = 0, padded_tiles = 0, n_local = 0;
     DevBuf<uint32_t> d_tile_list;
+    DevBuf<uint32_t> d_block_order; // launch block -> 256-pixel block of the frame: one L2 (XCD) per screen region (setup_frame)
     static constexpr int kRing = 128;          // per-frame stage events kept for art_collect_timings
     hipEvent_t ev[kRing][5] = {};
     uint64_t frame_no = 0, collected_upto = 0;
@@ -160,6 +161,35 @@ int32_t setup_frame(ArtContext *c) {
     size_t nl = c->lights.size() ? c->lights.size() : 1;
     HIPC(c->d_tile_list.ensure(c->tile_list.size()));
     if (!c->tile_list.empty()) HIPC(hipMemcpy(c->d_tile_list.p, c->tile_list.data(), c->tile_list.size() * 4, hipMemcpyHostToDevice));
+    {   // Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.  Group the owned tiles into macro-blocks of
+        // kMacro x kMacro tiles, deal the macro-blocks round-robin to the XCDs (balance: every XCD gets pieces from all over the
+        // frame) and order the launch so that XCD x works through ITS macro-blocks: its L2 then holds the BVH of a few screen
+        // regions instead of the whole view, in every kernel of the frame and in every frame in flight.  A permutation of the
+        // blocks whatever the hardware's dispatch order is; only the locality depends on it.  ART_MACRO=0: identity.
+        uint32_t macro = 2;
+        if (const char *e = std::getenv("ART_MACRO")) macro = (uint32_t)std::atoi(e);
+        const uint32_t nb = c->n_local / 256;
+        std::vector<uint32_t> order(nb);
+        for (uint32_t b = 0; b < nb; b++) order[b] = b;
+        if (macro > 0 && nb >= 64) {
+            const uint32_t mx = (c->tiles_x + macro - 1) / macro;
+            std::vector<std::vector<uint32_t>> queue(8);
+            std::vector<std::pair<uint32_t, uint32_t>> keyed; // (macro-block id, block)
+            for (uint32_t b = 0; b < nb; b++) { uint32_t t = c->tile_list[b >> 2]; keyed.push_back({(t / c->tiles_x / macro) * mx + (t % c->tiles_x) / macro, b}); }
+            std::stable_sort(keyed.begin(), keyed.end());
+            uint32_t rank = 0;
+            for (size_t i = 0; i < keyed.size(); i++) { if (i && keyed[i].first != keyed[i - 1].first) rank++; queue[rank & 7u].push_back(keyed[i].second); }
+            // launch position b runs on XCD b % 8: take that XCD's next block; once a queue is empty its positions take what is left
+            size_t head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t b = 0; b < nb; b++) {
+                uint32_t q = b & 7u;
+                for (uint32_t tries = 0; tries < 8 && head[q] >= queue[q].size(); tries++) q = (q + 1) & 7u;
+                order[b] = queue[q][head[q]++];
+            }
+        }
+        HIPC(c->d_block_order.ensure(nb ? nb : 1));
+        if (nb) HIPC(hipMemcpy(c->d_block_order.p, order.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+    }
     for (uint32_t k = 0; k < c->F; k++) {
         FrameSlot &S = c->slot[k];
         HIPC(S.d_counters.ensure(kCounterWords));
@@ -472,7 +502,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     FrameArgs a{};
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
-    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local;
+    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p;
     a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
     a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;

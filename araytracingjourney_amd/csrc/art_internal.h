@@ -93,6 +93,7 @@ struct FrameArgs {
     uint32_t W, H;
     const uint32_t *tile_list; uint32_t n_tiles_owned; uint32_t tiles_x; // owned 32x32 tiles
     uint32_t n_local;          // n_tiles_owned * 1024
+    const uint32_t *block_order; // [n_local / 256] launch block -> 256-pixel block (XCD-aware order, art_api.hip setup_frame)
     const DevNode *nodes; const DevNode4 *wide; const DevNodeW *widef; const DevNodeQ *qnodes; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
     bool packet_wide;          // packet walks use the 128-byte 4-wide nodes (else the binary nodes)
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)

@@ -382,7 +382,12 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
     const uint32_t total = MODE == PK_PRIMARY ? a.n_local : (MODE == PK_SHADOW ? a.n_local * a.n_lights : a.n_local * x.spp);
+    // primary / shadow: the launch order of the 256-pixel blocks is XCD-aware (a.block_order); shadow slots are [light][pixel]
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (MODE != PK_AO) {
+        const uint32_t per_light = a.n_local / kBlock, light = blockIdx.x / per_light;
+        slot = (light * per_light + a.block_order[blockIdx.x - light * per_light]) * kBlock + threadIdx.x;
+    }
     bool on = false;
     Ray r;
     if (MODE == PK_PRIMARY) {
@@ -735,8 +740,8 @@ __device__ float4 sample_tex(const uint32_t *__restrict__ pool, const DevPrim &P
 
 // raytrace.rgen.glsl:103-199 without the shadow traceRayEXT: emits one shadow ray per (pixel, light) that needs it
 __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
-    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= a.n_local) return;
+    if (blockIdx.x * kBlock >= a.n_local) return;
+    uint32_t p = a.block_order[blockIdx.x] * kBlock + threadIdx.x;
     uint32_t x, y;
     bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
     size_t pix = (size_t)y * a.W + x;
@@ -823,8 +828,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
 
 // rho += (rho_s + rho_d) * radiance * shadow_attenuation * NdotL (raytrace.rgen.glsl:185), lights in order
 __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
-    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= a.n_local) return;
+    if (blockIdx.x * kBlock >= a.n_local) return;
+    uint32_t p = a.block_order[blockIdx.x] * kBlock + threadIdx.x;
     uint32_t x, y;
     bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
     float rx = 0.f, ry = 0.f, rz = 0.f;
