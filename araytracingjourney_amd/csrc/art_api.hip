@@ -192,7 +192,7 @@ int32_t setup_frame(ArtContext *c) {
     }
     for (uint32_t k = 0; k < c->F; k++) {
         FrameSlot &S = c->slot[k];
-        HIPC(S.d_counters.ensure(kCounterWords));
+        HIPC(S.d_counters.ensure(kCounterWords)); HIPC(hipMemset(S.d_counters.p, 0, kCounterWords * 4)); // packet frames keep them clear themselves (k_accumulate)
         HIPC(S.d_hits.ensure(c->n_local));
         HIPC(S.d_contrib.ensure(nl * c->n_local));
         HIPC(S.d_shadow_rays.ensure(2 * nl * c->n_local));
@@ -502,7 +502,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     FrameArgs a{};
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
-    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p;
+    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p; a.fold_counters = c->kind_primary == 8 && c->kind_shadow == 8 && c->n_local != 0;
     a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
     a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
@@ -530,7 +530,7 @@ int32_t art_trace(ArtContext *c) {
         if (!S.graph) { // capture the frame once per slot; stage events are not part of it
             hipGraph_t g = nullptr;
             HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            hipError_t e = hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s);
+            hipError_t e = a.fold_counters ? hipSuccess : hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s);
             if (e == hipSuccess && a.n_local) { launch_primary(a, s); launch_shade(a, s); launch_shadow(a, s); launch_accumulate(a, s); e = hipGetLastError(); }
             hipError_t e2 = hipStreamEndCapture(s, &g);
             if (e != hipSuccess || e2 != hipSuccess) { if (g) (void)hipGraphDestroy(g); return hipfail(e != hipSuccess ? e : e2, "art_trace: graph capture"); }
@@ -547,7 +547,7 @@ int32_t art_trace(ArtContext *c) {
         c->last = k; c->frame_no++; c->traced = true;
         return ART_OK;
     }
-    HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s));
+    if (!a.fold_counters) HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s));
     HIPC(hipEventRecord(ev[0], s));
     if (a.n_local) launch_primary(a, s);
     HIPC(hipEventRecord(ev[1], s));
@@ -776,7 +776,7 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         r = sync_all(c); if (r) return r;
         std::vector<uint32_t> raw(kCounterWords);
         HIPC(hipMemcpy(raw.data(), c->slot[c->last].d_counters.p, kCounterWords * 4, hipMemcpyDeviceToHost));
-        uint64_t cnt[2] = {0, 0};
+        uint64_t cnt[2] = {raw[0], raw[1]}; // folded totals (packet frames) + the slots (per-ray frames): one of the two is zero
         for (uint32_t k = 0; k < kSlotCount; k++) { cnt[0] += raw[kShadowSlots + k * kSlotStride]; cnt[1] += raw[kHitSlots + k * kSlotStride]; }
         uint64_t owned = 0; // pixels of owned tiles that fall inside the frame
         for (uint32_t t : c->tile_list) {

@@ -103,6 +103,8 @@ struct FrameArgs {
     float4 *contrib;           // [n_lights][n_local]
     float4 *shadow_rays;       // [2 * n_lights * n_local] dense per (light, pixel): o.xyz,tmax (<=0: none) | d.xyz,-
     uint32_t *counters;        // kCounterWords, zeroed every frame
+    bool fold_counters;        // packet walks use no work cursors: the last launch of the frame folds the count slots into counters[0..1] and clears them for the
+                               // slot's next frame, instead of a memset launch in front of every frame
     float4 *color; float *depth; float4 *normal; // full frame, row-major
     float4 *color_tiles;       // compact [n_local] (sharded mode) or nullptr
     uint32_t *shadow_bits;     // debug, [n_local] or nullptr

@@ -838,6 +838,12 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
             float4 c = ld_nt(&a.contrib[(size_t)i * a.n_local + p]);
             rx += c.x * c.w; ry += c.y * c.w; rz += c.z * c.w;
         }
+    if (a.fold_counters && blockIdx.x == 0 && threadIdx.x < 64) { // every count of this frame is final (earlier launches): total them, clear the slots
+        uint32_t sh = a.counters[kShadowSlots + threadIdx.x * kSlotStride], hp = a.counters[kHitSlots + threadIdx.x * kSlotStride];
+        a.counters[kShadowSlots + threadIdx.x * kSlotStride] = 0; a.counters[kHitSlots + threadIdx.x * kSlotStride] = 0;
+        for (int off = 32; off >= 1; off >>= 1) { sh += (uint32_t)__shfl_xor((int)sh, off); hp += (uint32_t)__shfl_xor((int)hp, off); }
+        if (threadIdx.x == 0) { a.counters[0] = sh; a.counters[1] = hp; }
+    }
     float4 o = make_float4(rx, ry, rz, 1.0f);
     if (in) st_nt(&a.color[(size_t)y * a.W + x], o);
     if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
