@@ -68,6 +68,7 @@ struct ArtContext {
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
+    bool fused = true;        // packet frames run as ONE launch (k_frame); ART_FUSED=0: the four staged launches
     bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD / ART_SAH=0: keep the Karras tree)
     bool packet_wide = false; // ART_PACKET_WIDE=1: packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
@@ -199,7 +200,7 @@ int32_t setup_frame(ArtContext *c) {
         HIPC(S.d_color.ensure(npix)); HIPC(S.d_normal.ensure(npix)); HIPC(S.d_depth.ensure(npix));
         HIPC(hipMemset(S.d_color.p, 0, npix * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * 4));
         if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * 16)); }
-        if (c->cfg.flags & ART_FLAG_KEEP_DEBUG) HIPC(S.d_shadow_bits.ensure(c->n_local));
+        if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local)); // fused frames always write their per-pixel shadow bits (stats)
         if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * 16) { S.ext_tiles = nullptr; S.ext_tiles_bytes = 0; }
     }
     HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
@@ -294,6 +295,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     if (const char *pw = std::getenv("ART_PACKET_WIDE")) c->packet_wide = std::atoi(pw) != 0;
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
     if (const char *sh = std::getenv("ART_SAH")) c->fast_trace = std::atoi(sh) != 0;
+    if (const char *fu = std::getenv("ART_FUSED")) c->fused = std::atoi(fu) != 0;
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
         if (ok(w[0]) || w[0] == '8') { c->kind_primary = w[0] - '0'; c->kind_shadow = (ok(w[1]) || w[1] == '8') ? w[1] - '0' : (w[0] == '8' ? 4 : c->kind_primary);
             c->kind_ao = (w[1] && (ok(w[2]) || w[2] == '8')) ? w[2] - '0' : (c->kind_shadow == 8 ? 4 : c->kind_shadow); } }
@@ -509,6 +511,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
     a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr;
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
+    a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0;
     return a;
 }
 
@@ -525,13 +528,14 @@ int32_t art_trace(ArtContext *c) {
     hipStream_t s = c->stream_of(k);
     if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
     FrameArgs a = make_frame_args(c, S);
+    const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     if (c->graph_mode) {
         if (!S.graph) { // capture the frame once per slot; stage events are not part of it
             hipGraph_t g = nullptr;
             HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            hipError_t e = a.fold_counters ? hipSuccess : hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s);
-            if (e == hipSuccess && a.n_local) { launch_primary(a, s); launch_shade(a, s); launch_shadow(a, s); launch_accumulate(a, s); e = hipGetLastError(); }
+            hipError_t e = (a.fold_counters || fused) ? hipSuccess : hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s);
+            if (e == hipSuccess && a.n_local) { if (fused) launch_frame(a, s); else { launch_primary(a, s); launch_shade(a, s); launch_shadow(a, s); launch_accumulate(a, s); } e = hipGetLastError(); }
             hipError_t e2 = hipStreamEndCapture(s, &g);
             if (e != hipSuccess || e2 != hipSuccess) { if (g) (void)hipGraphDestroy(g); return hipfail(e != hipSuccess ? e : e2, "art_trace: graph capture"); }
             e = hipGraphInstantiate(&S.graph, g, nullptr, nullptr, 0);
@@ -543,6 +547,16 @@ int32_t art_trace(ArtContext *c) {
         HIPC(hipGraphLaunch(S.graph, s));
         if (!lean) HIPC(hipEventRecord(ev[4], s));
         HIPC(hipEventRecord(S.done, s));
+        S.ao_valid = false; S.presented = false;
+        c->last = k; c->frame_no++; c->traced = true;
+        return ART_OK;
+    }
+    if (fused) { // one launch; its time is booked on the first stage
+        HIPC(hipEventRecord(ev[0], s));
+        if (a.n_local) launch_frame(a, s);
+        for (int i = 1; i < 5; i++) HIPC(hipEventRecord(ev[i], s));
+        HIPC(hipEventRecord(S.done, s));
+        HIPC(hipGetLastError());
         S.ao_valid = false; S.presented = false;
         c->last = k; c->frame_no++; c->traced = true;
         return ART_OK;
@@ -775,6 +789,12 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         int32_t r = use_device(c); if (r) return r;
         r = sync_all(c); if (r) return r;
         std::vector<uint32_t> raw(kCounterWords);
+        if (c->fused && c->kind_primary == 8 && c->kind_shadow == 8) { // fused frames keep no counters: count from the frame's per-pixel bits + depth, here
+            FrameSlot &S = c->slot[c->last];
+            HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, c->stream_of(c->last)));
+            if (c->n_local) { launch_frame_stats(make_frame_args(c, S), S.d_counters.p, c->stream_of(c->last)); HIPC(hipGetLastError()); }
+            HIPC(hipStreamSynchronize(c->stream_of(c->last)));
+        }
         HIPC(hipMemcpy(raw.data(), c->slot[c->last].d_counters.p, kCounterWords * 4, hipMemcpyDeviceToHost));
         uint64_t cnt[2] = {raw[0], raw[1]}; // folded totals (packet frames) + the slots (per-ray frames): one of the two is zero
         for (uint32_t k = 0; k < kSlotCount; k++) { cnt[0] += raw[kShadowSlots + k * kSlotStride]; cnt[1] += raw[kHitSlots + k * kSlotStride]; }
@@ -806,6 +826,7 @@ int32_t art_read_hits(ArtContext *c, float *tuv, int32_t *ids, size_t n_pixels) 
     if (!c || !tuv || !ids) return fail(ART_E_INVALID, "art_read_hits: null argument");
     if (!c->traced) return fail(ART_E_STATE, "art_read_hits: nothing traced yet");
     if (n_pixels != (size_t)c->W * c->H) return fail(ART_E_INVALID, "art_read_hits: size mismatch");
+    if (c->fused && c->kind_primary == 8 && c->kind_shadow == 8 && !(c->cfg.flags & ART_FLAG_KEEP_DEBUG)) return fail(ART_E_STATE, "art_read_hits: fused frames keep hit records only with ART_FLAG_KEEP_DEBUG");
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
     std::vector<float4> h(c->n_local);

@@ -108,11 +108,15 @@ struct FrameArgs {
     float4 *color; float *depth; float4 *normal; // full frame, row-major
     float4 *color_tiles;       // compact [n_local] (sharded mode) or nullptr
     uint32_t *shadow_bits;     // debug, [n_local] or nullptr
+    uint32_t *pix_bits;        // fused frame: [n_local] shadowed / traced bits per pixel (always written)
+    bool keep_hits;            // fused frame: also store the hit records (art_read_hits)
 };
 void launch_primary(const FrameArgs &a, hipStream_t s);
 void launch_shade(const FrameArgs &a, hipStream_t s);
 void launch_shadow(const FrameArgs &a, hipStream_t s);
 void launch_accumulate(const FrameArgs &a, hipStream_t s);
+void launch_frame(const FrameArgs &a, hipStream_t s);      // the fused frame: primary + shade + shadow + accumulate in one launch
+void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s); // out[0] += shadow rays, out[1] += hit pixels
 // ambient occlusion on the frame's depth/normal outputs; occl: n_local*spp bytes; lut: spp+1 output values; cursors at counters[64+512..] are reused (queries never overlap a frame)
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, uint32_t *ao, const uint32_t *lut, hipStream_t s);
 struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; int kind; }; // kind: 2 | 4 | 1

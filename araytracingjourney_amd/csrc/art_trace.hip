@@ -372,6 +372,28 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
     }
 }
 
+// one packet through the walk that fits its rays' direction signs
+template <bool ANY, bool WIDE>
+__device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid) {
+    uint64_t act = ballot64(on);
+    if (act == 0ull) return;
+    // direction signs per axis: all set, none set, or mixed over the packet's rays
+    uint64_t nx = ballot64(on && r.inv.x < 0.0f), ny = ballot64(on && r.inv.y < 0.0f), nz = ballot64(on && r.inv.z < 0.0f);
+    bool uniform = (nx == 0ull || nx == act) && (ny == 0ull || ny == act) && (nz == 0ull || nz == act);
+    int oct = !uniform || WIDE ? 8 : (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
+    switch (oct) {
+    case 0: packet_walk<ANY, WIDE, WIDE ? 8 : 0>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 1: packet_walk<ANY, WIDE, WIDE ? 8 : 1>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 2: packet_walk<ANY, WIDE, WIDE ? 8 : 2>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 3: packet_walk<ANY, WIDE, WIDE ? 8 : 3>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 4: packet_walk<ANY, WIDE, WIDE ? 8 : 4>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 5: packet_walk<ANY, WIDE, WIDE ? 8 : 5>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 6: packet_walk<ANY, WIDE, WIDE ? 8 : 6>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 7: packet_walk<ANY, WIDE, WIDE ? 8 : 7>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    default: packet_walk<ANY, WIDE, 8>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    }
+}
+
 // MODE PK_PRIMARY: slot = local pixel (a wave = one 8x8 block), closest hit -> hits[].
 // MODE PK_SHADOW:  slot = light * n_local + local pixel (the dense shadow-ray slots of k_shade: the same 8x8 block, rays towards
 //                  one light), any hit -> the slot's contribution keeps 0.05.  A lane leaves the packet at its first hit.
@@ -416,24 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
     const bool traced = on;
     float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f; // -1: below every tmin, no box test passes (lanes without a ray, occluded lanes)
     uint32_t bpos = kNoHit, bgid = kNoHit;
-    uint64_t act = ballot64(on);
-    if (act != 0ull) {
-        // direction signs per axis: all set, none set, or mixed over the packet's rays
-        uint64_t nx = ballot64(on && r.inv.x < 0.0f), ny = ballot64(on && r.inv.y < 0.0f), nz = ballot64(on && r.inv.z < 0.0f);
-        bool uniform = (nx == 0ull || nx == act) && (ny == 0ull || ny == act) && (nz == 0ull || nz == act);
-        int oct = !uniform || WIDE ? 8 : (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
-        switch (oct) {
-        case 0: packet_walk<ANY, WIDE, WIDE ? 8 : 0>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        case 1: packet_walk<ANY, WIDE, WIDE ? 8 : 1>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        case 2: packet_walk<ANY, WIDE, WIDE ? 8 : 2>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        case 3: packet_walk<ANY, WIDE, WIDE ? 8 : 3>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        case 4: packet_walk<ANY, WIDE, WIDE ? 8 : 4>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        case 5: packet_walk<ANY, WIDE, WIDE ? 8 : 5>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        case 6: packet_walk<ANY, WIDE, WIDE ? 8 : 6>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        case 7: packet_walk<ANY, WIDE, WIDE ? 8 : 7>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        default: packet_walk<ANY, WIDE, 8>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-        }
-    }
+    walk_dispatch<ANY, WIDE>(a, r, on, stk, tbest, bu, bv, bpos, bgid);
     if (MODE == PK_PRIMARY) {
         if (slot < total) st_nt(&a.hits[slot], bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit)));
     } else if (MODE == PK_SHADOW) {
@@ -738,7 +743,75 @@ __device__ float4 sample_tex(const uint32_t *__restrict__ pool, const DevPrim &P
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// raytrace.rgen.glsl:103-199 without the shadow traceRayEXT: emits one shadow ray per (pixel, light) that needs it
+// ---- shading (raytrace.rgen.glsl:103-199), shared by the staged frame (k_shade) and the fused frame (k_frame) ---------
+struct Surface { V3 world_pos, N, Vv, albedo, F0; float metallic, alpha, nc_NdotV, NdotV; };
+
+// rgen:107-150: the hit triangle's attributes, normal mapping, material; also the frame's depth / view-space normal outputs
+__device__ __forceinline__ void shade_surface(const FrameArgs &a, uint32_t pos, float hu, float hv, Surface &S, float &out_depth, V3 &out_normal) {
+    // one dependent fetch: the shading record holds what get_indices + three vertex reads would return (rgen:107-114)
+    const float4 *sq = reinterpret_cast<const float4 *>(a.shade_tris + pos);
+    float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3], s4 = sq[4], s5 = sq[5], s6 = sq[6], s7 = sq[7], s8 = sq[8];
+    const DevPrim &P = a.prims[__float_as_uint(s8.z)];
+    float bx = 1.0f - hu - hv, by = hu, bz = hv;
+    V3 posv = (mk(s0.x, s0.y, s0.z) * bx + mk(s0.w, s1.x, s1.y) * by) + mk(s1.z, s1.w, s2.x) * bz;
+    V3 world_pos = xform_point(P.o2w, posv);
+    float tu = (s2.y * bx + s2.w * by) + s3.y * bz, tv = (s2.z * bx + s3.x * by) + s3.z * bz;
+    V3 nrm = nrm3((mk(s3.w, s4.x, s4.y) * bx + mk(s4.z, s4.w, s5.x) * by) + mk(s5.y, s5.z, s5.w) * bz);
+    const float *Wm = P.w2o;
+    V3 world_normal = nrm3(mk(dot3(nrm, mk(Wm[0], Wm[4], Wm[8])), dot3(nrm, mk(Wm[1], Wm[5], Wm[9])), dot3(nrm, mk(Wm[2], Wm[6], Wm[10]))));
+    V3 tan = nrm3((mk(s6.x, s6.y, s6.z) * bx + mk(s6.w, s7.x, s7.y) * by) + mk(s7.z, s7.w, s8.x) * bz);
+    V3 world_tangent = nrm3(xform_vec(P.o2w, tan));
+    world_tangent = nrm3(world_tangent - world_normal * dot3(world_tangent, world_normal));
+    V3 world_binormal = cross3(world_normal, world_tangent) * s8.y;
+    float4 tx = sample_tex(a.tex_pool, P, 2, tu, tv);
+    V3 N = nrm3(mk(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f));
+    N = nrm3((world_tangent * N.x + world_binormal * N.y) + world_normal * N.z);
+    tx = sample_tex(a.tex_pool, P, 0, tu, tv);
+    V3 albedo = mk(__powf(tx.x, 2.2f), __powf(tx.y, 2.2f), __powf(tx.z, 2.2f)); // radiance-only from here: fast intrinsics
+    tx = sample_tex(a.tex_pool, P, 1, tu, tv);
+    float roughness = tx.y, metallic = tx.z;
+    S.world_pos = world_pos; S.N = N; S.albedo = albedo; S.metallic = metallic;
+    S.Vv = nrm3(ld3(a.cam.camera_pos) - world_pos); // exact: V + L cancels at grazing angles and would amplify a 1-ulp rsq
+    S.F0 = mk(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
+    S.alpha = roughness * roughness;
+    S.nc_NdotV = dot3(N, S.Vv);
+    S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
+    V3 vp = mat4_mul(a.cam.view, world_pos.x, world_pos.y, world_pos.z, 1.0f);
+    out_depth = -vp.z;
+    const float *VI = a.cam.view_inv;
+    V3 on = mk((VI[0] * N.x + VI[1] * N.y) + VI[2] * N.z, (VI[4] * N.x + VI[5] * N.y) + VI[6] * N.z, (VI[8] * N.x + VI[9] * N.y) + VI[10] * N.z);
+    on.y = -on.y; on.z = -on.z;
+    on = nrm3(on);
+    out_normal = mk(on.x * 0.5f + 0.5f, on.y * 0.5f + 0.5f, on.z * 0.5f + 0.5f);
+}
+
+// rgen:152-185 up to the shadow ray: c = (rho_s + rho_d) * radiance, c.w = NdotL; the shadow ray (origin, tmax | direction) if one is due
+__device__ __forceinline__ bool shade_light(const ArtLight &l, const Surface &S, float4 &c4, float4 &ro, float4 &rd) {
+    V3 nn_L = get_unnormalized_L_vec(l, S.world_pos);
+    V3 L = nrm3(nn_L);
+    V3 Hh = nrm3(S.Vv + L);
+    float nc_NdotL = dot3(S.N, L);
+    float NdotL = clampf(nc_NdotL, 0.0f, 1.0f);
+    float NdotH = clampf(dot3(S.N, Hh), 0.0f, 1.0f);
+    float LdotH = clampf(dot3(L, Hh), 0.0f, 1.0f);
+    float sch = pow5(1.0f - LdotH);
+    V3 Ks = mk(S.F0.x + (1.0f - S.F0.x) * sch, S.F0.y + (1.0f - S.F0.y) * sch, S.F0.z + (1.0f - S.F0.z) * sch);
+    V3 Kd = S.albedo * (1.0f - S.metallic);
+    float DG = D_GGX(S.alpha, NdotH) * V_SmithGGXCorrelated_fast(S.alpha, S.NdotV, NdotL);
+    V3 rho_s = Ks * DG;
+    V3 rho_d = Kd * Burley_diffuse_local_sss(S.alpha, S.NdotV, S.nc_NdotV, nc_NdotL, LdotH, 0.4f);
+    V3 rad = get_light_radiance(l, S.world_pos, L);
+    V3 c = (rho_s + rho_d) * rad;
+    c4 = make_float4(c.x, c.y, c.z, NdotL);
+    if (l.casts_shadows && nc_NdotL > 0.0f) { // raytrace.rgen.glsl:165: origin world_pos, dir L, tmax length(nn_L)
+        ro = make_float4(S.world_pos.x, S.world_pos.y, S.world_pos.z, len3(nn_L));
+        rd = make_float4(L.x, L.y, L.z, 0.f);
+        return true;
+    }
+    return false;
+}
+
+// staged frame, stage 2: emits one shadow ray per (pixel, light) that needs it
 __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
     if (blockIdx.x * kBlock >= a.n_local) return;
     uint32_t p = a.block_order[blockIdx.x] * kBlock + threadIdx.x;
@@ -757,65 +830,19 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
             st_nt(&a.shadow_rays[2 * slot], make_float4(0.f, 0.f, 0.f, -1.0f)); // no shadow ray in this slot
         }
     } else {
-        // one dependent fetch: the shading record holds what get_indices + three vertex reads would return (rgen:107-114)
-        const float4 *sq = reinterpret_cast<const float4 *>(a.shade_tris + pos);
-        float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3], s4 = sq[4], s5 = sq[5], s6 = sq[6], s7 = sq[7], s8 = sq[8];
-        const DevPrim &P = a.prims[__float_as_uint(s8.z)];
-        float bx = 1.0f - h.y - h.z, by = h.y, bz = h.z;
-        V3 posv = (mk(s0.x, s0.y, s0.z) * bx + mk(s0.w, s1.x, s1.y) * by) + mk(s1.z, s1.w, s2.x) * bz;
-        V3 world_pos = xform_point(P.o2w, posv);
-        float tu = (s2.y * bx + s2.w * by) + s3.y * bz, tv = (s2.z * bx + s3.x * by) + s3.z * bz;
-        V3 nrm = nrm3((mk(s3.w, s4.x, s4.y) * bx + mk(s4.z, s4.w, s5.x) * by) + mk(s5.y, s5.z, s5.w) * bz);
-        const float *Wm = P.w2o;
-        V3 world_normal = nrm3(mk(dot3(nrm, mk(Wm[0], Wm[4], Wm[8])), dot3(nrm, mk(Wm[1], Wm[5], Wm[9])), dot3(nrm, mk(Wm[2], Wm[6], Wm[10]))));
-        V3 tan = nrm3((mk(s6.x, s6.y, s6.z) * bx + mk(s6.w, s7.x, s7.y) * by) + mk(s7.z, s7.w, s8.x) * bz);
-        V3 world_tangent = nrm3(xform_vec(P.o2w, tan));
-        world_tangent = nrm3(world_tangent - world_normal * dot3(world_tangent, world_normal));
-        V3 world_binormal = cross3(world_normal, world_tangent) * s8.y;
-        float4 tx = sample_tex(a.tex_pool, P, 2, tu, tv);
-        V3 N = nrm3(mk(tx.x * 2.0f - 1.0f, tx.y * 2.0f - 1.0f, tx.z * 2.0f - 1.0f));
-        N = nrm3((world_tangent * N.x + world_binormal * N.y) + world_normal * N.z);
-        tx = sample_tex(a.tex_pool, P, 0, tu, tv);
-        V3 albedo = mk(__powf(tx.x, 2.2f), __powf(tx.y, 2.2f), __powf(tx.z, 2.2f)); // radiance-only from here: fast intrinsics
-        tx = sample_tex(a.tex_pool, P, 1, tu, tv);
-        float roughness = tx.y, metallic = tx.z;
-        V3 Vv = nrm3(ld3(a.cam.camera_pos) - world_pos); // exact: V + L cancels at grazing angles and would amplify a 1-ulp rsq
-        V3 F0 = mk(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
-        float alpha = roughness * roughness;
-        float nc_NdotV = dot3(N, Vv);
-        float NdotV = clampf(nc_NdotV, 1e-5f, 1.0f);
+        Surface S;
+        shade_surface(a, pos, h.y, h.z, S, out_depth, out_normal);
         for (uint32_t i = 0; i < a.n_lights; i++) {
-            const ArtLight &l = a.lights[i];
-            V3 nn_L = get_unnormalized_L_vec(l, world_pos);
-            V3 L = nrm3(nn_L);
-            V3 Hh = nrm3(Vv + L);
-            float nc_NdotL = dot3(N, L);
-            float NdotL = clampf(nc_NdotL, 0.0f, 1.0f);
-            float NdotH = clampf(dot3(N, Hh), 0.0f, 1.0f);
-            float LdotH = clampf(dot3(L, Hh), 0.0f, 1.0f);
-            float sch = pow5(1.0f - LdotH);
-            V3 Ks = mk(F0.x + (1.0f - F0.x) * sch, F0.y + (1.0f - F0.y) * sch, F0.z + (1.0f - F0.z) * sch);
-            V3 Kd = albedo * (1.0f - metallic);
-            float DG = D_GGX(alpha, NdotH) * V_SmithGGXCorrelated_fast(alpha, NdotV, NdotL);
-            V3 rho_s = Ks * DG;
-            V3 rho_d = Kd * Burley_diffuse_local_sss(alpha, NdotV, nc_NdotV, nc_NdotL, LdotH, 0.4f);
-            V3 rad = get_light_radiance(l, world_pos, L);
-            V3 c = (rho_s + rho_d) * rad;
+            float4 c4, ro, rd;
+            bool want = shade_light(a.lights[i], S, c4, ro, rd);
             size_t slot = (size_t)i * a.n_local + p;
-            st_nt(&a.contrib[slot], make_float4(c.x, c.y, c.z, NdotL));
-            if (l.casts_shadows && nc_NdotL > 0.0f) { // raytrace.rgen.glsl:165: origin world_pos, dir L, tmax length(nn_L)
-                st_nt(&a.shadow_rays[2 * slot], make_float4(world_pos.x, world_pos.y, world_pos.z, len3(nn_L)));
-                st_nt(&a.shadow_rays[2 * slot + 1], make_float4(L.x, L.y, L.z, 0.f));
+            st_nt(&a.contrib[slot], c4);
+            if (want) {
+                st_nt(&a.shadow_rays[2 * slot], ro);
+                st_nt(&a.shadow_rays[2 * slot + 1], rd);
                 if (i < 16) sbits |= 1u << (16 + i);
             } else st_nt(&a.shadow_rays[2 * slot], make_float4(0.f, 0.f, 0.f, -1.0f));
         }
-        V3 vp = mat4_mul(a.cam.view, world_pos.x, world_pos.y, world_pos.z, 1.0f);
-        out_depth = -vp.z;
-        const float *VI = a.cam.view_inv;
-        V3 on = mk((VI[0] * N.x + VI[1] * N.y) + VI[2] * N.z, (VI[4] * N.x + VI[5] * N.y) + VI[6] * N.z, (VI[8] * N.x + VI[9] * N.y) + VI[10] * N.z);
-        on.y = -on.y; on.z = -on.z;
-        on = nrm3(on);
-        out_normal = mk(on.x * 0.5f + 0.5f, on.y * 0.5f + 0.5f, on.z * 0.5f + 0.5f);
     }
     if (in) {
         st_nt(&a.depth[pix], out_depth);
@@ -824,6 +851,90 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
     if (a.shadow_bits) a.shadow_bits[p] = sbits;
     uint64_t hitmask = __ballot(pos != kNoHit); // hit-pixel count: one atomic per wave, off the critical path
     if ((threadIdx.x & 63u) == 0 && hitmask) atomicAdd(&a.counters[kHitSlots + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlotCount) * kSlotStride], (uint32_t)__popcll(hitmask));
+}
+
+// The fused frame: one wave takes an 8x8 pixel block through the whole of raytrace.rgen.glsl -- primary packet, shading, one
+// shadow packet per light, accumulation -- and writes only the frame's outputs.  No hit / shadow-ray / contribution records
+// cross HBM, one launch per frame, and the CUs hold waves in every phase at once (node-fetch latency of the walks, texture
+// latency and ALU of the shading), which is what the staged frame needed a dozen frames in flight for.  The arithmetic and its
+// order are the staged kernels': the frames are bit-identical.  pix_bits[p]: bit i = light i shadowed, bit 16+i = shadow ray
+// traced (art_get_stats counts rays from it on demand; art_read_shadow_bits).
+template <bool WIDE>
+__global__ __launch_bounds__(kBlock) void k_frame(FrameArgs a) {
+    __shared__ int wstack[(kBlock / 64) * kPacketStack];
+    int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
+    if (blockIdx.x * kBlock >= a.n_local) return;
+    const uint32_t p = a.block_order[blockIdx.x] * kBlock + threadIdx.x;
+    uint32_t x = 0, y = 0;
+    const bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
+    const size_t pix = (size_t)y * a.W + x;
+    Ray r;
+    {
+        float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+        float dx = (fx / (float)a.W) * 2.0f - 1.0f, dy = (fy / (float)a.H) * 2.0f - 1.0f;
+        V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
+        V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
+        V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
+        ray_init(r, org, dir, 0.001f, 10000.0f);
+    }
+    bool on = in;
+    float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f;
+    uint32_t bpos = kNoHit, bgid = kNoHit;
+    walk_dispatch<false, WIDE>(a, r, on, stk, tbest, bu, bv, bpos, bgid);
+    if (a.keep_hits) a.hits[p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+    const bool hit = in && bpos != kNoHit;
+    float out_depth = 10000.0f;
+    V3 out_normal = mk(0.5f, 0.5f, 0.5f);
+    Surface S;
+    S.world_pos = mk(0.f, 0.f, 0.f); S.N = mk(0.f, 0.f, 1.f); S.Vv = mk(0.f, 0.f, 1.f); S.albedo = mk(0.f, 0.f, 0.f); S.F0 = mk(0.f, 0.f, 0.f);
+    S.metallic = 0.f; S.alpha = 0.f; S.nc_NdotV = 0.f; S.NdotV = 0.f;
+    if (hit) shade_surface(a, bpos, bu, bv, S, out_depth, out_normal);
+    if (in) {
+        st_nt(&a.depth[pix], out_depth);
+        st_nt(&a.normal[pix], make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f));
+    }
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    uint32_t sbits = 0;
+    for (uint32_t i = 0; i < a.n_lights; i++) { // uniform loop: the shadow packet needs the whole wave
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
+        bool want = false;
+        if (hit) want = shade_light(a.lights[i], S, c4, ro, rd);
+        if (want) sbits |= 1u << (16 + i);
+        Ray sr;
+        ray_init(sr, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), 0.01f, ro.w);
+        bool son = want;
+        float st = son ? sr.tmax : -1.0f, su = 0.f, sv = 0.f;
+        uint32_t spos = kNoHit, sgid = kNoHit;
+        walk_dispatch<true, WIDE>(a, sr, son, stk, st, su, sv, spos, sgid);
+        if (want && spos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
+            c4 = make_float4(c4.x * 0.05f, c4.y * 0.05f, c4.z * 0.05f, c4.w);
+            sbits |= 1u << i;
+        }
+        rx += c4.x * c4.w; ry += c4.y * c4.w; rz += c4.z * c4.w; // rgen:185, lights in order
+    }
+    if (!in) { rx = 0.f; ry = 0.f; rz = 0.f; }
+    float4 o = make_float4(rx, ry, rz, 1.0f);
+    if (in) st_nt(&a.color[pix], o);
+    if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
+        uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
+        uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
+        st_nt(&a.color_tiles[(size_t)(p >> 10) * kTilePixels + ly * kTile + lx], o);
+    }
+    a.pix_bits[p] = sbits;
+}
+
+// art_get_stats for fused frames: shadow rays = set bits 16..31 of pix_bits, hit pixels = depth < miss depth; on demand only
+__global__ __launch_bounds__(kBlock) void k_frame_stats(FrameArgs a, uint32_t *out) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t rays = 0, hits = 0;
+    if (p < a.n_local) {
+        uint32_t x, y;
+        bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
+        rays = (uint32_t)__popc(a.pix_bits[p] >> 16);
+        hits = in && a.depth[(size_t)y * a.W + x] < 10000.0f ? 1u : 0u;
+    }
+    for (int off = 32; off >= 1; off >>= 1) { rays += (uint32_t)__shfl_xor((int)rays, off); hits += (uint32_t)__shfl_xor((int)hits, off); }
+    if ((threadIdx.x & 63u) == 0) { if (rays) atomicAdd(&out[0], rays); if (hits) atomicAdd(&out[1], hits); }
 }
 
 // rho += (rho_s + rho_d) * radiance * shadow_attenuation * NdotL (raytrace.rgen.glsl:185), lights in order
@@ -902,6 +1013,10 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
+void launch_frame(const FrameArgs &a, hipStream_t s) {
+    if (a.packet_wide) k_frame<true><<<blocks_for(a.n_local), kBlock, 0, s>>>(a); else k_frame<false><<<blocks_for(a.n_local), kBlock, 0, s>>>(a);
+}
+void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s) { k_frame_stats<<<blocks_for(a.n_local), kBlock, 0, s>>>(a, out); }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 // queries: rays[2i] = o.xyz,tmin | rays[2i+1] = d.xyz,tmax;  cursors: 8 * kCursorStride zeroed words
 void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s) {
