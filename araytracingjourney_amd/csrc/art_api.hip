@@ -85,6 +85,7 @@ struct ArtContext {
     DevBuf<uint32_t> d_block_order; // launch block -> 256-pixel block of the frame: one L2 (XCD) per screen region (setup_frame)
     static constexpr int kRing = 128;          // per-frame stage events kept for art_collect_timings
     hipEvent_t ev[kRing][5] = {};
+    bool ev_fused[kRing] = {};                 // the frame was one launch: only ev[0] and ev[4] were recorded
     uint64_t frame_no = 0, collected_upto = 0;
     bool traced = false;
     bool graph_mode = false; // replay a captured hipGraph per slot instead of 5 launches + 6 event records (host-bound multi-GPU runs)
@@ -530,7 +531,8 @@ int32_t art_trace(ArtContext *c) {
     FrameArgs a = make_frame_args(c, S);
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
-    if (c->graph_mode) {
+    c->ev_fused[c->frame_no % ArtContext::kRing] = fused;
+    if (c->graph_mode && !fused) { // a fused frame is a single launch: nothing for a graph to save
         if (!S.graph) { // capture the frame once per slot; stage events are not part of it
             hipGraph_t g = nullptr;
             HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -554,7 +556,7 @@ int32_t art_trace(ArtContext *c) {
     if (fused) { // one launch; its time is booked on the first stage
         HIPC(hipEventRecord(ev[0], s));
         if (a.n_local) launch_frame(a, s);
-        for (int i = 1; i < 5; i++) HIPC(hipEventRecord(ev[i], s));
+        HIPC(hipEventRecord(ev[4], s));
         HIPC(hipEventRecord(S.done, s));
         HIPC(hipGetLastError());
         S.ao_valid = false; S.presented = false;
@@ -759,6 +761,7 @@ int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames)
     for (uint64_t f = from; f < c->frame_no; f++) {
         hipEvent_t *ev = c->ev[f % ArtContext::kRing];
         float ms = 0;
+        if (c->ev_fused[f % ArtContext::kRing]) { HIPC(hipEventElapsedTime(&ms, ev[0], ev[4])); sums_ms[0] += ms; sums_ms[4] += ms; continue; } // one launch: booked on the first stage
         for (int k = 0; k < 4; k++) { HIPC(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); sums_ms[k] += ms; }
         HIPC(hipEventElapsedTime(&ms, ev[0], ev[4])); sums_ms[4] += ms;
     }
@@ -805,16 +808,20 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
             owned += (uint64_t)w * h;
         }
         c->stats.primary_rays = owned; c->stats.shadow_rays = cnt[0]; c->stats.hit_pixels = cnt[1];
+        c->stats.frame_launches = (c->fused && c->kind_primary == 8 && c->kind_shadow == 8) ? 1u : 4u;
         c->stats.ao_rays = (uint64_t)c->ao_spp * cnt[1];
         if (c->ao_spp) { float ams = 0; if (hipEventElapsedTime(&ams, c->slot[c->last].ao_ev[0], c->slot[c->last].ao_ev[1]) == hipSuccess) c->stats.ao_ms = ams; }
         float ms = 0;
         if (c->frame_no) {
             hipEvent_t *ev = c->ev[(c->frame_no - 1) % ArtContext::kRing];
             if (hipEventElapsedTime(&ms, ev[0], ev[4]) == hipSuccess) c->stats.frame_ms = ms;
+            if (c->ev_fused[(c->frame_no - 1) % ArtContext::kRing]) { c->stats.trace_primary_ms = c->stats.frame_ms; c->stats.shade_ms = c->stats.trace_shadow_ms = c->stats.accumulate_ms = 0.f; }
+            else {
             if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.trace_primary_ms = ms;
             if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->stats.shade_ms = ms;
             if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.trace_shadow_ms = ms;
             if (hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess) c->stats.accumulate_ms = ms;
+            }
         }
     }
     *out = c->stats;

@@ -859,8 +859,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
 // latency and ALU of the shading), which is what the staged frame needed a dozen frames in flight for.  The arithmetic and its
 // order are the staged kernels': the frames are bit-identical.  pix_bits[p]: bit i = light i shadowed, bit 16+i = shadow ray
 // traced (art_get_stats counts rays from it on demand; art_read_shadow_bits).
-template <bool WIDE>
-__global__ __launch_bounds__(kBlock) void k_frame(FrameArgs a) {
+template <bool WIDE, int WAVES>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
     if (blockIdx.x * kBlock >= a.n_local) return;
@@ -1014,7 +1014,12 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
 void launch_frame(const FrameArgs &a, hipStream_t s) {
-    if (a.packet_wide) k_frame<true><<<blocks_for(a.n_local), kBlock, 0, s>>>(a); else k_frame<false><<<blocks_for(a.n_local), kBlock, 0, s>>>(a);
+    static const int waves = [] { const char *e = getenv("ART_FRAME_WAVES"); return e ? atoi(e) : 8; }(); // registers: 6 -> 80, 7 -> 72 (5 spilled), 8 -> 64 (17 spilled); measured 13.19 / 13.78 / 13.85 Gray/s
+    const uint32_t g = blocks_for(a.n_local);
+    if (a.packet_wide) k_frame<true, 5><<<g, kBlock, 0, s>>>(a);
+    else if (waves >= 8) k_frame<false, 8><<<g, kBlock, 0, s>>>(a);
+    else if (waves == 7) k_frame<false, 7><<<g, kBlock, 0, s>>>(a);
+    else k_frame<false, 6><<<g, kBlock, 0, s>>>(a);
 }
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s) { k_frame_stats<<<blocks_for(a.n_local), kBlock, 0, s>>>(a, out); }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }

@@ -223,12 +223,13 @@ def main():
     roof = None
     if ost is not None:
         ab = algorithmic_bytes(ost, args.lights)
-        dom = "primary" if stage_max["primary_ms"] >= stage_max["shadow_ms"] else "shadow"
-        kname = {"primary": "k_primary", "shadow": "k_shadow"}[dom]
-        dur_ms = stage_max[f"{dom}_ms"]
+        fused = st.get("frame_launches") == 1   # one launch per frame (k_frame): its span is booked on the first stage
+        dom = "frame" if fused else ("primary" if stage_max["primary_ms"] >= stage_max["shadow_ms"] else "shadow")
+        kname = {"frame": "k_frame", "primary": "k_primary", "shadow": "k_shadow"}[dom]
+        dur_ms = stage_max["primary_ms" if fused else f"{dom}_ms"]
         per_launch = ab[dom] / world  # each rank's launch handles 1/world of the frame's rays
         achieved = per_launch / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-        iso_ms = iso[f"{dom}_ms"]
+        iso_ms = iso["primary_ms" if fused else f"{dom}_ms"]
         roof = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None,
                     algorithmic_bytes_per_launch=per_launch, kernel_ms=dur_ms, frames_timed=n_timed, frames_in_flight=F,
                     kernel_ms_alone=iso_ms, frac_alone=(per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else None,

@@ -86,7 +86,7 @@ typedef struct ArtStats {
     uint32_t num_triangles;
     uint32_t num_primitives;
     uint32_t num_nodes;         /* nodes of the traversal structure */
-    uint32_t reserved;
+    uint32_t frame_launches; /* kernel launches per frame: 1 = fused frame kernel, 4 = primary / shade / shadow / accumulate */
     float build_ms;             /* last art_scene_build, device time */
     float frame_ms;             /* last art_trace, device time (events on the context's stream) */
     float trace_primary_ms, shade_ms, trace_shadow_ms, accumulate_ms;
