@@ -744,7 +744,7 @@ __device__ float4 sample_tex(const uint32_t *__restrict__ pool, const DevPrim &P
 }
 
 // ---- shading (raytrace.rgen.glsl:103-199), shared by the staged frame (k_shade) and the fused frame (k_frame) ---------
-struct Surface { V3 world_pos, N, Vv, albedo, F0; float metallic, alpha, nc_NdotV, NdotV; };
+struct Surface { V3 world_pos, N, Vv, albedo; float metallic, alpha, nc_NdotV, NdotV; };
 
 // rgen:107-150: the hit triangle's attributes, normal mapping, material; also the frame's depth / view-space normal outputs
 __device__ __forceinline__ void shade_surface(const FrameArgs &a, uint32_t pos, float hu, float hv, Surface &S, float &out_depth, V3 &out_normal) {
@@ -772,7 +772,6 @@ __device__ __forceinline__ void shade_surface(const FrameArgs &a, uint32_t pos, 
     float roughness = tx.y, metallic = tx.z;
     S.world_pos = world_pos; S.N = N; S.albedo = albedo; S.metallic = metallic;
     S.Vv = nrm3(ld3(a.cam.camera_pos) - world_pos); // exact: V + L cancels at grazing angles and would amplify a 1-ulp rsq
-    S.F0 = mk(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
     S.alpha = roughness * roughness;
     S.nc_NdotV = dot3(N, S.Vv);
     S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
@@ -795,7 +794,8 @@ __device__ __forceinline__ bool shade_light(const ArtLight &l, const Surface &S,
     float NdotH = clampf(dot3(S.N, Hh), 0.0f, 1.0f);
     float LdotH = clampf(dot3(L, Hh), 0.0f, 1.0f);
     float sch = pow5(1.0f - LdotH);
-    V3 Ks = mk(S.F0.x + (1.0f - S.F0.x) * sch, S.F0.y + (1.0f - S.F0.y) * sch, S.F0.z + (1.0f - S.F0.z) * sch);
+    V3 F0 = mk(mixf(0.04f, S.albedo.x, S.metallic), mixf(0.04f, S.albedo.y, S.metallic), mixf(0.04f, S.albedo.z, S.metallic));
+    V3 Ks = mk(F0.x + (1.0f - F0.x) * sch, F0.y + (1.0f - F0.y) * sch, F0.z + (1.0f - F0.z) * sch);
     V3 Kd = S.albedo * (1.0f - S.metallic);
     float DG = D_GGX(S.alpha, NdotH) * V_SmithGGXCorrelated_fast(S.alpha, S.NdotV, NdotL);
     V3 rho_s = Ks * DG;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
 // latency and ALU of the shading), which is what the staged frame needed a dozen frames in flight for.  The arithmetic and its
 // order are the staged kernels': the frames are bit-identical.  pix_bits[p]: bit i = light i shadowed, bit 16+i = shadow ray
 // traced (art_get_stats counts rays from it on demand; art_read_shadow_bits).
-template <bool WIDE, int WAVES>
+template <bool WIDE, int WAVES, bool ONE_LIGHT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     float out_depth = 10000.0f;
     V3 out_normal = mk(0.5f, 0.5f, 0.5f);
     Surface S;
-    S.world_pos = mk(0.f, 0.f, 0.f); S.N = mk(0.f, 0.f, 1.f); S.Vv = mk(0.f, 0.f, 1.f); S.albedo = mk(0.f, 0.f, 0.f); S.F0 = mk(0.f, 0.f, 0.f);
+    S.world_pos = mk(0.f, 0.f, 0.f); S.N = mk(0.f, 0.f, 1.f); S.Vv = mk(0.f, 0.f, 1.f); S.albedo = mk(0.f, 0.f, 0.f);
     S.metallic = 0.f; S.alpha = 0.f; S.nc_NdotV = 0.f; S.NdotV = 0.f;
     if (hit) shade_surface(a, bpos, bu, bv, S, out_depth, out_normal);
     if (in) {
@@ -895,7 +895,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     }
     float rx = 0.f, ry = 0.f, rz = 0.f;
     uint32_t sbits = 0;
-    for (uint32_t i = 0; i < a.n_lights; i++) { // uniform loop: the shadow packet needs the whole wave
+    // ONE_LIGHT: no loop, so the surface record is dead once the light is evaluated and the shadow walk runs on few live registers
+    for (uint32_t i = 0; i < (ONE_LIGHT ? 1u : a.n_lights); i++) { // uniform loop: the shadow packet needs the whole wave
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
         bool want = false;
         if (hit) want = shade_light(a.lights[i], S, c4, ro, rd);
@@ -1016,10 +1017,12 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
 void launch_frame(const FrameArgs &a, hipStream_t s) {
     static const int waves = [] { const char *e = getenv("ART_FRAME_WAVES"); return e ? atoi(e) : 8; }(); // registers: 6 -> 80, 7 -> 72 (5 spilled), 8 -> 64 (17 spilled); measured 13.19 / 13.78 / 13.85 Gray/s
     const uint32_t g = blocks_for(a.n_local);
-    if (a.packet_wide) k_frame<true, 5><<<g, kBlock, 0, s>>>(a);
-    else if (waves >= 8) k_frame<false, 8><<<g, kBlock, 0, s>>>(a);
-    else if (waves == 7) k_frame<false, 7><<<g, kBlock, 0, s>>>(a);
-    else k_frame<false, 6><<<g, kBlock, 0, s>>>(a);
+    const bool one = a.n_lights == 1;
+    if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); return; }
+    if (a.packet_wide) { if (one) k_frame<true, 5, true><<<g, kBlock, 0, s>>>(a); else k_frame<true, 5, false><<<g, kBlock, 0, s>>>(a); }
+    else if (waves >= 8) { if (one) k_frame<false, 8, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); }
+    else if (waves == 7) { if (one) k_frame<false, 7, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 7, false><<<g, kBlock, 0, s>>>(a); }
+    else { if (one) k_frame<false, 6, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 6, false><<<g, kBlock, 0, s>>>(a); }
 }
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s) { k_frame_stats<<<blocks_for(a.n_local), kBlock, 0, s>>>(a, out); }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }

@@ -74,7 +74,7 @@ def main():
     sc = scenes.sponza_like(args.detail)
     lights = scenes.sponza_lights(args.lights)
     sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else (12 if world == 1 else 16)
+    F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else 16
     r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F)
     r.upload_state()
     stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
