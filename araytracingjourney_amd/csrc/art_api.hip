@@ -68,6 +68,7 @@ struct ArtContext {
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
+    int frame_waves = 8;      // ART_FRAME_WAVES: occupancy target of the fused frame kernel's instance (6 | 7 | 8)
     bool fused = true;        // packet frames run as ONE launch (k_frame); ART_FUSED=0: the four staged launches
     bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD / ART_SAH=0: keep the Karras tree)
     bool packet_wide = false; // ART_PACKET_WIDE=1: packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
@@ -297,6 +298,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
     if (const char *sh = std::getenv("ART_SAH")) c->fast_trace = std::atoi(sh) != 0;
     if (const char *fu = std::getenv("ART_FUSED")) c->fused = std::atoi(fu) != 0;
+    if (const char *fw = std::getenv("ART_FRAME_WAVES")) c->frame_waves = std::atoi(fw);
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
         if (ok(w[0]) || w[0] == '8') { c->kind_primary = w[0] - '0'; c->kind_shadow = (ok(w[1]) || w[1] == '8') ? w[1] - '0' : (w[0] == '8' ? 4 : c->kind_primary);
             c->kind_ao = (w[1] && (ok(w[2]) || w[2] == '8')) ? w[2] - '0' : (c->kind_shadow == 8 ? 4 : c->kind_shadow); } }
@@ -512,7 +514,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
     a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr;
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
-    a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0;
+    a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0; a.frame_waves = c->frame_waves;
     return a;
 }
 

@@ -110,6 +110,7 @@ struct FrameArgs {
     uint32_t *shadow_bits;     // debug, [n_local] or nullptr
     uint32_t *pix_bits;        // fused frame: [n_local] shadowed / traced bits per pixel (always written)
     bool keep_hits;            // fused frame: also store the hit records (art_read_hits)
+    int frame_waves;           // fused frame: occupancy target of the instance to launch (ART_FRAME_WAVES, default 8)
 };
 void launch_primary(const FrameArgs &a, hipStream_t s);
 void launch_shade(const FrameArgs &a, hipStream_t s);

@@ -1015,7 +1015,7 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
 void launch_frame(const FrameArgs &a, hipStream_t s) {
-    static const int waves = [] { const char *e = getenv("ART_FRAME_WAVES"); return e ? atoi(e) : 8; }(); // registers: 6 -> 80, 7 -> 72 (5 spilled), 8 -> 64 (17 spilled); measured 13.19 / 13.78 / 13.85 Gray/s
+    const int waves = a.frame_waves; // multi-light instance, registers: 6 waves/SIMD -> 80, 7 -> 72 (5 spilled), 8 -> 64 (17 spilled); measured 13.19 / 13.78 / 13.85 Gray/s
     const uint32_t g = blocks_for(a.n_local);
     const bool one = a.n_lights == 1;
     if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); return; }

@@ -168,11 +168,12 @@ class Camera:
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
-    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1):
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False):
         self._L = _lib.load()
         w, h = extent
         cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
-                        flags=_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0, frames_in_flight=frames_in_flight)
+                        flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0),
+                        frames_in_flight=frames_in_flight)
         self._ctx = C.c_void_p()
         check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))
         self.extent = (w, h)

@@ -251,6 +251,35 @@ def test_frame_ring_gives_the_same_frames(R, get_scene):
     ring.close()
 
 
+def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
+    """the fused frame kernel, the four staged packet kernels, the per-ray kernels -- on the SAH tree and on the LBVH topology
+    (ART_FLAG_FAST_BUILD): one frame, bit for bit (colour, depth, normal, ray counts); 4 lights so the light loop is covered"""
+    from araytracingjourney_amd import scenes
+    sc = get_scene("sponza_like", 0.12)
+    w, h = 320, 200
+    def frame(frames_in_flight, fast_build=False, env=None):
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=frames_in_flight, fast_build=fast_build)
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+        for d in scenes.sponza_lights(4):
+            r.lights_mut().push_dict(d)
+        r.render_frame()
+        out = (r.read_color(), r.read_depth(), r.read_normal(), r.stats())
+        r.close()
+        return out
+    ref = frame(4)                                               # fused, SAH (the default with several frames in flight)
+    assert ref[3]["frame_launches"] == 1 and ref[3]["shadow_rays"] > 10000
+    for name, got in (("staged packets", frame(4, env={"ART_FUSED": "0"})), ("per-ray", frame(1)),
+                      ("fused on the LBVH topology", frame(4, fast_build=True)), ("per-ray on the LBVH topology", frame(1, fast_build=True)),
+                      ("fused, 7 waves/SIMD", frame(4, env={"ART_FRAME_WAVES": "7"})), ("fused, no block reordering", frame(4, env={"ART_MACRO": "0"}))):
+        for k in range(3):
+            assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
+        assert got[3]["shadow_rays"] == ref[3]["shadow_rays"] and got[3]["hit_pixels"] == ref[3]["hit_pixels"], name
+    assert frame(4, env={"ART_FUSED": "0"})[3]["frame_launches"] == 4
+
+
 def test_single_triangle_known_answers(R):
     """analytic KAT through the GPU: one triangle, hand-computed t/u/v, edge, parallel, behind, range cases"""
     from araytracingjourney_amd import scenes
