@@ -92,6 +92,8 @@ struct ArtContext {
     bool graph_mode = false; // replay a captured hipGraph per slot instead of 5 launches + 6 event records (host-bound multi-GPU runs)
     uint32_t ao_spp = 0;
     ArtStats stats{};
+    bool tiles_packed() const { return (cfg.flags & ART_FLAG_PACKED_TILES) != 0; }
+    size_t tile_px_bytes() const { return tiles_packed() ? 4 : 16; } // B10G11R11 words or float4 in the compact tile buffer
     hipStream_t stream_of(uint32_t k) const { return (ext_stream && F == 1) ? ext_stream : slot[k].own; }
     hipStream_t main_stream() const { return stream_of(0); }
 };
@@ -201,9 +203,9 @@ int32_t setup_frame(ArtContext *c) {
         HIPC(S.d_shadow_rays.ensure(2 * nl * c->n_local));
         HIPC(S.d_color.ensure(npix)); HIPC(S.d_normal.ensure(npix)); HIPC(S.d_depth.ensure(npix));
         HIPC(hipMemset(S.d_color.p, 0, npix * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * 4));
-        if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * 16)); }
+        if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes())); }
         if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local)); // fused frames always write their per-pixel shadow bits (stats)
-        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * 16) { S.ext_tiles = nullptr; S.ext_tiles_bytes = 0; }
+        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) { S.ext_tiles = nullptr; S.ext_tiles_bytes = 0; }
     }
     HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
     drop_graphs(c);
@@ -512,7 +514,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
-    a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr;
+    a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr; a.tiles_packed = c->tiles_packed();
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
     a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0; a.frame_waves = c->frame_waves;
     return a;
@@ -714,7 +716,7 @@ int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
     int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color_tiles"); if (r) return r;
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
     FrameSlot &S = c->slot[c->last];
-    *p = S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * 16;
+    *p = S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes();
     return ART_OK;
 }
 int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t bytes) {
@@ -722,7 +724,7 @@ int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t byt
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_bind_color_tiles: context is not sharded");
     if (slot >= c->F) return fail(ART_E_INVALID, "art_bind_color_tiles: slot >= frames in flight");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_bind_color_tiles"); if (r) return r;
-    if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * 16) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
+    if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
     HIPC(hipStreamSynchronize(c->stream_of(slot)));
     c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
     drop_graphs(c);
@@ -774,15 +776,20 @@ int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames)
 int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
     if (c && c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
     FrameSlot *S = c ? &c->slot[c->last] : nullptr;
-    return read_back(c, S ? (S->ext_tiles ? S->ext_tiles : S->d_color_tiles.p) : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * 16 : 0, dst, bytes, "art_read_color_tiles");
+    return read_back(c, S ? (S->ext_tiles ? S->ext_tiles : S->d_color_tiles.p) : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() : 0, dst, bytes, "art_read_color_tiles");
 }
 int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream) {
     if (!c || !gathered_dev) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_untile_gathered"); if (r) return r;
     if (shard_count != (c->cfg.shard_count > 1 ? c->cfg.shard_count : 1)) return fail(ART_E_INVALID, "art_untile_gathered: shard_count differs from the context's");
     r = use_device(c); if (r) return r;
-    launch_untile((const float4 *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->slot[c->last].d_color.p,
-                  hip_stream ? (hipStream_t)hip_stream : c->stream_of(c->last));
+    hipStream_t us = hip_stream ? (hipStream_t)hip_stream : c->stream_of(c->last);
+    if (c->tiles_packed()) { // the gathered tiles are B10G11R11 words: the frame is the packed colour image (art_read_packed)
+        FrameSlot &S = c->slot[c->last];
+        if (!frame_dev && S.d_pcolor.n < (size_t)c->W * c->H) { HIPC(hipStreamSynchronize(us)); HIPC(S.d_pcolor.ensure((size_t)c->W * c->H)); }
+        launch_untile_packed((const uint32_t *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (uint32_t *)frame_dev : S.d_pcolor.p, us);
+    } else
+    launch_untile((const float4 *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->slot[c->last].d_color.p, us);
     HIPC(hipGetLastError());
     c->traced = true;
     return ART_OK;

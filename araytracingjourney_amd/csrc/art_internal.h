@@ -88,6 +88,36 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s);
 hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s);
 void lbvh_free(Lbvh &l);
 
+// float32 -> unsigned small float (5 exponent bits, MB mantissa bits), round to nearest even; negatives -> 0, overflow -> +Inf
+template <int MB> __host__ __device__ inline uint32_t pack_ufloat(float f) {
+    uint32_t u;
+#ifdef __HIP_DEVICE_COMPILE__
+    u = __float_as_uint(f);
+#else
+    std::memcpy(&u, &f, 4);
+#endif
+    uint32_t e8 = (u >> 23) & 255u, m = u & 0x7FFFFFu;
+    if (e8 == 255u && m) return (31u << MB) | 1u;
+    if (u >> 31) return 0;
+    if (e8 == 255u) return 31u << MB;
+    int e = (int)e8 - 127 + 15;
+    if (e >= 31) return 31u << MB;
+    int shift = 23 - MB;
+    uint32_t full = m | (e8 ? 0x800000u : 0u);
+    if (e <= 0) { shift += 1 - e; e = 0; if (shift > 31) return 0; } else full &= 0x7FFFFFu;
+    uint32_t q = full >> shift, rem = full & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    uint32_t out = ((uint32_t)e << MB) + q;
+    return out > (31u << MB) ? (31u << MB) : out;
+}
+template <int MB> __device__ inline float unpack_ufloat(uint32_t v) {
+    uint32_t e = v >> MB, m = v & ((1u << MB) - 1u);
+    if (e == 31u) return m ? __uint_as_float(0x7FC00000u) : __uint_as_float(0x7F800000u);
+    if (e == 0) return ldexpf((float)m, -14 - MB);
+    return ldexpf((float)(m | (1u << MB)), (int)e - 15 - MB);
+}
+__device__ inline uint32_t pack_b10g11r11(float r, float g, float b) { return pack_ufloat<6>(r) | (pack_ufloat<6>(g) << 11) | (pack_ufloat<5>(b) << 22); }
+
 struct FrameArgs {
     CameraArg cam;
     uint32_t W, H;
@@ -107,6 +137,7 @@ struct FrameArgs {
                                // slot's next frame, instead of a memset launch in front of every frame
     float4 *color; float *depth; float4 *normal; // full frame, row-major
     float4 *color_tiles;       // compact [n_local] (sharded mode) or nullptr
+    bool tiles_packed;         // color_tiles holds B10G11R11 words (4 B per pixel, the reference's output image format) instead of float4
     uint32_t *shadow_bits;     // debug, [n_local] or nullptr
     uint32_t *pix_bits;        // fused frame: [n_local] shadowed / traced bits per pixel (always written)
     bool keep_hits;            // fused frame: also store the hit records (art_read_hits)
@@ -133,6 +164,7 @@ void lpm_control_block(bool shoulder, float soft_gap, float hdr_max, float expos
                        const float crosstalk[3], uint32_t ctl[96]);
 void launch_present(uint32_t n, const float4 *color, const float4 *normal, const float *depth, const uint32_t *ao, const uint32_t ctl[96], uint32_t *pcolor,
                     uint32_t *pnormal, uint16_t *pdepth, uint32_t *bgra, hipStream_t s);
+void launch_untile_packed(const uint32_t *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, uint32_t *frame, hipStream_t s);
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s);
 
 // shard tile ownership: 32x32 tile (tx,ty) belongs to shard (tx + 5*ty) % count -- a diagonal interleave, so that

@@ -9,35 +9,6 @@
 
 namespace art {
 
-// float32 -> unsigned small float (5 exponent bits, MB mantissa bits), round to nearest even; negatives -> 0, overflow -> +Inf
-template <int MB> __host__ __device__ inline uint32_t pack_ufloat(float f) {
-    uint32_t u;
-#ifdef __HIP_DEVICE_COMPILE__
-    u = __float_as_uint(f);
-#else
-    std::memcpy(&u, &f, 4);
-#endif
-    uint32_t e8 = (u >> 23) & 255u, m = u & 0x7FFFFFu;
-    if (e8 == 255u && m) return (31u << MB) | 1u;
-    if (u >> 31) return 0;
-    if (e8 == 255u) return 31u << MB;
-    int e = (int)e8 - 127 + 15;
-    if (e >= 31) return 31u << MB;
-    int shift = 23 - MB;
-    uint32_t full = m | (e8 ? 0x800000u : 0u);
-    if (e <= 0) { shift += 1 - e; e = 0; if (shift > 31) return 0; } else full &= 0x7FFFFFu;
-    uint32_t q = full >> shift, rem = full & ((1u << shift) - 1u), half = 1u << (shift - 1);
-    if (rem > half || (rem == half && (q & 1u))) q++;
-    uint32_t out = ((uint32_t)e << MB) + q;
-    return out > (31u << MB) ? (31u << MB) : out;
-}
-template <int MB> __device__ inline float unpack_ufloat(uint32_t v) {
-    uint32_t e = v >> MB, m = v & ((1u << MB) - 1u);
-    if (e == 31u) return m ? __uint_as_float(0x7FC00000u) : __uint_as_float(0x7F800000u);
-    if (e == 0) return ldexpf((float)m, -14 - MB);
-    return ldexpf((float)(m | (1u << MB)), (int)e - 15 - MB);
-}
-__device__ inline uint32_t pack_b10g11r11(float r, float g, float b) { return pack_ufloat<6>(r) | (pack_ufloat<6>(g) << 11) | (pack_ufloat<5>(b) << 22); }
 __device__ inline uint16_t pack_f16(float f) {
     uint32_t u = __float_as_uint(f);
     uint32_t sign = (u >> 16) & 0x8000u, e8 = (u >> 23) & 255u, m = u & 0x7FFFFFu;

@@ -919,7 +919,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
         uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
         uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
-        st_nt(&a.color_tiles[(size_t)(p >> 10) * kTilePixels + ly * kTile + lx], o);
+        size_t ti = (size_t)(p >> 10) * kTilePixels + ly * kTile + lx;
+        if (a.tiles_packed) __builtin_nontemporal_store(pack_b10g11r11(o.x, o.y, o.z), reinterpret_cast<uint32_t *>(a.color_tiles) + ti);
+        else st_nt(&a.color_tiles[ti], o);
     }
     a.pix_bits[p] = sbits;
 }
@@ -961,12 +963,14 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
     if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
         uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
         uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
-        st_nt(&a.color_tiles[(size_t)(p >> 10) * kTilePixels + ly * kTile + lx], o);
+        size_t ti = (size_t)(p >> 10) * kTilePixels + ly * kTile + lx;
+        if (a.tiles_packed) __builtin_nontemporal_store(pack_b10g11r11(o.x, o.y, o.z), reinterpret_cast<uint32_t *>(a.color_tiles) + ti);
+        else st_nt(&a.color_tiles[ti], o);
     }
 }
 
 // root side of the gather: shard s's j-th tile sits at gathered[(s*padded + j) * 1024]
-__global__ __launch_bounds__(kBlock) void k_untile(const float4 *__restrict__ gathered, uint32_t shard_count, uint32_t padded, uint32_t W, uint32_t H, float4 *__restrict__ frame) {
+template <class T> __global__ __launch_bounds__(kBlock) void k_untile(const T *__restrict__ gathered, uint32_t shard_count, uint32_t padded, uint32_t W, uint32_t H, T *__restrict__ frame) {
     uint32_t tiles_x = (W + kTile - 1) / kTile;
     uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
     if (x >= W || y >= H) return;
@@ -1067,7 +1071,11 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, ui
 }
 void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
     dim3 g((W + 31) / 32, (H + 7) / 8);
-    k_untile<<<g, kBlock, 0, s>>>(gathered, shard_count ? shard_count : 1, padded_tiles, W, H, frame);
+    k_untile<float4><<<g, kBlock, 0, s>>>(gathered, shard_count ? shard_count : 1, padded_tiles, W, H, frame);
+}
+void launch_untile_packed(const uint32_t *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, uint32_t *frame, hipStream_t s) {
+    dim3 g((W + 31) / 32, (H + 7) / 8);
+    k_untile<uint32_t><<<g, kBlock, 0, s>>>(gathered, shard_count ? shard_count : 1, padded_tiles, W, H, frame);
 }
 
 } // namespace art

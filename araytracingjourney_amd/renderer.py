@@ -168,16 +168,17 @@ class Camera:
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
-    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False):
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False):
         self._L = _lib.load()
         w, h = extent
         cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
-                        flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0),
+                        flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0) | (_lib.ART_FLAG_PACKED_TILES if packed_tiles else 0),
                         frames_in_flight=frames_in_flight)
         self._ctx = C.c_void_p()
         check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))
         self.extent = (w, h)
         self.shard = shard
+        self.packed_tiles = packed_tiles
         # defaults of renderer.rs:222-231
         self._camera = Camera((0.0, 0.0, 0.0), (0.0, 0.0, 1.0), w / h, math.pi / 2, 0.1, 1000.0)
         self._lights = Lights()
@@ -343,7 +344,7 @@ class Renderer:
 
     def read_color_tiles(self):
         _, padded = self.shard_tile_count()
-        a = np.empty((padded, 32, 32, 4), np.float32)
+        a = np.empty((padded, 32, 32), np.uint32) if self.packed_tiles else np.empty((padded, 32, 32, 4), np.float32)
         check(self._L.art_read_color_tiles(self._ctx, _ptr(a), a.nbytes))
         return a
 

@@ -23,9 +23,10 @@ def shard_layout(width, height, shard_count, shard_rank):
 
 
 def untile_host(gathered, width, height, shard_count):
-    """numpy mirror of the k_untile kernel: gathered [shard_count, padded, 32, 32, C] -> frame [height, width, C]"""
+    """numpy mirror of the k_untile kernel: gathered [shard_count, padded, 32, 32, C] -> frame [height, width, C]
+    (or [shard_count, padded, 32, 32] -> [height, width] for packed B10G11R11 words)"""
     gathered = np.asarray(gathered)
-    frame = np.zeros((height, width, gathered.shape[-1]), gathered.dtype)
+    frame = np.zeros((height, width) + gathered.shape[4:], gathered.dtype)
     tiles_x = (width + TILE - 1) // TILE
     for s in range(shard_count):
         tiles, _ = shard_layout(width, height, shard_count, s)
@@ -42,7 +43,7 @@ def tile_host(frame, shard_count, shard_rank):
     frame = np.asarray(frame)
     height, width = frame.shape[:2]
     tiles, padded = shard_layout(width, height, shard_count, shard_rank)
-    out = np.zeros((padded, TILE, TILE, frame.shape[-1]), frame.dtype)
+    out = np.zeros((padded, TILE, TILE) + frame.shape[2:], frame.dtype)
     tiles_x = (width + TILE - 1) // TILE
     for j, t in enumerate(tiles):
         tx, ty = int(t) % tiles_x, int(t) // tiles_x

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
 
@@ -75,7 +76,8 @@ def main():
     lights = scenes.sponza_lights(args.lights)
     sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
     F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else 16
-    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F)
+    packed = world > 1 and args.gather == "packed"
+    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F, packed_tiles=packed)
     r.upload_state()
     stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
     torch.cuda.set_stream(stream)
@@ -84,12 +86,13 @@ def main():
     consumed = [None] * F             # per ring slot: event "the gather that read this slot's tiles has finished"
     if world > 1:
         owned, padded = r.shard_tile_count()
-        tiles = [torch.zeros((padded, 32, 32, 4), dtype=torch.float32, device="cuda") for _ in range(F)]
+        tshape, tdtype = ((padded, 32, 32), torch.int32) if packed else ((padded, 32, 32, 4), torch.float32)
+        tiles = [torch.zeros(tshape, dtype=tdtype, device="cuda") for _ in range(F)]
         for k in range(F):
             r.bind_color_tiles(k, tiles[k].data_ptr(), tiles[k].numel() * 4)
         if rank == 0:
-            gathered = [torch.empty((world, padded, 32, 32, 4), dtype=torch.float32, device="cuda") for _ in range(F)]
-            frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            gathered = [torch.empty((world,) + tshape, dtype=tdtype, device="cuda") for _ in range(F)]
+            frame = torch.zeros((H, W) if packed else (H, W, 4), dtype=tdtype, device="cuda")
         torch.cuda.synchronize()
 
     def step():
@@ -153,7 +156,11 @@ def main():
     if world > 1 and rank == 0:
         whole = renderer.renderer_for_scene(sc, (W, H), device=local_rank)
         whole.render_frame()
-        frame_ok = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), whole.read_color().view(np.uint32)))
+        if packed:   # the assembled frame is the packed colour image: against the single GPU's (art_present packs it, vk_rt_lightning_shadows.rs:152)
+            whole.present()
+            frame_ok = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), whole.read_packed()[0]))
+        else:
+            frame_ok = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), whole.read_color().view(np.uint32)))
         whole.close()
     t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["primary_ms"], stage["shadow_ms"], stage["shade_ms"], stage["frame_ms"], iso["primary_ms"], iso["shadow_ms"]],
                      dtype=torch.float64, device="cuda")
@@ -247,7 +254,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"sponza_like(seed=0x5A0A, {sc.n_tris} triangles, 25 primitives) {W}x{H}, {args.lights} light(s), "
                                f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather to rank 0") + f", {F} frames in flight"},
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0") + f", {F} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F, "hip_graph_replay": use_graph,
         "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "build_ms": st["build_ms"],
         "gathered_frame_equals_single_gpu_frame": frame_ok,

@@ -156,6 +156,35 @@ def test_sharded_tiles_gather_to_the_unsharded_frame(R, get_scene):
         s.close()
 
 
+def test_packed_tiles_gather_to_the_packed_colour_image(R, get_scene):
+    """ART_FLAG_PACKED_TILES: the gather payload is B10G11R11 (the reference's colour image format, renderer.rs:268), 4 B per pixel;
+    un-tiled on shard 0 it equals the packed colour of the unsharded frame; fused and staged frames"""
+    import torch
+    sc = get_scene("cornell")
+    w, h, G = 200, 136, 3
+    whole = R.renderer_for_scene(sc, (w, h))
+    whole.render_frame()
+    whole.present()
+    want = whole.read_packed()[0]
+    for fif in (4, 1):
+        shards = [R.renderer_for_scene(sc, (w, h), shard=(k, G), packed_tiles=True, frames_in_flight=fif) for k in range(G)]
+        bufs = []
+        for s in shards:
+            s.render_frame()
+            bufs.append(s.read_color_tiles())
+        assert bufs[0].dtype == np.uint32 and bufs[0].shape[1:] == (32, 32)
+        gathered = torch.from_numpy(np.concatenate(bufs).view(np.int32)).cuda()
+        frame = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        shards[0].untile_gathered(gathered.data_ptr(), G, frame.data_ptr())
+        shards[0].sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), want), fif
+        for s in shards:
+            s.close()
+    whole.close()
+
+
 @pytest.mark.parametrize("name,detail,size,spp", [("cornell", 1.0, (256, 256), 16), ("sponza_like", 0.12, (480, 270), 16), ("sponza_like", 0.12, (200, 120), 5)])
 def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp):
     """BASELINE config 5's pass: AO rays from the frame's depth + normal outputs; the 0..255 output is an integer: bit-exact"""

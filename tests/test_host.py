@@ -128,9 +128,14 @@ gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
 dist.gather(mine, gathered, dst=0)                                                 # the one exchange step of a frame
 rays = torch.tensor([float(len(owned) * 1024)], dtype=torch.float64)
 dist.all_reduce(rays)                                                              # whole-job ray count, as bench.py does
+packed = (np.arange(w * h, dtype=np.uint32).reshape(h, w) * np.uint32(2654435761))   # the B10G11R11 payload: one word per pixel
+pmine = torch.from_numpy(sharding.tile_host(packed, world, rank).view(np.int32))
+pgathered = [torch.empty_like(pmine) for _ in range(world)] if rank == 0 else None
+dist.gather(pmine, pgathered, dst=0)
 if rank == 0:
     got = sharding.untile_host(torch.stack(gathered).numpy(), w, h, world)
     assert np.array_equal(got, frame)
+    assert np.array_equal(sharding.untile_host(torch.stack(pgathered).numpy().view(np.uint32), w, h, world), packed)
     assert rays.item() == ((w + 31) // 32) * ((h + 31) // 32) * 1024
     print("GLOO_OK")
 dist.barrier()
