@@ -102,6 +102,7 @@ SYMBOLS = {
     "art_collect_timings": (_I32, [_P, _P, _P]),
     "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
     "art_untile_gathered": (_I32, [_P, _P, _U32, _P, _P]),
+    "art_untile_gathered_strided": (_I32, [_P, _P, _U32, _U32, _P, _P]),
     "art_get_stats": (_I32, [_P, _P]),
     "art_read_hits": (_I32, [_P, _P, _P, _SZ]),
     "art_read_shadow_bits": (_I32, [_P, _P, _SZ]),

@@ -778,8 +778,9 @@ int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
     FrameSlot *S = c ? &c->slot[c->last] : nullptr;
     return read_back(c, S ? (S->ext_tiles ? S->ext_tiles : S->d_color_tiles.p) : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() : 0, dst, bytes, "art_read_color_tiles");
 }
-int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream) {
+int32_t art_untile_gathered_strided(ArtContext *c, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, void *frame_dev, void *hip_stream) {
     if (!c || !gathered_dev) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
+    if (shard_stride_tiles < c->padded_tiles) return fail(ART_E_INVALID, "art_untile_gathered_strided: stride smaller than a shard's padded tile count");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_untile_gathered"); if (r) return r;
     if (shard_count != (c->cfg.shard_count > 1 ? c->cfg.shard_count : 1)) return fail(ART_E_INVALID, "art_untile_gathered: shard_count differs from the context's");
     r = use_device(c); if (r) return r;
@@ -787,12 +788,17 @@ int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t sh
     if (c->tiles_packed()) { // the gathered tiles are B10G11R11 words: the frame is the packed colour image (art_read_packed)
         FrameSlot &S = c->slot[c->last];
         if (!frame_dev && S.d_pcolor.n < (size_t)c->W * c->H) { HIPC(hipStreamSynchronize(us)); HIPC(S.d_pcolor.ensure((size_t)c->W * c->H)); }
-        launch_untile_packed((const uint32_t *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (uint32_t *)frame_dev : S.d_pcolor.p, us);
+        launch_untile_packed((const uint32_t *)gathered_dev, shard_count, shard_stride_tiles, c->W, c->H, frame_dev ? (uint32_t *)frame_dev : S.d_pcolor.p, us);
     } else
-    launch_untile((const float4 *)gathered_dev, shard_count, c->padded_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->slot[c->last].d_color.p, us);
+    launch_untile((const float4 *)gathered_dev, shard_count, shard_stride_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->slot[c->last].d_color.p, us);
     HIPC(hipGetLastError());
     c->traced = true;
     return ART_OK;
+}
+
+int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream) {
+    if (!c) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
+    return art_untile_gathered_strided(c, gathered_dev, shard_count, c->padded_tiles, frame_dev, hip_stream);
 }
 
 int32_t art_get_stats(ArtContext *c, ArtStats *out) {

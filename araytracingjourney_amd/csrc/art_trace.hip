@@ -970,7 +970,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
 }
 
 // root side of the gather: shard s's j-th tile sits at gathered[(s*padded + j) * 1024]
-template <class T> __global__ __launch_bounds__(kBlock) void k_untile(const T *__restrict__ gathered, uint32_t shard_count, uint32_t padded, uint32_t W, uint32_t H, T *__restrict__ frame) {
+template <class T> __global__ __launch_bounds__(kBlock) void k_untile(const T *__restrict__ gathered, uint32_t shard_count, uint32_t shard_stride, uint32_t W, uint32_t H, T *__restrict__ frame) {
     uint32_t tiles_x = (W + kTile - 1) / kTile;
     uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y = blockIdx.y * 8u + (threadIdx.x >> 5);
     if (x >= W || y >= H) return;
@@ -984,7 +984,7 @@ template <class T> __global__ __launch_bounds__(kBlock) void k_untile(const T *_
         uint32_t first = (s + shard_count - (5u * yy) % shard_count) % shard_count;
         if (xe > first) j += (xe - first + shard_count - 1) / shard_count;
     }
-    frame[(size_t)y * W + x] = gathered[((size_t)s * padded + j) * kTilePixels + (y % kTile) * kTile + (x % kTile)];
+    frame[(size_t)y * W + x] = gathered[((size_t)s * shard_stride + j) * kTilePixels + (y % kTile) * kTile + (x % kTile)]; // shard_stride: tiles between two shards' buffers
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

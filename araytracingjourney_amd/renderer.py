@@ -353,7 +353,11 @@ class Renderer:
         check(self._L.art_shard_tile_count(self._ctx, C.byref(o), C.byref(pd)))
         return o.value, pd.value
 
-    def untile_gathered(self, gathered_dev_ptr, shard_count, frame_dev_ptr=None, hip_stream_ptr=None):
+    def untile_gathered(self, gathered_dev_ptr, shard_count, frame_dev_ptr=None, hip_stream_ptr=None, shard_stride_tiles=None):
+        if shard_stride_tiles is not None:
+            check(self._L.art_untile_gathered_strided(self._ctx, C.c_void_p(gathered_dev_ptr), shard_count, shard_stride_tiles,
+                                                      C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None, C.c_void_p(hip_stream_ptr) if hip_stream_ptr else None))
+            return
         check(self._L.art_untile_gathered(self._ctx, C.c_void_p(gathered_dev_ptr), shard_count, C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None,
                                           C.c_void_p(hip_stream_ptr) if hip_stream_ptr else None))
 

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-frames", type=int, default=4, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
     ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
@@ -83,21 +84,25 @@ def main():
     torch.cuda.set_stream(stream)
 
     tiles = gathered = frame = None
+    GB = 1
     consumed = [None] * F             # per ring slot: event "the gather that read this slot's tiles has finished"
     if world > 1:
         owned, padded = r.shard_tile_count()
+        GB = max(1, min(args.gather_frames, F))
+        while F % GB:                 # whole gather groups per trip round the ring
+            GB -= 1
         tshape, tdtype = ((padded, 32, 32), torch.int32) if packed else ((padded, 32, 32, 4), torch.float32)
-        tiles = [torch.zeros(tshape, dtype=tdtype, device="cuda") for _ in range(F)]
+        tiles = torch.zeros((F,) + tshape, dtype=tdtype, device="cuda")      # slot k renders into tiles[k]: GB slots = one contiguous message
         for k in range(F):
             r.bind_color_tiles(k, tiles[k].data_ptr(), tiles[k].numel() * 4)
         if rank == 0:
-            gathered = [torch.empty((world,) + tshape, dtype=tdtype, device="cuda") for _ in range(F)]
+            gathered = torch.empty((world, F) + tshape, dtype=tdtype, device="cuda")   # [peer][slot]: a frame's shards are F * padded tiles apart
             frame = torch.zeros((H, W) if packed else (H, W, 4), dtype=tdtype, device="cuda")
         torch.cuda.synchronize()
 
     def step():
         if world == 1:
-            r.trace()                 # primary + shade + shadow + accumulate on the next ring slot's stream
+            r.trace()                 # the whole frame (one fused launch; four staged ones with one frame in flight) on the next ring slot's stream
             if args.ao:
                 r.trace_ao(args.ao)
             return
@@ -107,22 +112,38 @@ def main():
         r.trace()
         if args.ao:
             r.trace_ao(args.ao)                             # per tile from the local G-buffer: no extra exchange
-        r.stream_wait_frame(stream.cuda_stream)             # torch's stream (hence RCCL) waits for this frame only
+        r.stream_wait_frame(stream.cuda_stream)             # torch's stream (hence RCCL) waits for this frame
+        pending[1] += 1
+        if pending[1] == GB or k + 1 == F:                  # the exchange runs once per GB frames (never across the ring's wrap: one contiguous slice)
+            exchange()
+
+    pending = [0, 0]                  # first slot and number of frames traced but not yet gathered
+
+    def exchange():
+        k0, n = pending
+        if n == 0:
+            return
+        pending[0], pending[1] = (k0 + n) % F, 0
         if args.backend == "nccl":
-            dist.gather(tiles[k], list(gathered[k].unbind(0)) if rank == 0 else None, dst=0)
+            dist.gather(tiles[k0:k0 + n], [gathered[w, k0:k0 + n] for w in range(world)] if rank == 0 else None, dst=0)
         else:   # rehearsal: same call sequence, payload through host memory
-            host = tiles[k].cpu()
+            host = tiles[k0:k0 + n].cpu()
             parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
             dist.gather(host, parts, dst=0)
             if rank == 0:
-                gathered[k].copy_(torch.stack(parts))
+                for w in range(world):
+                    gathered[w, k0:k0 + n].copy_(parts[w])
         if rank == 0:
-            r.untile_gathered(gathered[k].data_ptr(), world, frame.data_ptr(), stream.cuda_stream)
+            for j in range(k0, k0 + n):                     # the root keeps the newest frame; every frame is un-tiled
+                r.untile_gathered(gathered[0, j].data_ptr(), world, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * padded)
         ev = torch.cuda.Event()
         ev.record(stream)
-        consumed[k] = ev
+        for j in range(k0, k0 + n):
+            consumed[j] = ev
 
     def fence():
+        if world > 1:
+            exchange()                # frames still waiting for their group: the timed region ends with every frame on the root
         r.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -254,7 +275,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"sponza_like(seed=0x5A0A, {sc.n_tris} triangles, 25 primitives) {W}x{H}, {args.lights} light(s), "
                                f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0") + f", {F} frames in flight"},
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {GB} frames per gather") + f", {F} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F, "hip_graph_replay": use_graph,
         "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "build_ms": st["build_ms"],
         "gathered_frame_equals_single_gpu_frame": frame_ok,

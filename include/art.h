@@ -197,6 +197,9 @@ int32_t art_bind_color_tiles(ArtContext *ctx, uint32_t slot, void *dev_ptr, size
 int32_t art_read_color_tiles(ArtContext *ctx, void *dst, size_t bytes); /* host copy of the same buffer (tests) */
 /* frame_dev NULL = the context's colour buffer; hip_stream NULL = the latest frame's stream */
 int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream);
+/* the same with shard s's tiles at gathered + s * shard_stride_tiles tiles: several frames gathered by ONE collective leave each
+ * rank's frames back to back, so consecutive shards of one frame are a whole block of frames apart */
+int32_t art_untile_gathered_strided(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, void *frame_dev, void *hip_stream);
 
 int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
 /* device time per stage (HIP events on the context's stream) summed over the frames traced since the previous call
