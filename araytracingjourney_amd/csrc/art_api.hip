@@ -293,9 +293,8 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
         for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[f][i]);
     if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
     c->W = cfg->width; c->H = cfg->height;
-    // one frame at a time is bound by the slowest wave: per-ray walks (binary for primary, 4-wide for shadow) have the shorter
-    // critical path; with several frames in flight the packet walks' lower instruction count wins (profiles/README.md)
-    if (c->F == 1) { c->kind_primary = 2; c->kind_shadow = 4; }
+    // the fused packet frame is the default at every ring depth (one frame at a time: 0.575 ms against 0.669 ms for the staged per-ray
+    // kernels, profiles/README.md r1h); ART_BVH=24 selects the per-ray walks (binary for primary rays, 4-wide for shadow rays)
     if (const char *pw = std::getenv("ART_PACKET_WIDE")) c->packet_wide = std::atoi(pw) != 0;
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
     if (const char *sh = std::getenv("ART_SAH")) c->fast_trace = std::atoi(sh) != 0;

@@ -50,9 +50,21 @@ def test_ray_queries_match_oracle_bitwise(R, orc, get_scene, name, detail):
     r.close()
 
 
-def _frame_parity(R, orc, sc, w, h, n_lights, frames_in_flight=1):
-    # frames_in_flight 1: per-ray walks (latency preset); > 1: packet walks for primary and shadow rays (throughput preset)
-    r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True, frames_in_flight=frames_in_flight)
+FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"ART_FUSED": "0"}), "per-ray": (1, {"ART_BVH": "24"})}
+
+
+def _frame_parity(R, orc, sc, w, h, n_lights, form="fused"):
+    # the three forms of the frame: one fused launch (packet walks), four staged launches (packet walks), four staged launches with
+    # the per-ray walks (binary for primary rays, 4-wide for shadow rays)
+    import os
+    fif, env = FORMS[form]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True, frames_in_flight=fif)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
     r.render_frame()
     S, L, nl = oracle_for(orc, sc, n_lights)
     ref = S.render(oracle_camera(orc, sc, w, h), L, nl, w, h, threads=8, debug=True)
@@ -72,27 +84,27 @@ def _frame_parity(R, orc, sc, w, h, n_lights, frames_in_flight=1):
     return ref
 
 
-@pytest.mark.parametrize("frames_in_flight", [1, 3])
-def test_cornell_frame_matches_oracle(R, orc, get_scene, frames_in_flight):
-    ref = _frame_parity(R, orc, get_scene("cornell"), 256, 256, None, frames_in_flight)
+@pytest.mark.parametrize("form", ["fused", "fused-1", "staged", "per-ray"])
+def test_cornell_frame_matches_oracle(R, orc, get_scene, form):
+    ref = _frame_parity(R, orc, get_scene("cornell"), 256, 256, None, form)
     assert ref["stats"]["shadow_rays"] > 1000
 
 
-@pytest.mark.parametrize("frames_in_flight", [1, 3])
+@pytest.mark.parametrize("form", ["fused", "staged", "per-ray"])
 @pytest.mark.parametrize("n_lights", [1, 4])
-def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights, frames_in_flight):
+def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights, form):
     sc = get_scene("sponza_like", 0.12)
     if n_lights == 4:
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, scenes.sponza_lights(4))
-    ref = _frame_parity(R, orc, sc, 480, 270, None, frames_in_flight)
+    ref = _frame_parity(R, orc, sc, 480, 270, None, form)
     assert ref["stats"]["shadow_rays"] > 10000
 
 
 def test_config2_full_size_frame_matches_oracle(R, orc, get_scene):
     """BASELINE config 2 at its real size: 262 816 triangles, 1920x1080, one directional light"""
     import json, os
-    _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, frames_in_flight=1)
-    ref = _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, frames_in_flight=4)   # the packet walks, as bench.py runs them
+    _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, "per-ray")
+    ref = _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, "fused")   # the fused frame, as bench.py runs it
     fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_sponza_like_1080p_1light.stats.json")))
     for k in ("primary_rays", "shadow_rays", "hit_pixels", "n_int_primary", "n_tri_primary", "n_int_shadow", "n_tri_shadow"):
         assert ref["stats"][k] == fx[k], k       # the committed visit counters bench.py prices the roofline with
@@ -116,7 +128,7 @@ def test_config4_bistro_class_scene(R, orc, get_scene):
     seen = np.bincount(idx.reshape(-1), minlength=2 * T - 1)
     assert seen[0] == 0 and np.all(seen[1:] == 1)                # every node and leaf has exactly one parent
     r.close()
-    _frame_parity(R, orc, sc, 960, 540, None, frames_in_flight=2)
+    _frame_parity(R, orc, sc, 960, 540, None, "fused")
 
 
 def test_ragged_extent_and_resize(R, orc, get_scene):
@@ -216,9 +228,9 @@ def test_glb_ingest_feeds_the_same_frame(R, get_scene, tmp_path):
     sc = get_scene("cornell")
     path = tmp_path / "cornell.glb"
     write_glb(str(path), sc.primitives, png_modes=("RGBA", "RGBA", "RGBA"))
-    direct = R.renderer_for_scene(sc, (128, 128))
+    direct = R.renderer_for_scene(sc, (128, 128), keep_debug=True)
     direct.render_frame()
-    g = R.Renderer((128, 128))
+    g = R.Renderer((128, 128), keep_debug=True)
     ids = g.add_model_glb(mr.GltfModelReader(str(path), True, mr.COERCE_B8G8R8A8), sc.primitives[0].model)
     assert ids == [0, 1, 2]
     cam = g.camera_mut()
@@ -300,8 +312,8 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
         return out
     ref = frame(4)                                               # fused, SAH (the default with several frames in flight)
     assert ref[3]["frame_launches"] == 1 and ref[3]["shadow_rays"] > 10000
-    for name, got in (("staged packets", frame(4, env={"ART_FUSED": "0"})), ("per-ray", frame(1)),
-                      ("fused on the LBVH topology", frame(4, fast_build=True)), ("per-ray on the LBVH topology", frame(1, fast_build=True)),
+    for name, got in (("staged packets", frame(4, env={"ART_FUSED": "0"})), ("per-ray", frame(1, env={"ART_BVH": "24"})), ("fused, one frame in flight", frame(1)),
+                      ("fused on the LBVH topology", frame(4, fast_build=True)), ("per-ray on the LBVH topology", frame(1, fast_build=True, env={"ART_BVH": "24"})),
                       ("fused, 7 waves/SIMD", frame(4, env={"ART_FRAME_WAVES": "7"})), ("fused, no block reordering", frame(4, env={"ART_MACRO": "0"}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
