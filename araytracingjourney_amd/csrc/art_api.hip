@@ -23,6 +23,7 @@ struct HostPrim {
     std::vector<uint8_t> tex;
     uint32_t tw, th;
     float o2w[12], w2o[12];
+    bool enabled = true; // instanced in the acceleration structure (the reference's Device state, vk_model.rs:334-345); else kept on the host only
 };
 
 template <class T> struct DevBuf {
@@ -367,30 +368,58 @@ int32_t art_scene_clear(ArtContext *c) {
     return ART_OK;
 }
 
+int32_t art_scene_set_primitive_enabled(ArtContext *c, uint32_t id, int32_t enabled) {
+    if (!c) return fail(ART_E_INVALID, "art_scene_set_primitive_enabled: null context");
+    if (id >= c->prims.size()) return fail(ART_E_INVALID, "art_scene_set_primitive_enabled: no such primitive");
+    if (c->prims[id].enabled != (enabled != 0)) { c->prims[id].enabled = enabled != 0; c->built = false; } // takes effect at the next art_scene_build
+    return ART_OK;
+}
+
 int32_t art_scene_build(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "art_scene_build: null context");
     if (c->prims.empty()) return fail(ART_E_STATE, "art_scene_build: no primitives");
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
     lbvh_free(c->bvh); c->built = false; drop_graphs(c);
-    size_t nv = 0, ib = 0, nt = 0; uint32_t T = 0;
-    for (auto &p : c->prims) { nv += p.verts.size(); ib += (p.indices.size() + 15) & ~(size_t)15; nt += (size_t)3 * p.tw * p.th; }
+    // Only enabled primitives are uploaded and instanced (get_acceleration_structure_instance returns None unless the model is in
+    // the Device state, vk_model.rs:360-372).  Ids keep their meaning: a disabled primitive stays in the table with zero triangles.
+    // With nothing enabled the tree is one zero-area triangle that no ray can hit (an empty TLAS: every ray misses).
+    static const ArtVertex kNoVertex{};
+    static const uint16_t kNoIndex[3] = {0, 0, 0};
+    static const uint8_t kNoTexel[12] = {0};
+    bool any = false;
+    for (auto &p : c->prims) any = any || (p.enabled && p.n_indices >= 3);
+    size_t nv = any ? 0 : 1, ib = any ? 0 : 16, nt = any ? 0 : 3; uint32_t T = 0;
+    for (auto &p : c->prims) if (p.enabled) { nv += p.verts.size(); ib += (p.indices.size() + 15) & ~(size_t)15; nt += (size_t)3 * p.tw * p.th; }
     HIPC(c->d_verts.ensure(nv * 12)); HIPC(c->d_indices.ensure(ib)); HIPC(c->d_tex.ensure(nt));
-    std::vector<DevPrim> dp(c->prims.size());
-    std::vector<uint32_t> first(c->prims.size());
+    std::vector<DevPrim> dp(c->prims.size() + (any ? 0 : 1));
+    std::vector<uint32_t> first(dp.size());
     size_t ov = 0, oi = 0, ot = 0;
     for (size_t k = 0; k < c->prims.size(); k++) {
         auto &p = c->prims[k];
+        DevPrim &d = dp[k];
+        std::memset(&d, 0, sizeof(d));
+        d.vertices = c->d_verts.p + ov * 12; d.indices = c->d_indices.p + oi; d.texture_offset = (uint32_t)ot; d.single_index_size = p.idx_bytes;
+        d.tw = p.tw; d.th = p.th; d.first_tri = T; d.n_tri = p.enabled ? p.n_indices / 3 : 0;
+        std::memcpy(d.o2w, p.o2w, 48); std::memcpy(d.w2o, p.w2o, 48);
+        first[k] = T;
+        if (!p.enabled) continue;
         HIPC(hipMemcpy(c->d_verts.p + ov * 12, p.verts.data(), p.verts.size() * 48, hipMemcpyHostToDevice));
         HIPC(hipMemcpy(c->d_indices.p + oi, p.indices.data(), p.indices.size(), hipMemcpyHostToDevice));
         HIPC(hipMemcpy(c->d_tex.p + ot, p.tex.data(), p.tex.size(), hipMemcpyHostToDevice));
-        DevPrim &d = dp[k];
-        d.vertices = c->d_verts.p + ov * 12; d.indices = c->d_indices.p + oi; d.texture_offset = (uint32_t)ot; d.single_index_size = p.idx_bytes;
-        d.tw = p.tw; d.th = p.th; d.first_tri = T; d.n_tri = p.n_indices / 3;
-        std::memcpy(d.o2w, p.o2w, 48); std::memcpy(d.w2o, p.w2o, 48);
-        first[k] = T;
         T += d.n_tri;
         ov += p.verts.size(); oi += (p.indices.size() + 15) & ~(size_t)15; ot += (size_t)3 * p.tw * p.th;
+    }
+    if (!any) {
+        DevPrim &d = dp.back();
+        std::memset(&d, 0, sizeof(d));
+        HIPC(hipMemcpy(c->d_verts.p, &kNoVertex, 48, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(c->d_indices.p, kNoIndex, 6, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(c->d_tex.p, kNoTexel, 12, hipMemcpyHostToDevice));
+        d.vertices = c->d_verts.p; d.indices = c->d_indices.p; d.texture_offset = 0; d.single_index_size = 2; d.tw = 1; d.th = 1; d.first_tri = T; d.n_tri = 1;
+        d.o2w[0] = d.o2w[5] = d.o2w[10] = 1.0f; d.w2o[0] = d.w2o[5] = d.w2o[10] = 1.0f;
+        first.back() = T;
+        T += 1;
     }
     HIPC(c->d_prims.ensure(dp.size())); HIPC(c->d_first_tri.ensure(first.size()));
     HIPC(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DevPrim), hipMemcpyHostToDevice));

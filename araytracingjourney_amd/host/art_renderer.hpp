@@ -105,8 +105,37 @@ public:
 };
 
 // ---- renderer.rs ------------------------------------------------------------------------------------------------------
+// ---- model_reader.rs:100-146 + vk_model.rs:280-345: bounding sphere and the residency state machine ----------------------
+struct Sphere {
+    Vector3 center{0, 0, 0}; float radius = 0;
+    float get_distance_from_point(const Vector3 &p) const { // model_reader.rs:124-126
+        float dx = center[0] - p[0], dy = center[1] - p[1], dz = center[2] - p[2];
+        return std::sqrt(dx * dx + dy * dy + dz * dz) - radius;
+    }
+    Sphere transform(const Matrix3x4 &m) const {              // model_reader.rs:128-141
+        float sc = 0;
+        for (int k = 0; k < 3; k++) sc = std::fmax(sc, std::sqrt(m[k] * m[k] + m[4 + k] * m[4 + k] + m[8 + k] * m[8 + k]));
+        Sphere o;
+        for (int r = 0; r < 3; r++) o.center[r] = m[4 * r] * center[0] + m[4 * r + 1] * center[1] + m[4 * r + 2] * center[2] + m[4 * r + 3];
+        o.radius = sc * radius;
+        return o;
+    }
+};
+enum class ModelState { Storage, Host, Device };
+struct Model { // VkModel: only Device models are instanced in the acceleration structure (renderer.rs:640-651)
+    std::vector<uint32_t> primitive_ids; Sphere model_bounding_sphere; ModelState state = ModelState::Host; bool needs_cb_submit = false, instanced = true;
+    void update_model_status(const Vector3 &camera_pos) { // vk_model.rs:334-345
+        float d = model_bounding_sphere.get_distance_from_point(camera_pos);
+        ModelState want = d <= 10.0f ? ModelState::Device : (d <= 20.0f ? ModelState::Host : ModelState::Storage);
+        if ((want == ModelState::Device) != (state == ModelState::Device)) needs_cb_submit = true;
+        state = want;
+    }
+    bool needs_command_buffer_submission() const { return needs_cb_submit; }
+    void reset_command_buffer_submission_status() { needs_cb_submit = false; }
+};
+
 class Renderer {
-    ArtContext *ctx_ = nullptr; uint32_t w_, h_; Camera camera_; Lights lights_;
+    ArtContext *ctx_ = nullptr; uint32_t w_, h_; Camera camera_; Lights lights_; std::vector<Model> models_;
 public:
     // VulkanTempleRayTracedRenderer::new (renderer.rs:140); camera defaults of renderer.rs:222-231
     Renderer(uint32_t width, uint32_t height, int device = -1, uint32_t frames_in_flight = 1)
@@ -118,15 +147,36 @@ public:
     ~Renderer() { if (ctx_) art_destroy(ctx_); }
     void add_model(const std::string &file_path, const Matrix3x4 &model_matrix) { // renderer.rs:346 -> vk_model.rs:494-528
         GltfModelReader r = GltfModelReader::open(file_path, true, GltfModelReader::B8G8R8A8_UNORM);
-        check_glb(art_scene_add_glb(ctx_, r.handle(), model_matrix.data(), nullptr, nullptr));
+        uint32_t first = 0, n = 0;
+        check_glb(art_scene_add_glb(ctx_, r.handle(), model_matrix.data(), &first, &n));
+        Model m;
+        for (uint32_t i = 0; i < n; i++) m.primitive_ids.push_back(first + i);
+        auto cs = r.get_primitives_bounding_sphere();                      // vk_model.rs:501, then set_model_matrix (:461-466)
+        Sphere sp; sp.center = cs.first; sp.radius = cs.second;
+        m.model_bounding_sphere = sp.transform(model_matrix);
+        models_.push_back(m);
+    }
+    std::vector<Model> &models_mut() { return models_; }
+    // renderer.rs:637-651: residency by camera distance; rebuilds the acceleration structure over the Device models when the set changed
+    bool update_models_status(bool build = true) {
+        bool changed = false;
+        for (Model &m : models_) {
+            m.update_model_status(camera_.pos());
+            m.reset_command_buffer_submission_status();
+            bool dev = m.state == ModelState::Device;
+            if (dev != m.instanced) { m.instanced = dev; for (uint32_t id : m.primitive_ids) check(art_scene_set_primitive_enabled(ctx_, id, dev ? 1 : 0)); changed = true; }
+        }
+        if (changed && build) check(art_scene_build(ctx_));
+        return changed && build;
     }
     void add_primitive(const ArtVertex *v, uint32_t nv, const void *idx, uint32_t n_idx, uint32_t idx_bytes, const uint8_t *rgba8, uint32_t tw, uint32_t th, const Matrix3x4 &m) {
         check(art_scene_add_primitive(ctx_, v, nv, idx, n_idx, idx_bytes, rgba8, tw, th, m.data(), nullptr));
     }
-    void prepare_first_frame() { check(art_scene_build(ctx_)); }          // renderer.rs:356
+    void prepare_first_frame() { update_models_status(false); check(art_scene_build(ctx_)); } // renderer.rs:356
     Camera &camera_mut() { return camera_; }                              // renderer.rs:515
     Lights &lights_mut() { return lights_; }                              // renderer.rs:519
     void render_frame(bool wait = true) {                                  // renderer.rs:371
+        update_models_status();
         check(art_set_camera(ctx_, &camera_.update_host_buffer()));
         std::vector<ArtLight> ls = lights_.copy_lights_shader_data();
         check(art_set_lights(ctx_, ls.data(), (uint32_t)ls.size()));

@@ -165,6 +165,50 @@ class Camera:
 
 
 # ------------------------------------------------------------------------------------------------ renderer (renderer.rs)
+class Sphere:
+    """model_reader.rs:100-146"""
+
+    def __init__(self, center, radius):
+        self.center, self.radius = np.asarray(center, np.float32), float(radius)
+
+    def get_distance_from_point(self, point):  # model_reader.rs:124-126
+        return float(np.linalg.norm(self.center - np.asarray(point, np.float32))) - self.radius
+
+    def transform(self, m):  # model_reader.rs:128-141; m: row-major 3x4
+        m = np.asarray(m, np.float32).reshape(3, 4)
+        scale = max(float(np.linalg.norm(m[:, k])) for k in range(3))
+        return Sphere(m[:, :3] @ self.center + m[:, 3], scale * self.radius)
+
+
+STORAGE, HOST, DEVICE = "Storage", "Host", "Device"
+
+
+class Model:
+    """VkModel's residency state machine (vk_model.rs:280-345, states :27-275): Storage <-> Host <-> Device by the distance between the
+    camera and the model's bounding sphere.  Only Device models are instanced in the acceleration structure (renderer.rs:640-651)."""
+
+    def __init__(self, primitive_ids, sphere, reload=None):
+        self.primitive_ids = list(primitive_ids)
+        self.model_bounding_sphere = sphere
+        self.state = HOST                       # VkModel::new goes Storage -> Host (vk_model.rs:324-329)
+        self.needs_cb_submit = False            # a transition to or from Device changes what the next build must contain
+        self._reload = reload                   # Storage -> Host: how to read the model again (GLB path), None for in-memory models
+        self._instanced = True                  # libart instances a primitive from the moment it is added
+
+    def update_model_status(self, camera_pos):  # vk_model.rs:334-345
+        d = self.model_bounding_sphere.get_distance_from_point(camera_pos)
+        want = DEVICE if d <= 10.0 else (HOST if d <= 20.0 else STORAGE)
+        if (want == DEVICE) != (self.state == DEVICE):
+            self.needs_cb_submit = True
+        self.state = want
+
+    def needs_command_buffer_submission(self):
+        return self.needs_cb_submit
+
+    def reset_command_buffer_submission_status(self):
+        self.needs_cb_submit = False
+
+
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
@@ -209,7 +253,12 @@ class Renderer:
             check(self._L.art_scene_add_primitive(self._ctx, _ptr(verts), verts.shape[0], _ptr(idx), idx.size, idx.dtype.itemsize, _ptr(tex),
                                                   tex.shape[2], tex.shape[1], _ptr(m), C.byref(pid)))
             ids.append(pid.value)
-        self._models.append(ids)
+        lo = np.min([np.asarray(p.verts)[:, :3].min(0) for p in primitives], 0)
+        hi = np.max([np.asarray(p.verts)[:, :3].max(0) for p in primitives], 0)
+        c = 0.5 * (lo + hi)
+        rad = max(float(np.linalg.norm(np.asarray(p.verts)[:, :3] - c, axis=1).max()) for p in primitives)
+        mm = model_matrix if model_matrix is not None else primitives[0].model
+        self._models.append(Model(ids, Sphere(c, rad).transform(mm)))
         return ids
 
     def add_model_glb(self, reader, model_matrix):
@@ -220,7 +269,8 @@ class Renderer:
         if r != 0:
             raise _lib.ArtError(r, self._L.art_glb_last_error().decode("utf-8", "replace"))
         ids = list(range(first.value, first.value + n.value))
-        self._models.append(ids)
+        c, rad = reader.get_primitives_bounding_sphere()   # vk_model.rs:501, then set_model_matrix (:461-466)
+        self._models.append(Model(ids, Sphere(c, rad).transform(model_matrix)))
         return ids
 
     def models_mut(self):
@@ -233,7 +283,24 @@ class Renderer:
         return self._lights
 
     def prepare_first_frame(self):  # renderer.rs:356: uploads + BLAS/TLAS builds
+        self.update_models_status(build=False)
         check(self._L.art_scene_build(self._ctx))
+
+    def update_models_status(self, build=True):
+        """renderer.rs:637-651: every model decides its residency from the camera position; the acceleration structure is rebuilt over the
+        Device models when that set changed.  Returns True when it was rebuilt."""
+        changed = False
+        for m in self._models:
+            m.update_model_status(self._camera.pos())
+            m.reset_command_buffer_submission_status()
+            if (m.state == DEVICE) != m._instanced:      # what libart holds differs from the model's state
+                m._instanced = m.state == DEVICE
+                for pid in m.primitive_ids:
+                    check(self._L.art_scene_set_primitive_enabled(self._ctx, pid, 1 if m._instanced else 0))
+                changed = True
+        if changed and build:
+            check(self._L.art_scene_build(self._ctx))
+        return changed and build
 
     def set_stream(self, hip_stream_ptr):
         check(self._L.art_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))
@@ -280,6 +347,7 @@ class Renderer:
         return c, n, d
 
     def render_frame(self, sync=True):  # renderer.rs:371
+        self.update_models_status()
         self.upload_state()
         self.trace()
         if sync:

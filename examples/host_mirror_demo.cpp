@@ -21,6 +21,16 @@ static int host_checks() {
     bool panicked = false;
     try { GltfModelReader::open("/nonexistent.glb", true, GltfModelReader::B8G8R8A8_UNORM); } catch (const Panic &p) { panicked = std::strstr(p.what(), "Could not read file") != nullptr; }
     if (!panicked) { std::puts("FAIL missing file must panic"); return 1; }
+    // residency state machine with the camera positions of the reference's own test (vk_model.rs:1082-1152)
+    Model m; m.model_bounding_sphere.radius = 1.0f;
+    m.update_model_status({100, 100, 100}); if (m.state != ModelState::Storage || m.needs_command_buffer_submission()) { std::puts("FAIL residency storage"); return 1; }
+    m.update_model_status({7, 7, 7});       if (m.state != ModelState::Host || m.needs_command_buffer_submission()) { std::puts("FAIL residency host"); return 1; }
+    m.update_model_status({3, 3, 3});       if (m.state != ModelState::Device || !m.needs_command_buffer_submission()) { std::puts("FAIL residency device"); return 1; }
+    m.reset_command_buffer_submission_status();
+    m.update_model_status({7, 7, 7});       if (m.state != ModelState::Host || !m.needs_command_buffer_submission()) { std::puts("FAIL residency back to host"); return 1; }
+    Sphere sp; sp.center = {1, 0, 0}; sp.radius = 2.0f;
+    Sphere st = sp.transform({2, 0, 0, 5, 0, 3, 0, 0, 0, 0, 1, 0});                                              // model_reader.rs:128-141
+    if (std::fabs(st.center[0] - 7.0f) > 1e-6f || std::fabs(st.radius - 6.0f) > 1e-6f) { std::puts("FAIL sphere transform"); return 1; }
     std::puts("HOST_MIRROR_OK");
     return 0;
 }

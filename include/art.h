@@ -126,6 +126,9 @@ int32_t art_scene_add_primitive(ArtContext *ctx, const ArtVertex *verts, uint32_
                                 uint32_t n_indices, uint32_t idx_bytes, const uint8_t *rgba8, uint32_t tw, uint32_t th,
                                 const float model3x4[12], uint32_t *out_primitive_id);
 int32_t art_scene_clear(ArtContext *ctx);
+/* residency (vk_model.rs:334-345, renderer.rs:637-651): only models in the Device state are instanced in the TLAS.  A disabled
+ * primitive keeps its id and its host copy but is neither uploaded nor traced; takes effect at the next art_scene_build. */
+int32_t art_scene_set_primitive_enabled(ArtContext *ctx, uint32_t primitive_id, int32_t enabled);
 /* VkBlasBuilder::build_blas_from_geometry (vk_blas_builder.rs:88-170) + VkTlasBuilder::recreate_tlas
  * (vk_tlas_builder.rs:38-233): device LBVH over the world-space triangle soup. */
 int32_t art_scene_build(ArtContext *ctx);

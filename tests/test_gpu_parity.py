@@ -321,6 +321,43 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
     assert frame(4, env={"ART_FUSED": "0"})[3]["frame_launches"] == 4
 
 
+def test_residency_only_device_models_are_traced(R, get_scene):
+    """renderer.rs:637-651 + vk_model.rs:334-345: a model farther than 10 units from the camera leaves the acceleration structure
+    (the frame equals the one without it), comes back when the camera approaches; with nothing in range every ray misses"""
+    sc = get_scene("cornell")
+    w, h = 128, 96
+    far = np.array([[1, 0, 0, 30.0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32)   # the same boxes, 30 units to the right
+    both = R.Renderer((w, h), frames_in_flight=2)
+    near_ids = both.add_model(sc.primitives)
+    far_ids = both.add_model(sc.primitives, far)
+    for d in sc.lights:
+        both.lights_mut().push_dict(d)
+    cam = both.camera_mut()
+    cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
+    both.prepare_first_frame()
+    assert [m.state for m in both.models_mut()] == [R.DEVICE, R.STORAGE]
+    both.render_frame()
+    only = R.renderer_for_scene(sc, (w, h), frames_in_flight=2)
+    only.render_frame()
+    assert np.array_equal(both.read_color().view(np.uint32), only.read_color().view(np.uint32))
+    assert both.stats()["num_triangles"] == only.stats()["num_triangles"] == 34
+    # camera next to the far copy: that one is instanced now, the first one is 30 units away (Storage)
+    p = sc.camera["pos"]
+    cam.set_pos((p[0] + 30.0, p[1], p[2]))
+    both.render_frame()
+    assert [m.state for m in both.models_mut()] == [R.STORAGE, R.DEVICE]
+    d1, d0 = both.read_depth(), only.read_depth()                 # the same boxes seen from the same relative position (x + 30 costs float precision)
+    hit1, hit0 = d1 < 10000.0, d0 < 10000.0
+    assert (hit1 != hit0).mean() < 1e-3 and np.allclose(d1[hit1 & hit0], d0[hit1 & hit0], rtol=1e-3)
+    # half way: both copies are 14 units off -> Host, nothing is traced
+    cam.set_pos((p[0] + 15.0, p[1], p[2]))
+    both.render_frame()
+    assert [m.state for m in both.models_mut()] == [R.HOST, R.HOST]
+    st = both.stats()
+    assert st["hit_pixels"] == 0 and st["shadow_rays"] == 0 and np.all(both.read_depth() == 10000.0)
+    both.close(); only.close()
+
+
 def test_single_triangle_known_answers(R):
     """analytic KAT through the GPU: one triangle, hand-computed t/u/v, edge, parallel, behind, range cases"""
     from araytracingjourney_amd import scenes
