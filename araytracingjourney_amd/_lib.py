@@ -110,6 +110,7 @@ SYMBOLS = {
     "art_query_closest": (_I32, [_P, _P, _U32, _P, _P]),
     "art_query_any": (_I32, [_P, _P, _U32, _P]),
     "art_get_lbvh": (_I32, [_P] + [_P] * 7),
+    "art_get_traversal_tree": (_I32, [_P, _P, _P, _P]),
     "art_glb_last_error": (C.c_char_p, []),
     "art_glb_open": (_I32, [C.c_char_p, _I32, _I32, _P]),
     "art_glb_close": (_I32, [_P]),

@@ -985,4 +985,18 @@ int32_t art_get_lbvh(ArtContext *c, uint32_t *leaf_gid, uint64_t *keys, int32_t 
     return ART_OK;
 }
 
+// the tree the walks actually use: the SAH topology when it was built (default), else the canonical one; leaves are those of art_get_lbvh
+int32_t art_get_traversal_tree(ArtContext *c, int32_t *child, float *node_lo, float *node_hi) {
+    if (!c) return fail(ART_E_INVALID, "art_get_traversal_tree: null context");
+    if (!c->built) return fail(ART_E_STATE, "art_get_traversal_tree: scene not built");
+    int32_t r = use_device(c); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    size_t T = c->T, NI = T > 1 ? T - 1 : 0;
+    const bool sah = c->bvh.trav_child != nullptr;
+    if (child && NI) HIPC(hipMemcpy(child, sah ? c->bvh.trav_child : c->bvh.child, NI * 8, hipMemcpyDeviceToHost));
+    if (node_lo && NI) HIPC(hipMemcpy(node_lo, sah ? c->bvh.trav_lo : c->bvh.node_lo, NI * 12, hipMemcpyDeviceToHost));
+    if (node_hi && NI) HIPC(hipMemcpy(node_hi, sah ? c->bvh.trav_hi : c->bvh.node_hi, NI * 12, hipMemcpyDeviceToHost));
+    return ART_OK;
+}
+
 } // extern "C"

@@ -471,6 +471,13 @@ class Renderer:
         check(self._L.art_get_lbvh(self._ctx, *[_ptr(out[k]) for k in ("leaf_gid", "keys", "child", "node_lo", "node_hi", "leaf_lo", "leaf_hi")]))
         return out
 
+    def get_traversal_tree(self):
+        """the tree the walks use over get_lbvh()'s leaves (binned SAH by default)"""
+        NI = max(self.stats()["num_triangles"] - 1, 0)
+        out = dict(child=np.zeros((NI, 2), np.int32), node_lo=np.zeros((NI, 3), np.float32), node_hi=np.zeros((NI, 3), np.float32))
+        check(self._L.art_get_traversal_tree(self._ctx, _ptr(out["child"]), _ptr(out["node_lo"]), _ptr(out["node_hi"])))
+        return out
+
 
 def renderer_for_scene(scene, extent, n_lights=None, **kw) -> Renderer:
     """Convenience used by tests and bench: the main.rs:23-66 sequence for a synthetic scene."""

@@ -221,6 +221,9 @@ int32_t art_query_any(ArtContext *ctx, const float *rays, uint32_t n, uint8_t *h
  * leaf_gid[T], keys[T], child[2*(T-1)], node_lo/hi[(T-1)*3], leaf_lo/hi[T*3] */
 int32_t art_get_lbvh(ArtContext *ctx, uint32_t *leaf_gid, uint64_t *keys, int32_t *child, float *node_lo,
                      float *node_hi, float *leaf_lo, float *leaf_hi);
+/* the topology and node boxes the walks use over those leaves (child[2*(T-1)], node_lo/hi[3*(T-1)]): the binned-SAH tree by
+ * default, the canonical tree with ART_FLAG_FAST_BUILD.  Node 0 is the root; child >= 0: internal node, < 0: ~leaf position. */
+int32_t art_get_traversal_tree(ArtContext *ctx, int32_t *child, float *node_lo, float *node_hi);
 
 /* ---- GLB ingest: the step right before the path (model_reader/gltf_model_reader.rs), host only ------------------ */
 typedef struct ArtGlb ArtGlb;
