@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--lights", type=int, default=1, choices=[1, 4])
+    ap.add_argument("--scene", default="sponza", choices=["sponza", "bistro"], help="sponza = BASELINE configs 2/3/5 (the default is config 2); bistro = config 4 (2.8 M triangles, one directional light)")
     ap.add_argument("--detail", type=float, default=1.0, help="scene detail (1.0 = the 262k-triangle config)")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="ring of per-frame streams/buffers; default 3 like the reference's FrameData ring (renderer.rs:135) on one GPU, 12 when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
@@ -73,9 +74,13 @@ def main():
             dist.init_process_group("gloo")
 
     W, H = args.width, args.height
-    sc = scenes.sponza_like(args.detail)
-    lights = scenes.sponza_lights(args.lights)
-    sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
+    if args.scene == "bistro":
+        sc = scenes.bistro_like(args.detail)
+        lights = sc.lights
+    else:
+        sc = scenes.sponza_like(args.detail)
+        lights = scenes.sponza_lights(args.lights)
+        sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
     F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else 16
     packed = world > 1 and args.gather == "packed"
     r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F, packed_tiles=packed)
@@ -209,7 +214,7 @@ def main():
 
     # ---- algorithmic bytes: the oracle's canonical-LBVH visit counters for this exact frame
     tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights))
-    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and args.detail == 1.0 and not args.ao else None
+    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and args.detail == 1.0 and not args.ao and args.scene == "sponza" else None
     ost = json.load(open(fx)) if fx and os.path.exists(fx) else None
 
     # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame
@@ -270,10 +275,11 @@ def main():
                     note="working set (BVH + triangles, ~30 MB) is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes")
 
     line = {
-        "metric": "Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}",
+        "metric": ("Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}") if args.scene == "sponza"
+                  else f"Mray/s (primary+shadow), Bistro-class {W}x{H}",
         "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"sponza_like(seed=0x5A0A, {sc.n_tris} triangles, 25 primitives) {W}x{H}, {args.lights} light(s), "
+        "config": {"workload": f"{'bistro_like(seed=0xB157' if args.scene == 'bistro' else 'sponza_like(seed=0x5A0A'}, {sc.n_tris} triangles, {len(sc.primitives)} primitives) {W}x{H}, {len(lights)} light(s), "
                                f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
                    "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {GB} frames per gather") + f", {F} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F, "hip_graph_replay": use_graph,
