@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -40,32 +41,70 @@ struct Builder {
     // tree at kSahDepth + ceil(log2 T) <= 80 levels
     static constexpr uint32_t kSahDepth = 48;
 
+    static constexpr unsigned kMaxThreads = 16;
+    unsigned wide_threads = 1; // threads for the passes over one large range (the top of the tree, before subtrees run in parallel)
+
+    // run f(chunk_begin, chunk_end, chunk_index) over [b,e) on up to wide_threads threads
+    template <class F> void chunks(uint32_t b, uint32_t e, unsigned &n_chunks, F &&f) {
+        const uint32_t n = e - b;
+        n_chunks = (wide_threads > 1 && n >= 65536) ? wide_threads : 1;
+        if (n_chunks == 1) { f(b, e, 0u); return; }
+        std::vector<std::thread> pool;
+        for (unsigned c = 0; c < n_chunks; c++)
+            pool.emplace_back([&, c] { f(b + (uint32_t)((uint64_t)n * c / n_chunks), b + (uint32_t)((uint64_t)n * (c + 1) / n_chunks), c); });
+        for (auto &t : pool) t.join();
+    }
+
     // choose the split of idx[b,e), partition, return the middle; also writes node k's box
     uint32_t split(uint32_t b, uint32_t e, uint32_t k, uint32_t depth) {
         Box3 nb, cb;
-        for (uint32_t i = b; i < e; i++) {
-            const float *l = llo + 3 * (size_t)idx[i], *h = lhi + 3 * (size_t)idx[i];
-            nb.grow(l, h);
-            float c[3] = {0.5f * l[0] + 0.5f * h[0], 0.5f * l[1] + 0.5f * h[1], 0.5f * l[2] + 0.5f * h[2]};
-            cb.grow(c, c);
+        {
+            unsigned nc = 1;
+            Box3 pn[kMaxThreads], pc[kMaxThreads];
+            chunks(b, e, nc, [&](uint32_t cb0, uint32_t ce, unsigned c) {
+                Box3 n1, c1;
+                for (uint32_t i = cb0; i < ce; i++) {
+                    const float *l = llo + 3 * (size_t)idx[i], *h = lhi + 3 * (size_t)idx[i];
+                    n1.grow(l, h);
+                    float ct[3] = {0.5f * l[0] + 0.5f * h[0], 0.5f * l[1] + 0.5f * h[1], 0.5f * l[2] + 0.5f * h[2]};
+                    c1.grow(ct, ct);
+                }
+                pn[c] = n1; pc[c] = c1;
+            });
+            for (unsigned c = 0; c < nc; c++) { nb.grow(pn[c]); cb.grow(pc[c]); }
         }
         for (int a = 0; a < 3; a++) { nlo[3 * (size_t)k + a] = nb.lo[a]; nhi[3 * (size_t)k + a] = nb.hi[a]; }
         const uint32_t n = e - b;
         if (n == 2) return b + 1;
         if (depth >= kSahDepth) return b + n / 2;
+        // one pass fills the bins of all three axes
+        struct Bins { Box3 box[3][kBins]; uint32_t cnt[3][kBins]; };
+        float sc[3]; bool live[3];
+        for (int a = 0; a < 3; a++) { float ext = cb.hi[a] - cb.lo[a]; live[a] = ext > 0.0f; sc[a] = live[a] ? (float)kBins / ext : 0.0f; }
+        unsigned nc = 1;
+        Bins first{};                       // the common case (small ranges, one thread) stays on the stack
+        std::vector<Bins> more(wide_threads > 1 && n >= 65536 ? wide_threads - 1 : 0);
+        auto part_of = [&](unsigned c) -> Bins & { return c == 0 ? first : more[c - 1]; };
+        chunks(b, e, nc, [&](uint32_t cb0, uint32_t ce, unsigned c) {
+            Bins &B = part_of(c);
+            for (uint32_t i = cb0; i < ce; i++) {
+                const float *l = llo + 3 * (size_t)idx[i], *h = lhi + 3 * (size_t)idx[i];
+                for (int a = 0; a < 3; a++) {
+                    if (!live[a]) continue;
+                    int bi = (int)(((0.5f * l[a] + 0.5f * h[a]) - cb.lo[a]) * sc[a]);
+                    bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
+                    B.box[a][bi].grow(l, h); B.cnt[a][bi]++;
+                }
+            }
+        });
+        Bins &T0 = first;
+        for (unsigned c = 1; c < nc; c++)
+            for (int a = 0; a < 3; a++) for (int i = 0; i < kBins; i++) { T0.box[a][i].grow(more[c - 1].box[a][i]); T0.cnt[a][i] += more[c - 1].cnt[a][i]; }
         int best_axis = -1, best_bin = 0;
         double best_cost = INFINITY;
         for (int a = 0; a < 3; a++) {
-            float ext = cb.hi[a] - cb.lo[a];
-            if (!(ext > 0.0f)) continue;
-            Box3 bins[kBins]; uint32_t cnt[kBins] = {};
-            float sc = (float)kBins / ext;
-            for (uint32_t i = b; i < e; i++) {
-                const float *l = llo + 3 * (size_t)idx[i], *h = lhi + 3 * (size_t)idx[i];
-                int bi = (int)(((0.5f * l[a] + 0.5f * h[a]) - cb.lo[a]) * sc);
-                bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
-                bins[bi].grow(l, h); cnt[bi]++;
-            }
+            if (!live[a]) continue;
+            const Box3 *bins = T0.box[a]; const uint32_t *cnt = T0.cnt[a];
             double right_area[kBins]; uint32_t right_cnt[kBins];
             Box3 acc; uint32_t c = 0;
             for (int i = kBins - 1; i > 0; i--) { acc.grow(bins[i]); c += cnt[i]; right_area[i] = acc.half_area(); right_cnt[i] = c; }
@@ -78,11 +117,11 @@ struct Builder {
             }
         }
         if (best_axis < 0) return b + n / 2; // coincident centroids: any split is as good
-        float ext = cb.hi[best_axis] - cb.lo[best_axis], sc = (float)kBins / ext, c0 = cb.lo[best_axis];
         const int a = best_axis;
+        const float s1 = sc[a], c0 = cb.lo[a];
         auto mid = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t p) {
             const float *l = llo + 3 * (size_t)p, *h = lhi + 3 * (size_t)p;
-            int bi = (int)(((0.5f * l[a] + 0.5f * h[a]) - c0) * sc);
+            int bi = (int)(((0.5f * l[a] + 0.5f * h[a]) - c0) * s1);
             bi = bi < 0 ? 0 : (bi >= kBins ? kBins - 1 : bi);
             return bi <= best_bin;
         });
@@ -109,6 +148,7 @@ struct Builder {
         // the top of the tree on this thread until there are enough independent subtrees, largest first
         std::vector<Task> open; open.push_back(Task{0, T, 0, 0});
         const size_t want = threads > 1 ? (size_t)threads * 8 : 1;
+        wide_threads = threads < kMaxThreads ? threads : kMaxThreads;
         while (threads > 1 && open.size() < want) {
             size_t big = 0;
             for (size_t i = 1; i < open.size(); i++) if (open[i].e - open[i].b > open[big].e - open[big].b) big = i;
@@ -116,6 +156,7 @@ struct Builder {
             Task t = open[big]; open.erase(open.begin() + (long)big);
             node(t, [&](Task c) { open.push_back(c); });
         }
+        wide_threads = 1;
         if (threads <= 1 || open.size() < 2) { for (const Task &t : open) subtree(t); return; }
         std::sort(open.begin(), open.end(), [](const Task &x, const Task &y) { return x.e - x.b > y.e - y.b; });
         std::atomic<size_t> next{0};
