@@ -42,6 +42,7 @@ struct Builder {
     static constexpr uint32_t kSahDepth = 48;
 
     static constexpr unsigned kMaxThreads = 16;
+    static constexpr uint32_t kSweep = 32;
     unsigned wide_threads = 1; // threads for the passes over one large range (the top of the tree, before subtrees run in parallel)
 
     // run f(chunk_begin, chunk_end, chunk_index) over [b,e) on up to wide_threads threads
@@ -77,6 +78,30 @@ struct Builder {
         const uint32_t n = e - b;
         if (n == 2) return b + 1;
         if (depth >= kSahDepth) return b + n / 2;
+        if (n <= kSweep) { // small ranges: the exact sweep over every split of every axis (sorted by centroid)
+            uint32_t ord[kSweep], best_ord[kSweep];
+            double best = INFINITY; uint32_t best_left = 0;
+            for (int a = 0; a < 3; a++) {
+                if (!(cb.hi[a] > cb.lo[a])) continue;
+                for (uint32_t i = 0; i < n; i++) ord[i] = idx[b + i];
+                std::sort(ord, ord + n, [&](uint32_t x, uint32_t y) {
+                    float cx = 0.5f * llo[3 * (size_t)x + a] + 0.5f * lhi[3 * (size_t)x + a], cy = 0.5f * llo[3 * (size_t)y + a] + 0.5f * lhi[3 * (size_t)y + a];
+                    return cx < cy || (cx == cy && x < y);
+                });
+                double right_area[kSweep];
+                Box3 acc;
+                for (uint32_t i = n - 1; i > 0; i--) { acc.grow(llo + 3 * (size_t)ord[i], lhi + 3 * (size_t)ord[i]); right_area[i] = acc.half_area(); }
+                acc = Box3{};
+                for (uint32_t i = 0; i + 1 < n; i++) {
+                    acc.grow(llo + 3 * (size_t)ord[i], lhi + 3 * (size_t)ord[i]);
+                    double cost = acc.half_area() * (i + 1) + right_area[i + 1] * (n - 1 - i);
+                    if (cost < best) { best = cost; best_left = i + 1; std::memcpy(best_ord, ord, n * sizeof(uint32_t)); }
+                }
+            }
+            if (best_left == 0) return b + n / 2;
+            for (uint32_t i = 0; i < n; i++) idx[b + i] = best_ord[i];
+            return b + best_left;
+        }
         // one pass fills the bins of all three axes
         struct Bins { Box3 box[3][kBins]; uint32_t cnt[3][kBins]; };
         float sc[3]; bool live[3];
