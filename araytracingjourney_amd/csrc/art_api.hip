@@ -199,9 +199,9 @@ int32_t setup_frame(ArtContext *c) {
     for (uint32_t k = 0; k < c->F; k++) {
         FrameSlot &S = c->slot[k];
         HIPC(S.d_counters.ensure(kCounterWords)); HIPC(hipMemset(S.d_counters.p, 0, kCounterWords * 4)); // packet frames keep them clear themselves (k_accumulate)
-        HIPC(S.d_hits.ensure(c->n_local));
-        HIPC(S.d_contrib.ensure(nl * c->n_local));
-        HIPC(S.d_shadow_rays.ensure(2 * nl * c->n_local));
+        const bool staged = !(c->fused && c->kind_primary == 8 && c->kind_shadow == 8); // the fused frame keeps these records in registers
+        if (staged || (c->cfg.flags & ART_FLAG_KEEP_DEBUG)) HIPC(S.d_hits.ensure(c->n_local));
+        if (staged) { HIPC(S.d_contrib.ensure(nl * c->n_local)); HIPC(S.d_shadow_rays.ensure(2 * nl * c->n_local)); }
         HIPC(S.d_color.ensure(npix)); HIPC(S.d_normal.ensure(npix)); HIPC(S.d_depth.ensure(npix));
         HIPC(hipMemset(S.d_color.p, 0, npix * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * 4));
         if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes())); }
