@@ -96,6 +96,7 @@ SYMBOLS = {
     "art_shard_tile_count": (_I32, [_P, _P, _P]),
     "art_device_color_tiles": (_I32, [_P, _P, _P]),
     "art_bind_color_tiles": (_I32, [_P, _U32, _P, _SZ]),
+    "art_bind_color_tiles_pair": (_I32, [_P, _U32, _P, _P, _SZ]),
     "art_set_graph_mode": (_I32, [_P, _I32]),
     "art_frames_in_flight": (_I32, [_P, _P, _P]),
     "art_stream_wait_frame": (_I32, [_P, _P]),
@@ -104,6 +105,7 @@ SYMBOLS = {
     "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
     "art_untile_gathered": (_I32, [_P, _P, _U32, _P, _P]),
     "art_untile_gathered_strided": (_I32, [_P, _P, _U32, _U32, _P, _P]),
+    "art_untile_gathered_frames": (_I32, [_P, _P, _U32, _U32, _U32, _P, _P]),
     "art_get_stats": (_I32, [_P, _P]),
     "art_read_hits": (_I32, [_P, _P, _P, _SZ]),
     "art_read_shadow_bits": (_I32, [_P, _P, _SZ]),

@@ -50,6 +50,10 @@ struct FrameSlot {
     DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; bool ao_valid = false;
     DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
+    float4 *ext_tiles_alt = nullptr;   // second caller-owned buffer: the slot's frames alternate between the two (art_bind_color_tiles_pair)
+    float4 *tiles_of_last = nullptr;   // where the slot's most recent frame wrote its tiles
+    float4 *tiles_for(uint64_t frame_no, uint32_t F) { float4 *t = ext_tiles ? ((ext_tiles_alt && ((frame_no / F) & 1u)) ? ext_tiles_alt : ext_tiles) : d_color_tiles.p; tiles_of_last = t; return t; }
+    float4 *last_tiles() const { return tiles_of_last ? tiles_of_last : (ext_tiles ? ext_tiles : d_color_tiles.p); }
     hipEvent_t done = nullptr;       // recorded after the slot's last frame
     hipGraphExec_t graph = nullptr;  // the frame's launch sequence captured once (graph mode); dropped whenever an input changes
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
@@ -84,6 +88,7 @@ struct ArtContext {
     // frame
     std::vector<uint32_t> tile_list; uint32_t tiles_x = 0, tiles_y = 0, padded_tiles = 0, n_local = 0;
     DevBuf<uint32_t> d_tile_list;
+    DevBuf<uint32_t> d_tile_slot;   // un-tile table: tile -> owner << 24 | index among the owner's tiles (every shard's layout, setup_frame)
     DevBuf<uint32_t> d_block_order; // launch block -> 256-pixel block of the frame: one L2 (XCD) per screen region (setup_frame)
     static constexpr int kRing = 128;          // per-frame stage events kept for art_collect_timings
     hipEvent_t ev[kRing][5] = {};
@@ -153,13 +158,16 @@ int32_t setup_frame(ArtContext *c) {
     c->tiles_x = (c->W + kTile - 1) / kTile; c->tiles_y = (c->H + kTile - 1) / kTile;
     uint32_t count = c->cfg.shard_count > 1 ? c->cfg.shard_count : 1, rank = count > 1 ? c->cfg.shard_rank : 0;
     c->tile_list.clear();
-    std::vector<uint32_t> per(count, 0);
+    std::vector<uint32_t> per(count, 0), slot_of((size_t)c->tiles_x * c->tiles_y);
     for (uint32_t ty = 0; ty < c->tiles_y; ty++)
         for (uint32_t tx = 0; tx < c->tiles_x; tx++) {
             uint32_t o = tile_owner(tx, ty, count);
+            slot_of[(size_t)ty * c->tiles_x + tx] = (o << 24) | per[o];
             per[o]++;
             if (o == rank) c->tile_list.push_back(ty * c->tiles_x + tx);
         }
+    HIPC(c->d_tile_slot.ensure(slot_of.size()));
+    HIPC(hipMemcpy(c->d_tile_slot.p, slot_of.data(), slot_of.size() * 4, hipMemcpyHostToDevice));
     c->padded_tiles = 0;
     for (uint32_t v : per) c->padded_tiles = v > c->padded_tiles ? v : c->padded_tiles;
     c->n_local = (uint32_t)c->tile_list.size() * kTilePixels;
@@ -206,7 +214,7 @@ int32_t setup_frame(ArtContext *c) {
         HIPC(hipMemset(S.d_color.p, 0, npix * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * 4));
         if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes())); }
         if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local)); // fused frames always write their per-pixel shadow bits (stats)
-        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) { S.ext_tiles = nullptr; S.ext_tiles_bytes = 0; }
+        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) { S.ext_tiles = nullptr; S.ext_tiles_alt = nullptr; S.tiles_of_last = nullptr; S.ext_tiles_bytes = 0; }
     }
     HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
     drop_graphs(c);
@@ -542,7 +550,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
-    a.color_tiles = c->cfg.shard_count > 1 ? (S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p) : nullptr; a.tiles_packed = c->tiles_packed();
+    a.color_tiles = c->cfg.shard_count > 1 ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
     a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0; a.frame_waves = c->frame_waves;
     return a;
@@ -561,10 +569,11 @@ int32_t art_trace(ArtContext *c) {
     hipStream_t s = c->stream_of(k);
     if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
     FrameArgs a = make_frame_args(c, S);
+    if (c->cfg.shard_count > 1) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     c->ev_fused[c->frame_no % ArtContext::kRing] = fused;
-    if (c->graph_mode && !fused) { // a fused frame is a single launch: nothing for a graph to save
+    if (c->graph_mode && !fused && !S.ext_tiles_alt) { // a fused frame is a single launch: nothing for a graph to save; alternating tile buffers change a kernel argument
         if (!S.graph) { // capture the frame once per slot; stage events are not part of it
             hipGraph_t g = nullptr;
             HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -744,7 +753,7 @@ int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
     int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color_tiles"); if (r) return r;
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
     FrameSlot &S = c->slot[c->last];
-    *p = S.ext_tiles ? S.ext_tiles : S.d_color_tiles.p; if (b) *b = (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes();
+    *p = S.last_tiles(); if (b) *b = (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes();
     return ART_OK;
 }
 int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t bytes) {
@@ -754,8 +763,14 @@ int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t byt
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_bind_color_tiles"); if (r) return r;
     if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
     HIPC(hipStreamSynchronize(c->stream_of(slot)));
-    c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
+    c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_tiles_alt = nullptr; c->slot[slot].tiles_of_last = nullptr; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
     drop_graphs(c);
+    return ART_OK;
+}
+int32_t art_bind_color_tiles_pair(ArtContext *c, uint32_t slot, void *dev_even, void *dev_odd, size_t bytes) {
+    if (!dev_even || !dev_odd) return fail(ART_E_INVALID, "art_bind_color_tiles_pair: null buffer");
+    int32_t r = art_bind_color_tiles(c, slot, dev_even, bytes); if (r) return r;
+    c->slot[slot].ext_tiles_alt = (float4 *)dev_odd;
     return ART_OK;
 }
 int32_t art_set_graph_mode(ArtContext *c, int32_t on) {
@@ -804,26 +819,29 @@ int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames)
 int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
     if (c && c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
     FrameSlot *S = c ? &c->slot[c->last] : nullptr;
-    return read_back(c, S ? (S->ext_tiles ? S->ext_tiles : S->d_color_tiles.p) : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() : 0, dst, bytes, "art_read_color_tiles");
+    return read_back(c, S ? S->last_tiles() : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() : 0, dst, bytes, "art_read_color_tiles");
 }
-int32_t art_untile_gathered_strided(ArtContext *c, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, void *frame_dev, void *hip_stream) {
+int32_t art_untile_gathered_frames(ArtContext *c, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, uint32_t n_frames, void *frames_dev, void *hip_stream) {
     if (!c || !gathered_dev) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
-    if (shard_stride_tiles < c->padded_tiles) return fail(ART_E_INVALID, "art_untile_gathered_strided: stride smaller than a shard's padded tile count");
+    if (shard_stride_tiles < c->padded_tiles) return fail(ART_E_INVALID, "art_untile_gathered: stride smaller than a shard's padded tile count");
+    if (n_frames == 0 || (n_frames > 1 && (!frames_dev || (uint64_t)n_frames * c->padded_tiles > shard_stride_tiles))) return fail(ART_E_INVALID, "art_untile_gathered_frames: frames do not fit the shard stride (or no output given)");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_untile_gathered"); if (r) return r;
     if (shard_count != (c->cfg.shard_count > 1 ? c->cfg.shard_count : 1)) return fail(ART_E_INVALID, "art_untile_gathered: shard_count differs from the context's");
     r = use_device(c); if (r) return r;
     hipStream_t us = hip_stream ? (hipStream_t)hip_stream : c->stream_of(c->last);
     if (c->tiles_packed()) { // the gathered tiles are B10G11R11 words: the frame is the packed colour image (art_read_packed)
         FrameSlot &S = c->slot[c->last];
-        if (!frame_dev && S.d_pcolor.n < (size_t)c->W * c->H) { HIPC(hipStreamSynchronize(us)); HIPC(S.d_pcolor.ensure((size_t)c->W * c->H)); }
-        launch_untile_packed((const uint32_t *)gathered_dev, shard_count, shard_stride_tiles, c->W, c->H, frame_dev ? (uint32_t *)frame_dev : S.d_pcolor.p, us);
+        if (!frames_dev && S.d_pcolor.n < (size_t)c->W * c->H) { HIPC(hipStreamSynchronize(us)); HIPC(S.d_pcolor.ensure((size_t)c->W * c->H)); }
+        launch_untile_packed((const uint32_t *)gathered_dev, c->d_tile_slot.p, shard_stride_tiles, n_frames, c->padded_tiles, c->W, c->H, frames_dev ? (uint32_t *)frames_dev : S.d_pcolor.p, us);
     } else
-    launch_untile((const float4 *)gathered_dev, shard_count, shard_stride_tiles, c->W, c->H, frame_dev ? (float4 *)frame_dev : c->slot[c->last].d_color.p, us);
+    launch_untile((const float4 *)gathered_dev, c->d_tile_slot.p, shard_stride_tiles, n_frames, c->padded_tiles, c->W, c->H, frames_dev ? (float4 *)frames_dev : c->slot[c->last].d_color.p, us);
     HIPC(hipGetLastError());
     c->traced = true;
     return ART_OK;
 }
-
+int32_t art_untile_gathered_strided(ArtContext *c, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, void *frame_dev, void *hip_stream) {
+    return art_untile_gathered_frames(c, gathered_dev, shard_count, shard_stride_tiles, 1, frame_dev, hip_stream);
+}
 int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream) {
     if (!c) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
     return art_untile_gathered_strided(c, gathered_dev, shard_count, c->padded_tiles, frame_dev, hip_stream);

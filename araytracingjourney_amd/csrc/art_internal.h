@@ -164,8 +164,10 @@ void lpm_control_block(bool shoulder, float soft_gap, float hdr_max, float expos
                        const float crosstalk[3], uint32_t ctl[96]);
 void launch_present(uint32_t n, const float4 *color, const float4 *normal, const float *depth, const uint32_t *ao, const uint32_t ctl[96], uint32_t *pcolor,
                     uint32_t *pnormal, uint16_t *pdepth, uint32_t *bgra, hipStream_t s);
-void launch_untile_packed(const uint32_t *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, uint32_t *frame, hipStream_t s);
-void launch_untile(const float4 *gathered, uint32_t shard_count, uint32_t padded_tiles, uint32_t W, uint32_t H, float4 *frame, hipStream_t s);
+// tile_slot[tile] = owner << 24 | index among the owner's tiles; shard_stride = tiles between two shards' buffers
+// n_frames frames in one launch: frame z reads frame_stride tiles further into every shard's buffer and writes frame + z * W * H
+void launch_untile_packed(const uint32_t *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, uint32_t *frame, hipStream_t s);
+void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, float4 *frame, hipStream_t s);
 
 // shard tile ownership: 32x32 tile (tx,ty) belongs to shard (tx + 5*ty) % count -- a diagonal interleave, so that
 // every shard gets a near-equal number of tiles from every screen region (load balance)

@@ -388,6 +388,10 @@ class Renderer:
     def bind_color_tiles(self, slot, dev_ptr, nbytes):
         check(self._L.art_bind_color_tiles(self._ctx, slot, C.c_void_p(dev_ptr) if dev_ptr else None, nbytes))
 
+    def bind_color_tiles_pair(self, slot, dev_even, dev_odd, nbytes):
+        """two tile buffers per ring slot, written alternately: the next frame of a slot does not wait for the exchange of the previous one"""
+        check(self._L.art_bind_color_tiles_pair(self._ctx, slot, C.c_void_p(dev_even), C.c_void_p(dev_odd), nbytes))
+
     def set_graph_mode(self, on):
         check(self._L.art_set_graph_mode(self._ctx, int(bool(on))))
 
@@ -421,7 +425,11 @@ class Renderer:
         check(self._L.art_shard_tile_count(self._ctx, C.byref(o), C.byref(pd)))
         return o.value, pd.value
 
-    def untile_gathered(self, gathered_dev_ptr, shard_count, frame_dev_ptr=None, hip_stream_ptr=None, shard_stride_tiles=None):
+    def untile_gathered(self, gathered_dev_ptr, shard_count, frame_dev_ptr=None, hip_stream_ptr=None, shard_stride_tiles=None, n_frames=None):
+        if n_frames is not None:   # several consecutive ring slots in one launch; frame_dev_ptr: n_frames images back to back
+            check(self._L.art_untile_gathered_frames(self._ctx, C.c_void_p(gathered_dev_ptr), shard_count, shard_stride_tiles, n_frames,
+                                                     C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None, C.c_void_p(hip_stream_ptr) if hip_stream_ptr else None))
+            return
         if shard_stride_tiles is not None:
             check(self._L.art_untile_gathered_strided(self._ctx, C.c_void_p(gathered_dev_ptr), shard_count, shard_stride_tiles,
                                                       C.c_void_p(frame_dev_ptr) if frame_dev_ptr else None, C.c_void_p(hip_stream_ptr) if hip_stream_ptr else None))

@@ -90,31 +90,39 @@ def main():
 
     tiles = gathered = frame = None
     GB = 1
-    consumed = [None] * F             # per ring slot: event "the gather that read this slot's tiles has finished"
+    consumed = [[None] * F, [None] * F]   # per tile buffer (two per ring slot): event "the exchange that read these tiles has finished"
     if world > 1:
         owned, padded = r.shard_tile_count()
         GB = max(1, min(args.gather_frames, F))
         while F % GB:                 # whole gather groups per trip round the ring
             GB -= 1
         tshape, tdtype = ((padded, 32, 32), torch.int32) if packed else ((padded, 32, 32, 4), torch.float32)
-        tiles = torch.zeros((F,) + tshape, dtype=tdtype, device="cuda")      # slot k renders into tiles[k]: GB slots = one contiguous message
+        # slot k renders into tiles[trip parity][k]: GB slots are one contiguous message, and a slot's next frame never waits for the
+        # exchange that still reads its previous tiles
+        tiles = torch.zeros((2, F) + tshape, dtype=tdtype, device="cuda")
         for k in range(F):
-            r.bind_color_tiles(k, tiles[k].data_ptr(), tiles[k].numel() * 4)
+            r.bind_color_tiles_pair(k, tiles[0, k].data_ptr(), tiles[1, k].data_ptr(), tiles[0, k].numel() * 4)
         if rank == 0:
             gathered = torch.empty((world, F) + tshape, dtype=tdtype, device="cuda")   # [peer][slot]: a frame's shards are F * padded tiles apart
-            frame = torch.zeros((H, W) if packed else (H, W, 4), dtype=tdtype, device="cuda")
+            frame = torch.zeros((GB,) + ((H, W) if packed else (H, W, 4)), dtype=tdtype, device="cuda")   # the frames of one exchange, un-tiled by one launch
         torch.cuda.synchronize()
+
+    traced = [0]                      # frames submitted so far (trip parity = (traced // F) & 1)
 
     def step():
         if world == 1:
-            r.trace()                 # the whole frame (one fused launch; four staged ones with one frame in flight) on the next ring slot's stream
+            r.trace()                 # the whole frame (one fused launch) on the next ring slot's stream
             if args.ao:
                 r.trace_ao(args.ao)
             return
         _, k = r.frames_in_flight()
-        if consumed[k] is not None:
-            r.wait_external_event(consumed[k].cuda_event)   # do not overwrite tiles a gather is still reading
+        ev = consumed[(traced[0] // F) & 1][k]
+        if ev is not None and not ev.query():
+            # Gate on the HOST: a cross-stream wait queued in front of every frame costs the frame kernels their L2 contents (an acquire
+            # per launch; measured 115 instead of 55 us per frame on a 1/8 share).  The event is two trips old: it has almost always fired.
+            ev.synchronize()
         r.trace()
+        traced[0] += 1
         if args.ao:
             r.trace_ao(args.ao)                             # per tile from the local G-buffer: no extra exchange
         r.stream_wait_frame(stream.cuda_stream)             # torch's stream (hence RCCL) waits for this frame
@@ -123,28 +131,31 @@ def main():
             exchange()
 
     pending = [0, 0]                  # first slot and number of frames traced but not yet gathered
+    newest = [0]                      # where in `frame` the most recent frame sits
 
     def exchange():
         k0, n = pending
         if n == 0:
             return
         pending[0], pending[1] = (k0 + n) % F, 0
+        par = ((traced[0] - 1) // F) & 1                     # the buffers these frames wrote
+        src = tiles[par, k0:k0 + n]
         if args.backend == "nccl":
-            dist.gather(tiles[k0:k0 + n], [gathered[w, k0:k0 + n] for w in range(world)] if rank == 0 else None, dst=0)
+            dist.gather(src, [gathered[w, k0:k0 + n] for w in range(world)] if rank == 0 else None, dst=0)
         else:   # rehearsal: same call sequence, payload through host memory
-            host = tiles[k0:k0 + n].cpu()
+            host = src.cpu()
             parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
             dist.gather(host, parts, dst=0)
             if rank == 0:
                 for w in range(world):
                     gathered[w, k0:k0 + n].copy_(parts[w])
-        if rank == 0:
-            for j in range(k0, k0 + n):                     # the root keeps the newest frame; every frame is un-tiled
-                r.untile_gathered(gathered[0, j].data_ptr(), world, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * padded)
+        if rank == 0:                                       # every frame of the exchange is un-tiled, by one launch
+            r.untile_gathered(gathered[0, k0].data_ptr(), world, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * padded, n_frames=n)
+            newest[0] = n - 1
         ev = torch.cuda.Event()
         ev.record(stream)
         for j in range(k0, k0 + n):
-            consumed[j] = ev
+            consumed[par][j] = ev
 
     def fence():
         if world > 1:
@@ -184,9 +195,9 @@ def main():
         whole.render_frame()
         if packed:   # the assembled frame is the packed colour image: against the single GPU's (art_present packs it, vk_rt_lightning_shadows.rs:152)
             whole.present()
-            frame_ok = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), whole.read_packed()[0]))
+            frame_ok = bool(np.array_equal(frame[newest[0]].cpu().numpy().view(np.uint32), whole.read_packed()[0]))
         else:
-            frame_ok = bool(np.array_equal(frame.cpu().numpy().view(np.uint32), whole.read_color().view(np.uint32)))
+            frame_ok = bool(np.array_equal(frame[newest[0]].cpu().numpy().view(np.uint32), whole.read_color().view(np.uint32)))
         whole.close()
     t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["primary_ms"], stage["shadow_ms"], stage["shade_ms"], stage["frame_ms"], iso["primary_ms"], iso["shadow_ms"]],
                      dtype=torch.float64, device="cuda")

@@ -197,12 +197,19 @@ int32_t art_device_color_tiles(ArtContext *ctx, void **dev_ptr, size_t *bytes);
 /* render ring slot `slot`'s compact tiles straight into a caller-owned device buffer (e.g. the tensor handed to the
  * gather); bytes must equal padded * 16 KiB; NULL unbinds */
 int32_t art_bind_color_tiles(ArtContext *ctx, uint32_t slot, void *dev_ptr, size_t bytes);
+/* two buffers per slot: the slot's frames write them alternately (even / odd trips round the ring), so a frame never waits for the
+ * exchange that is still reading the slot's previous tiles -- only for the one of two trips ago.  art_device_color_tiles and
+ * art_read_color_tiles refer to the buffer the latest frame wrote. */
+int32_t art_bind_color_tiles_pair(ArtContext *ctx, uint32_t slot, void *dev_even, void *dev_odd, size_t bytes);
 int32_t art_read_color_tiles(ArtContext *ctx, void *dst, size_t bytes); /* host copy of the same buffer (tests) */
 /* frame_dev NULL = the context's colour buffer; hip_stream NULL = the latest frame's stream */
 int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream);
 /* the same with shard s's tiles at gathered + s * shard_stride_tiles tiles: several frames gathered by ONE collective leave each
  * rank's frames back to back, so consecutive shards of one frame are a whole block of frames apart */
 int32_t art_untile_gathered_strided(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, void *frame_dev, void *hip_stream);
+/* n_frames frames in ONE launch (the exchange of several ring slots by one collective): frame z's tiles start z * padded tiles into
+ * every shard's buffer, its image is written at frames_dev + z * width * height elements */
+int32_t art_untile_gathered_frames(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, uint32_t n_frames, void *frames_dev, void *hip_stream);
 
 int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
 /* device time per stage (HIP events on the context's stream) summed over the frames traced since the previous call

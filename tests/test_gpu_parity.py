@@ -168,6 +168,47 @@ def test_sharded_tiles_gather_to_the_unsharded_frame(R, get_scene):
         s.close()
 
 
+def test_tile_buffer_pairs_alternate_per_trip(R, get_scene):
+    """art_bind_color_tiles_pair: a ring slot writes its two caller-owned tile buffers on alternate trips round the ring, so the exchange
+    that still reads one is never in the next frame's way; several frames are un-tiled by one launch (art_untile_gathered_frames)"""
+    import torch
+    from araytracingjourney_amd import sharding
+    sc = get_scene("cornell")
+    w, h, G, F = 160, 96, 2, 2
+    whole = R.renderer_for_scene(sc, (w, h))
+    shards = [R.renderer_for_scene(sc, (w, h), shard=(k, G), frames_in_flight=F) for k in range(G)]
+    owned, padded = shards[0].shard_tile_count()
+    bufs = [torch.zeros((2, F, padded, 32, 32, 4), dtype=torch.float32, device="cuda") for _ in range(G)]
+    for s, b in zip(shards, bufs):
+        for k in range(F):
+            s.bind_color_tiles_pair(k, b[0, k].data_ptr(), b[1, k].data_ptr(), b[0, k].numel() * 4)
+    want = []
+    for i in range(2 * F):                                   # two trips: frame i lands in buffer [i // F % 2][i % F]
+        pos = (0.02 * i, 0.01 * i, -0.95)
+        for r in [whole] + shards:
+            r.camera_mut().set_pos(pos)
+            r.upload_state()
+            r.trace()
+        want.append(whole.read_color())
+    for s in shards:
+        s.sync()
+    for i in range(2 * F):
+        for k, b in enumerate(bufs):
+            ref = sharding.tile_host(want[i], G, k)
+            n = shards[k].shard_tile_count()[0]
+            assert np.array_equal(b[i // F % 2, i % F, :n].cpu().numpy().view(np.uint32), ref[:n].view(np.uint32)), (i, k)
+    # the second trip's two frames, gathered [shard][slot] and un-tiled by ONE launch
+    gathered = torch.stack([b[1] for b in bufs]).contiguous()             # [G, F, padded, 32, 32, 4]
+    frames = torch.zeros((F, h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    shards[0].untile_gathered(gathered.data_ptr(), G, frames.data_ptr(), None, shard_stride_tiles=F * padded, n_frames=F)
+    shards[0].sync(); torch.cuda.synchronize()
+    for j in range(F):
+        assert np.array_equal(frames[j].cpu().numpy().view(np.uint32), want[F + j].view(np.uint32)), j
+    for r in [whole] + shards:
+        r.close()
+
+
 def test_packed_tiles_gather_to_the_packed_colour_image(R, get_scene):
     """ART_FLAG_PACKED_TILES: the gather payload is B10G11R11 (the reference's colour image format, renderer.rs:268), 4 B per pixel;
     un-tiled on shard 0 it equals the packed colour of the unsharded frame; fused and staged frames"""
