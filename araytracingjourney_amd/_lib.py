@@ -101,6 +101,7 @@ SYMBOLS = {
     "art_frames_in_flight": (_I32, [_P, _P, _P]),
     "art_stream_wait_frame": (_I32, [_P, _P]),
     "art_wait_external_event": (_I32, [_P, _P]),
+    "art_trace_for_stream": (_I32, [_P, _P, _P]),
     "art_collect_timings": (_I32, [_P, _P, _P]),
     "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
     "art_untile_gathered": (_I32, [_P, _P, _U32, _P, _P]),

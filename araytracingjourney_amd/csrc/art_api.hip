@@ -795,6 +795,13 @@ int32_t art_stream_wait_frame(ArtContext *c, void *hip_stream) {
     { FrameSlot &S = c->slot[c->last]; HIPC(hipStreamWaitEvent((hipStream_t)hip_stream, S.done_alias ? S.done_alias : S.done, 0)); }
     return ART_OK;
 }
+int32_t art_trace_for_stream(ArtContext *c, void *hip_stream, uint32_t *slot_used) {
+    if (!c) return fail(ART_E_INVALID, "art_trace_for_stream: null context");
+    const uint32_t k = (uint32_t)(c->frame_no % c->F);
+    int32_t r = art_trace(c); if (r) return r;
+    if (slot_used) *slot_used = k;
+    return art_stream_wait_frame(c, hip_stream);
+}
 int32_t art_wait_external_event(ArtContext *c, void *hip_event) {
     if (!c) return fail(ART_E_INVALID, "art_wait_external_event: null context");
     c->slot[c->frame_no % c->F].wait_event = hip_event;

@@ -403,6 +403,12 @@ class Renderer:
     def stream_wait_frame(self, hip_stream_ptr):
         check(self._L.art_stream_wait_frame(self._ctx, C.c_void_p(hip_stream_ptr)))
 
+    def trace_for_stream(self, hip_stream_ptr):
+        """trace() + stream_wait_frame() in one call; returns the ring slot the frame took"""
+        k = C.c_uint32()
+        check(self._L.art_trace_for_stream(self._ctx, C.c_void_p(hip_stream_ptr), C.byref(k)))
+        return k.value
+
     def wait_external_event(self, hip_event_ptr):
         check(self._L.art_wait_external_event(self._ctx, C.c_void_p(hip_event_ptr)))
 

@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-frames", type=int, default=4, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
+    ap.add_argument("--gather-frames", type=int, default=8, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
     ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
@@ -108,6 +108,7 @@ def main():
         torch.cuda.synchronize()
 
     traced = [0]                      # frames submitted so far (trip parity = (traced // F) & 1)
+    stream_ptr = stream.cuda_stream
 
     def step():
         if world == 1:
@@ -115,17 +116,19 @@ def main():
             if args.ao:
                 r.trace_ao(args.ao)
             return
-        _, k = r.frames_in_flight()
+        k = traced[0] % F                                   # the ring slot this frame takes
         ev = consumed[(traced[0] // F) & 1][k]
         if ev is not None and not ev.query():
             # Gate on the HOST: a cross-stream wait queued in front of every frame costs the frame kernels their L2 contents (an acquire
             # per launch; measured 115 instead of 55 us per frame on a 1/8 share).  The event is two trips old: it has almost always fired.
             ev.synchronize()
-        r.trace()
-        traced[0] += 1
         if args.ao:
+            r.trace()
             r.trace_ao(args.ao)                             # per tile from the local G-buffer: no extra exchange
-        r.stream_wait_frame(stream.cuda_stream)             # torch's stream (hence RCCL) waits for this frame
+            r.stream_wait_frame(stream_ptr)
+        else:
+            r.trace_for_stream(stream_ptr)                  # trace + "torch's stream (hence RCCL) waits for this frame", one call
+        traced[0] += 1
         pending[1] += 1
         if pending[1] == GB or k + 1 == F:                  # the exchange runs once per GB frames (never across the ring's wrap: one contiguous slice)
             exchange()

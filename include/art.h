@@ -117,6 +117,8 @@ int32_t art_frames_in_flight(ArtContext *ctx, uint32_t *frames, uint32_t *next_s
 int32_t art_stream_wait_frame(ArtContext *ctx, void *hip_stream);
 /* make the NEXT art_trace wait (on the device) for an external hipEvent_t, e.g. "the gather that read this slot's tiles
  * three frames ago has finished" */
+/* art_trace + art_stream_wait_frame in one call (the per-frame host path of a sharded run); *slot_used = the ring slot the frame took */
+int32_t art_trace_for_stream(ArtContext *ctx, void *hip_stream, uint32_t *slot_used);
 int32_t art_wait_external_event(ArtContext *ctx, void *hip_event);
 
 /* add_model (renderer.rs:346) -> VkModel::create_blas geometry contract (vk_model.rs:886-943): one call per glTF
