@@ -48,6 +48,7 @@ struct FrameSlot {
     DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
     DevBuf<float> d_depth;
     DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; bool ao_valid = false;
+    DevBuf<int> d_ao_entry;            // per local pixel: the node its AO rays start from
     DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     hipEvent_t done_alias = nullptr;   // the latest frame's completion is this ring event (fused frames: one record less per frame) instead of `done`
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
@@ -60,7 +61,7 @@ struct FrameSlot {
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
-        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
+        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_entry.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
     }
 };
 constexpr uint32_t kMaxFrames = 16;
@@ -639,9 +640,9 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     r = ensure_wide(c, c->kind_ao == 4 || (c->kind_ao == 8 && c->packet_wide)); if (r) return r;
     FrameSlot &S = c->slot[c->last];
     hipStream_t s = c->stream_of(c->last);
-    if (S.d_occl.n < (size_t)c->n_local * spp || S.d_ao.n < (size_t)c->W * c->H) {
+    if (S.d_occl.n < (size_t)c->n_local * spp || S.d_ao.n < (size_t)c->W * c->H || S.d_ao_entry.n < c->n_local) {
         HIPC(hipStreamSynchronize(s));
-        HIPC(S.d_occl.ensure((size_t)c->n_local * spp)); HIPC(S.d_ao.ensure((size_t)c->W * c->H));
+        HIPC(S.d_occl.ensure((size_t)c->n_local * spp)); HIPC(S.d_ao.ensure((size_t)c->W * c->H)); HIPC(S.d_ao_entry.ensure(c->n_local));
         HIPC(hipMemset(S.d_ao.p, 0, (size_t)c->W * c->H * 4)); HIPC(hipDeviceSynchronize());
     }
     uint32_t lut[65] = {0};
@@ -649,7 +650,8 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     FrameArgs a = make_frame_args(c, S);
     HIPC(hipMemsetAsync(S.d_counters.p + 64 + 16 * 32, 0, 8 * 32 * 4, s)); // the AO launch's work cursors
     HIPC(hipEventRecord(S.ao_ev[0], s));
-    if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, S.d_ao.p, lut, s);
+    static const bool ao_entry = !std::getenv("ART_AO_ENTRY") || std::atoi(std::getenv("ART_AO_ENTRY")) != 0;
+    if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, ao_entry ? S.d_ao_entry.p : nullptr, S.d_ao.p, lut, s);
     HIPC(hipEventRecord(S.ao_ev[1], s));
     HIPC(hipEventRecord(S.done, s)); S.done_alias = nullptr;
     HIPC(hipGetLastError());

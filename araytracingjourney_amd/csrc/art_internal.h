@@ -150,7 +150,7 @@ void launch_accumulate(const FrameArgs &a, hipStream_t s);
 void launch_frame(const FrameArgs &a, hipStream_t s);      // the fused frame: primary + shade + shadow + accumulate in one launch
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s); // out[0] += shadow rays, out[1] += hit pixels
 // ambient occlusion on the frame's depth/normal outputs; occl: n_local*spp bytes; lut: spp+1 output values; cursors at counters[64+512..] are reused (queries never overlap a frame)
-void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, uint32_t *ao, const uint32_t *lut, hipStream_t s);
+void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, int *entry, uint32_t *ao, const uint32_t *lut, hipStream_t s); // entry: n_local ints of scratch (per-pixel start node) or null
 struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; int kind; }; // kind: 2 | 4 | 1
 void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);

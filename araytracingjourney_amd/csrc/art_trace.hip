@@ -502,6 +502,46 @@ __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_
     d = (T * (r * cc) + B * (r * ss)) + N * cz;
 }
 
+// AO rays are short: the 16 rays of a pixel stay inside a ball of the AO radius around one point.  Descend the 4-wide tree while
+// exactly ONE child box overlaps that ball's bounding box -- every other subtree cannot hold a triangle the rays could reach --
+// and let the pixel's rays start there (or skip them when nothing overlaps).  Quantised boxes contain the float boxes, so the test
+// errs on the side of overlap; the rays' answers are those of a walk from the root (accept() is per triangle).
+constexpr int kAoNothingNear = (int)0x80000000; // no leaf has position 2^31 - 1
+__global__ __launch_bounds__(kBlock) void k_ao_entry(FrameArgs a, const DevNode4 *__restrict__ wide, float radius, int *__restrict__ entry) {
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.n_local) return;
+    uint32_t x, y;
+    bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
+    float depth = in ? a.depth[(size_t)y * a.W + x] : 10000.0f;
+    if (!(depth < 10000.0f)) { entry[p] = kAoNothingNear; return; }
+    V3 o, d;
+    ao_ray(a.cam, a.W, a.H, x, y, depth, a.normal[(size_t)y * a.W + x], 0, o, d);
+    const float R = radius * 1.01f; // t runs to `radius` along a direction of length 1 +- rounding
+    const float lox = o.x - R, loy = o.y - R, loz = o.z - R, hix = o.x + R, hiy = o.y + R, hiz = o.z + R;
+    int cur = 0;
+    for (int level = 0; level < 64; level++) {
+        const uint4 *nq = reinterpret_cast<const uint4 *>(wide + cur);
+        uint4 qa = nq[0], qb = nq[1], qc = nq[2], qd = nq[3];
+        float ox = __uint_as_float(qa.x), oy = __uint_as_float(qa.y), oz = __uint_as_float(qa.z);
+        float sx = __uint_as_float((qa.w & 255u) << 23), sy = __uint_as_float(((qa.w >> 8) & 255u) << 23), sz = __uint_as_float(((qa.w >> 16) & 255u) << 23);
+        uint32_t mask = qa.w >> 24;
+        int refs[4] = {(int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w};
+        int n_over = 0, which = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float lx = fmaf((float)((qb.x >> (8 * i)) & 255u), sx, ox), ly = fmaf((float)((qb.y >> (8 * i)) & 255u), sy, oy), lz = fmaf((float)((qb.z >> (8 * i)) & 255u), sz, oz);
+            float hx = fmaf((float)((qb.w >> (8 * i)) & 255u), sx, ox), hy = fmaf((float)((qc.x >> (8 * i)) & 255u), sy, oy), hz = fmaf((float)((qc.y >> (8 * i)) & 255u), sz, oz);
+            bool over = ((mask >> i) & 1u) && lx <= hix && hx >= lox && ly <= hiy && hy >= loy && lz <= hiz && hz >= loz;
+            if (over) { n_over++; which = refs[i]; }
+        }
+        if (n_over == 0) { cur = kAoNothingNear; break; }
+        if (n_over > 1) break;          // the rays may go either way from here: this node is the entry
+        cur = which;
+        if (cur < 0) break;             // a single triangle is all there is
+    }
+    entry[p] = cur;
+}
+
 // what a persistent tracing wave reads its rays from and writes its results to
 enum { MODE_PRIMARY = 0, MODE_SHADOW = 1, MODE_QUERY_CLOSEST = 2, MODE_QUERY_ANY = 3, MODE_AO = 4 };
 struct TraceArgs {
@@ -520,6 +560,7 @@ struct TraceArgs {
     uint32_t *any_out;
     // MODE_AO: rays are generated from the frame's depth + view-space normal outputs (XeGTAO's inputs); slot = local pixel * spp + sample
     const float *depth; const float4 *normal; uint32_t spp; float ao_radius; uint8_t *occl;
+    const int *ao_entry;      // MODE_AO with the 4-wide nodes: per local pixel, the node its AO rays start from (k_ao_entry), or null
 };
 
 // Persistent-threads wavefront tracer.  Each wave keeps up to 64 rays in flight; when kRefill or more lanes have
@@ -585,9 +626,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
                         float depth = on ? a.depth[(size_t)y * a.W + x] : 10000.0f;
                         if (depth < 10000.0f) {
                             V3 o, d;
-                            ao_ray(a.cam, a.W, a.H, x, y, depth, a.normal[(size_t)y * a.W + x], smp, o, d);
-                            tr.start(o, d, a.ao_radius * 0.01f, a.ao_radius);
-                            active = true;
+                            int entry = a.ao_entry ? a.ao_entry[p] : 0;
+                            if (entry == kAoNothingNear) a.occl[sidx] = 0; // no box within the AO radius of this pixel: unoccluded, nothing to trace
+                            else {
+                                ao_ray(a.cam, a.W, a.H, x, y, depth, a.normal[(size_t)y * a.W + x], smp, o, d);
+                                tr.start(o, d, a.ao_radius * 0.01f, a.ao_radius);
+                                tr.cur = entry;                            // the walk starts below the part of the tree that every ray of this pixel would cross alike
+                                active = true;
+                            }
                         } else a.occl[sidx] = 0;
                     } else {
                         float4 r0 = a.rays[2 * (size_t)sidx];
@@ -1053,7 +1099,7 @@ __global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_
     for (uint32_t s = 0; s < spp; s++) k += occl[(size_t)p * spp + s];
     ao[pix] = a.depth[pix] < 10000.0f ? lut.v[k] : 255u;
 }
-void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
+void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, int *entry, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
     AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
     if (f.trace_kind[2] == 8) { // measured 2x slower than the per-ray walk (incoherent directions): off by default
         PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl;
@@ -1064,6 +1110,10 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, ui
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
+    if (f.trace_kind[2] == 4 && entry) { // one entry node per pixel for its spp rays
+        k_ao_entry<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, f.wide, radius, entry);
+        a.ao_entry = entry;
+    }
     launch_trace<MODE_AO>(a, f.trace_kind[2], f.pipelined, s);
     k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
