@@ -77,6 +77,7 @@ struct ArtContext {
     bool built = false, have_camera = false, frame_ready = false;
     int frame_waves = 8;      // ART_FRAME_WAVES: occupancy target of the fused frame kernel's instance (6 | 7 | 8)
     bool fused = true;        // packet frames run as ONE launch (k_frame); ART_FUSED=0: the four staged launches
+    int tree_builder = 1;     // with fast_trace: 1 = binned SAH on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip); ART_SAH=<n>
     bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD / ART_SAH=0: keep the Karras tree)
     bool packet_wide = false; // ART_PACKET_WIDE=1: packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
@@ -308,7 +309,8 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     // kernels, profiles/README.md r1h); ART_BVH=24 selects the per-ray walks (binary for primary rays, 4-wide for shadow rays)
     if (const char *pw = std::getenv("ART_PACKET_WIDE")) c->packet_wide = std::atoi(pw) != 0;
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
-    if (const char *sh = std::getenv("ART_SAH")) c->fast_trace = std::atoi(sh) != 0;
+    if (cfg->flags & ART_FLAG_DEVICE_TREE) c->tree_builder = 2;
+    if (const char *sh = std::getenv("ART_SAH")) { c->fast_trace = std::atoi(sh) != 0; if (std::atoi(sh) == 2) c->tree_builder = 2; else if (std::atoi(sh) == 1) c->tree_builder = 1; }
     if (const char *fu = std::getenv("ART_FUSED")) c->fused = std::atoi(fu) != 0;
     if (const char *fw = std::getenv("ART_FRAME_WAVES")) c->frame_waves = std::atoi(fw);
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
@@ -441,9 +443,18 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(hipEventRecord(e0, c->main_stream()));
     hipError_t e = lbvh_build(in, c->bvh, c->main_stream());
     if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "lbvh_build"); }
-    if (c->fast_trace) { // PREFER_FAST_TRACE (vk_model.rs:968): the traversal nodes get a SAH topology over the same leaves
-        e = sah_build(c->bvh, T, c->main_stream());
-        if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "sah_build"); }
+    if (c->fast_trace) { // PREFER_FAST_TRACE (vk_model.rs:968): the traversal nodes get a SAH-driven topology over the same leaves
+        bool done = false;
+        if (c->tree_builder == 2) { // on the device (PLOC); a tree deeper than the walks' stacks allow (never seen) is rebuilt on the host
+            uint32_t depth = 0;
+            e = ploc_build(c->bvh, T, c->main_stream(), &depth);
+            if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "ploc_build"); }
+            done = depth <= 80;
+        }
+        if (!done) {
+            e = sah_build(c->bvh, T, c->main_stream());
+            if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "sah_build"); }
+        }
     }
     HIPC(hipEventRecord(e1, c->main_stream())); HIPC(hipEventSynchronize(e1));
     float ms = 0; HIPC(hipEventElapsedTime(&ms, e0, e1));

@@ -86,6 +86,8 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s); // alloc
 hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s);
 // PREFER_FAST_TRACE: rebuilds l.nodes as a binned-SAH tree over the same leaves (host threads); frames are unchanged by construction
 hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s);
+// the same purpose on the device: parallel locally-ordered clustering over the Morton-ordered leaves; *depth_out = depth of the tree
+hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out);
 void lbvh_free(Lbvh &l);
 
 // float32 -> unsigned small float (5 exponent bits, MB mantissa bits), round to nearest even; negatives -> 0, overflow -> +Inf

@@ -78,6 +78,8 @@ typedef struct ArtConfig {
 #define ART_FLAG_FAST_BUILD 2u /* traversal nodes keep the LBVH topology (PREFER_FAST_BUILD); default: binned-SAH rebuild = PREFER_FAST_TRACE, vk_model.rs:968 */
 #define ART_FLAG_PACKED_TILES 4u /* sharded contexts: the compact tile buffer (the gather's payload) holds B10G11R11_UFLOAT_PACK32 words -- the reference's colour
                                    image format (renderer.rs:268) -- 4 B per pixel instead of RGBA32F; art_untile_gathered then assembles the packed colour image */
+#define ART_FLAG_DEVICE_TREE 8u /* build the PREFER_FAST_TRACE tree on the device (parallel locally-ordered clustering over the Morton-ordered leaves)
+                                  instead of the binned SAH on the host threads: 4x faster build, ~4 % fewer rays/s (profiles/README.md) */
 #define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits) */
 
 typedef struct ArtStats {

@@ -339,10 +339,10 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
     from araytracingjourney_amd import scenes
     sc = get_scene("sponza_like", 0.12)
     w, h = 320, 200
-    def frame(frames_in_flight, fast_build=False, env=None):
+    def frame(frames_in_flight, fast_build=False, env=None, device_tree=False):
         for k, v in (env or {}).items():
             monkeypatch.setenv(k, v)
-        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=frames_in_flight, fast_build=fast_build)
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=frames_in_flight, fast_build=fast_build, device_tree=device_tree)
         for k in (env or {}):
             monkeypatch.delenv(k)
         for d in scenes.sponza_lights(4):
@@ -354,7 +354,8 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
     ref = frame(4)                                               # fused, SAH (the default with several frames in flight)
     assert ref[3]["frame_launches"] == 1 and ref[3]["shadow_rays"] > 10000
     for name, got in (("staged packets", frame(4, env={"ART_FUSED": "0"})), ("per-ray", frame(1, env={"ART_BVH": "24"})), ("fused, one frame in flight", frame(1)),
-                      ("fused on the LBVH topology", frame(4, fast_build=True)), ("per-ray on the LBVH topology", frame(1, fast_build=True, env={"ART_BVH": "24"})),
+                      ("fused on the LBVH topology", frame(4, fast_build=True)), ("fused on the device-built (PLOC) tree", frame(4, device_tree=True)),
+                      ("per-ray on the PLOC tree", frame(1, device_tree=True, env={"ART_BVH": "24"})), ("per-ray on the LBVH topology", frame(1, fast_build=True, env={"ART_BVH": "24"})),
                       ("fused, 7 waves/SIMD", frame(4, env={"ART_FRAME_WAVES": "7"})), ("fused, no block reordering", frame(4, env={"ART_MACRO": "0"}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
@@ -399,11 +400,12 @@ def test_residency_only_device_models_are_traced(R, get_scene):
     both.close(); only.close()
 
 
+@pytest.mark.parametrize("device_tree", [False, True])
 @pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12), ("sponza_like", 1.0)])
-def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail):
+def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail, device_tree):
     """what makes the SAH rebuild invisible: every leaf of the canonical LBVH hangs in the traversal tree exactly once,
     every node box is the exact min/max union of its children's boxes, the root is node 0, the depth stays inside the walks' stacks"""
-    r = R.renderer_for_scene(get_scene(name, detail), (64, 64))
+    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=device_tree)   # binned SAH on the host / PLOC on the device
     lb, tr = r.get_lbvh(), r.get_traversal_tree()
     T = lb["leaf_gid"].size
     child = tr["child"]
