@@ -162,9 +162,10 @@ int32_t setup_frame(ArtContext *c) {
     uint32_t count = c->cfg.shard_count > 1 ? c->cfg.shard_count : 1, rank = count > 1 ? c->cfg.shard_rank : 0;
     c->tile_list.clear();
     std::vector<uint32_t> per(count, 0), slot_of((size_t)c->tiles_x * c->tiles_y);
+    const std::vector<uint8_t> owner_of = shard_owner_table(c->tiles_x, c->tiles_y, count);
     for (uint32_t ty = 0; ty < c->tiles_y; ty++)
         for (uint32_t tx = 0; tx < c->tiles_x; tx++) {
-            uint32_t o = tile_owner(tx, ty, count);
+            uint32_t o = owner_of[(size_t)ty * c->tiles_x + tx];
             slot_of[(size_t)ty * c->tiles_x + tx] = (o << 24) | per[o];
             per[o]++;
             if (o == rank) c->tile_list.push_back(ty * c->tiles_x + tx);
@@ -287,6 +288,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
         return fail(ART_E_NO_DEVICE, std::string("art_create: device is ") + prop.gcnArchName + ", libart is built for gfx950 only");
     if (cfg->morton_bits != 0 && cfg->morton_bits != 30 && cfg->morton_bits != 63) return fail(ART_E_INVALID, "art_create: morton_bits must be 0, 30 or 63");
     if (cfg->shard_count > 1 && cfg->shard_rank >= cfg->shard_count) return fail(ART_E_INVALID, "art_create: shard_rank >= shard_count");
+    if (cfg->shard_count > 255) return fail(ART_E_INVALID, "art_create: at most 255 shards");
     if (cfg->frames_in_flight > kMaxFrames) return fail(ART_E_INVALID, "art_create: at most 16 frames in flight");
     ArtContext *c = new (std::nothrow) ArtContext();
     if (!c) return fail(ART_E_NOMEM, "art_create: out of memory");
@@ -744,10 +746,12 @@ int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, 
     uint32_t count = shard_count > 1 ? shard_count : 1;
     if (shard_rank >= count) return fail(ART_E_INVALID, "art_shard_layout: shard_rank >= shard_count");
     uint32_t tx_n = (width + kTile - 1) / kTile, ty_n = (height + kTile - 1) / kTile, mine = 0;
+    if (count > 255) return fail(ART_E_INVALID, "art_shard_layout: at most 255 shards");
     std::vector<uint32_t> per(count, 0);
+    const std::vector<uint8_t> owner_of = shard_owner_table(tx_n, ty_n, count);
     for (uint32_t ty = 0; ty < ty_n; ty++)
         for (uint32_t tx = 0; tx < tx_n; tx++) {
-            uint32_t o = tile_owner(tx, ty, count);
+            uint32_t o = owner_of[(size_t)ty * tx_n + tx];
             per[o]++;
             if (o == shard_rank) { if (tiles && mine < cap) tiles[mine] = ty * tx_n + tx; mine++; }
         }

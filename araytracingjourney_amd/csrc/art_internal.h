@@ -5,6 +5,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "../../include/art.h"
 
 namespace art {
@@ -173,6 +175,26 @@ void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t s
 
 // shard tile ownership: 32x32 tile (tx,ty) belongs to shard (tx + 5*ty) % count -- a diagonal interleave, so that
 // every shard gets a near-equal number of tiles from every screen region (load balance)
-__host__ __device__ inline uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_t count) { return count <= 1 ? 0u : (tx + 5u * ty) % count; }
+// Which shard owns which 32x32 tile (row-major table).  The tiles are walked along a Morton curve in groups of `count` neighbours and
+// every group hands its tiles to the shards in a fresh pseudo-random order: each shard holds one tile of every neighbourhood (its work
+// follows the frame's cost everywhere) and no lattice can beat against the scene's regularities -- the diagonal interleave
+// (tx + 5 ty) mod count left the slowest of 8 shards 18 % above the mean on config 2 (profiles/README.md r1k).  Shares differ by <= 1 tile.
+inline std::vector<uint8_t> shard_owner_table(uint32_t tiles_x, uint32_t tiles_y, uint32_t count) {
+    std::vector<uint8_t> owner((size_t)tiles_x * tiles_y, 0);
+    if (count <= 1) return owner;
+    auto spread = [](uint32_t v) { v &= 0xFFFFu; v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
+    std::vector<std::pair<uint32_t, uint32_t>> order; // (Morton key, tile)
+    order.reserve(owner.size());
+    for (uint32_t ty = 0; ty < tiles_y; ty++) for (uint32_t tx = 0; tx < tiles_x; tx++) order.push_back({spread(tx) | (spread(ty) << 1), ty * tiles_x + tx});
+    std::sort(order.begin(), order.end());
+    std::vector<uint32_t> perm(count);
+    for (size_t g = 0; g * count < order.size(); g++) {
+        uint32_t state = (uint32_t)g * 2654435761u + 0x9E3779B9u; // one small generator per group: the table is the same on every rank
+        for (uint32_t i = 0; i < count; i++) perm[i] = i;
+        for (uint32_t i = count - 1; i > 0; i--) { state = state * 1664525u + 1013904223u; uint32_t j = (state >> 8) % (i + 1); std::swap(perm[i], perm[j]); }
+        for (uint32_t i = 0; i < count && g * count + i < order.size(); i++) owner[order[g * count + i].second] = (uint8_t)perm[i];
+    }
+    return owner;
+}
 
 } // namespace art

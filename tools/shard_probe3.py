@@ -7,7 +7,7 @@ import os
 FF = int(os.environ.get('PF', '16'))
 GG = int(os.environ.get('PG', '32'))
 for G, F, graph in ((GG, FF, True),):
-    r = renderer.renderer_for_scene(sc, (1920, 1080), shard=(0, G), frames_in_flight=F)
+    r = renderer.renderer_for_scene(sc, (1920, 1080), shard=(int(os.environ.get("PK", "0")), G), frames_in_flight=F)
     r.upload_state(); r.set_graph_mode(graph)
     for i in range(40): r.trace()
     r.sync()
