@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-frames", type=int, default=8, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
+    ap.add_argument("--compositor", default="auto", choices=["auto", "dedicated", "shared"],
+                    help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
+                         "1/(N-1) each (the exchange no longer waits behind rank 0's own frames); auto = dedicated from 4 GPUs on")
     ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
@@ -83,7 +86,11 @@ def main():
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
     F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else 16
     packed = world > 1 and args.gather == "packed"
-    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=(rank, world), frames_in_flight=F, packed_tiles=packed)
+    dedicated = world > 1 and (args.compositor == "dedicated" or (args.compositor == "auto" and world >= 4))
+    G = world - 1 if dedicated else world           # shards of the frame = ranks that trace
+    renders = not (dedicated and rank == 0)
+    shard = ((rank - 1) if dedicated else rank, G) if renders else (0, G)   # the compositor keeps a context for the layout tables and the un-tile
+    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=shard if world > 1 else (0, 1), frames_in_flight=F, packed_tiles=packed)
     r.upload_state()
     stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
     torch.cuda.set_stream(stream)
@@ -122,7 +129,9 @@ def main():
             # Gate on the HOST: a cross-stream wait queued in front of every frame costs the frame kernels their L2 contents (an acquire
             # per launch; measured 115 instead of 55 us per frame on a 1/8 share).  The event is two trips old: it has almost always fired.
             ev.synchronize()
-        if args.ao:
+        if not renders:
+            pass                                            # the compositor only takes part in the exchange
+        elif args.ao:
             r.trace()
             r.trace_ao(args.ao)                             # per tile from the local G-buffer: no extra exchange
             r.stream_wait_frame(stream_ptr)
@@ -153,7 +162,8 @@ def main():
                 for w in range(world):
                     gathered[w, k0:k0 + n].copy_(parts[w])
         if rank == 0:                                       # every frame of the exchange is un-tiled, by one launch
-            r.untile_gathered(gathered[0, k0].data_ptr(), world, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * padded, n_frames=n)
+            first = 1 if dedicated else 0                   # shard s of the frame came from rank first + s
+            r.untile_gathered(gathered[first, k0].data_ptr(), G, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * padded, n_frames=n)
             newest[0] = n - 1
         ev = torch.cuda.Event()
         ev.record(stream)
@@ -190,6 +200,8 @@ def main():
     iso, _ = r.collect_timings()
 
     st = r.stats()
+    if not renders:                   # the compositor traced nothing
+        st = dict(st, primary_rays=0, shadow_rays=0, ao_rays=0, hit_pixels=0)
     rays_local = st["primary_rays"] + st["shadow_rays"] + st["ao_rays"]
     # outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit
     frame_ok = None
@@ -295,7 +307,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{'bistro_like(seed=0xB157' if args.scene == 'bistro' else 'sponza_like(seed=0x5A0A'}, {sc.n_tris} triangles, {len(sc.primitives)} primitives) {W}x{H}, {len(lights)} light(s), "
                                f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {world} GPUs + RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {GB} frames per gather") + f", {F} frames in flight"},
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else "") + f", RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {GB} frames per gather") + f", {F} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F, "hip_graph_replay": use_graph,
         "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "build_ms": st["build_ms"],
         "gathered_frame_equals_single_gpu_frame": frame_ok,
