@@ -1,6 +1,7 @@
 // art_api.hip -- the C ABI of include/art.h: context, scene tables, frame orchestration, host maths.
 // Product code; gfx950 only; there is no CPU fallback anywhere in this file.
 #include "art_internal.h"
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -106,6 +107,24 @@ struct ArtContext {
     hipStream_t stream_of(uint32_t k) const { return (ext_stream && F == 1) ? ext_stream : slot[k].own; }
     hipStream_t main_stream() const { return stream_of(0); }
 };
+
+// Frame streams are kept for the life of the process and handed from a destroyed context to the next one: streams created after
+// others were destroyed share hardware queues badly (a context made after another had been destroyed ran 60 % slower, profiles r1k).
+static std::mutex g_stream_mutex;
+static std::vector<std::pair<int, hipStream_t>> g_free_streams; // (device, stream)
+static hipError_t acquire_stream(int device, hipStream_t *out) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        for (size_t i = 0; i < g_free_streams.size(); i++)
+            if (g_free_streams[i].first == device) { *out = g_free_streams[i].second; g_free_streams.erase(g_free_streams.begin() + (long)i); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void release_stream(int device, hipStream_t s) {
+    (void)hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    g_free_streams.push_back({device, s});
+}
 
 namespace {
 
@@ -298,7 +317,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     c->F = cfg->frames_in_flight == 0 ? 1 : cfg->frames_in_flight;
     hipError_t e = hipSetDevice(dev);
     for (uint32_t k = 0; k < c->F && e == hipSuccess; k++) {
-        e = hipStreamCreateWithFlags(&c->slot[k].own, hipStreamNonBlocking);
+        e = acquire_stream(c->device, &c->slot[k].own);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->slot[k].done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&c->slot[k].ao_ev[0]);
         if (e == hipSuccess) e = hipEventCreate(&c->slot[k].ao_ev[1]);
@@ -334,7 +353,7 @@ int32_t art_destroy(ArtContext *c) {
         c->slot[k].release();
         if (c->slot[k].done) (void)hipEventDestroy(c->slot[k].done);
         for (int i = 0; i < 2; i++) if (c->slot[k].ao_ev[i]) (void)hipEventDestroy(c->slot[k].ao_ev[i]);
-        if (c->slot[k].own) (void)hipStreamDestroy(c->slot[k].own);
+        if (c->slot[k].own) release_stream(c->device, c->slot[k].own);
     }
     for (int f = 0; f < ArtContext::kRing; f++)
         for (int i = 0; i < 5; i++) if (c->ev[f][i]) (void)hipEventDestroy(c->ev[f][i]);
