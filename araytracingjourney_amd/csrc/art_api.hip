@@ -65,7 +65,7 @@ struct FrameSlot {
         d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_entry.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
     }
 };
-constexpr uint32_t kMaxFrames = 16;
+constexpr uint32_t kMaxFrames = 24;
 
 struct ArtContext {
     ArtConfig cfg{};
@@ -308,7 +308,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     if (cfg->morton_bits != 0 && cfg->morton_bits != 30 && cfg->morton_bits != 63) return fail(ART_E_INVALID, "art_create: morton_bits must be 0, 30 or 63");
     if (cfg->shard_count > 1 && cfg->shard_rank >= cfg->shard_count) return fail(ART_E_INVALID, "art_create: shard_rank >= shard_count");
     if (cfg->shard_count > 255) return fail(ART_E_INVALID, "art_create: at most 255 shards");
-    if (cfg->frames_in_flight > kMaxFrames) return fail(ART_E_INVALID, "art_create: at most 16 frames in flight");
+    if (cfg->frames_in_flight > kMaxFrames) return fail(ART_E_INVALID, "art_create: at most 24 frames in flight");
     ArtContext *c = new (std::nothrow) ArtContext();
     if (!c) return fail(ART_E_NOMEM, "art_create: out of memory");
     c->cfg = *cfg;

@@ -20,7 +20,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Several frames are kept in flight (the reference keeps 3: renderer.rs:135); each ring slot's stream needs a hardware queue of
 # its own to overlap with the others, and the runtime's default is 4.  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# A share of a sharded frame is bound by its slowest 8x8 block (a launch lasts as long as that wave) and gains from more launches in
+# flight: 20 slots on 20 queues (1/8 share: 42 -> 36 us per frame).  From 23 streams on the command processor falls off a cliff
+# (3x slower), so the count stays capped; the whole frame on one GPU is the same at 16 and 20.
+_SHARDED = int(os.environ.get("WORLD_SIZE", "1")) > 1
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20" if _SHARDED else "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 
@@ -47,7 +51,7 @@ def main():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-frames", type=int, default=8, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
+    ap.add_argument("--gather-frames", type=int, default=10, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
     ap.add_argument("--compositor", default="auto", choices=["auto", "dedicated", "shared"],
                     help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
                          "1/(N-1) each (the exchange no longer waits behind rank 0's own frames); auto = dedicated from 4 GPUs on")
@@ -84,7 +88,7 @@ def main():
         sc = scenes.sponza_like(args.detail)
         lights = scenes.sponza_lights(args.lights)
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    F = max(1, min(16, args.frames_in_flight)) if args.frames_in_flight > 0 else 16
+    F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (20 if world > 1 else 16)
     packed = world > 1 and args.gather == "packed"
     dedicated = world > 1 and (args.compositor == "dedicated" or (args.compositor == "auto" and world >= 4))
     G = world - 1 if dedicated else world           # shards of the frame = ranks that trace

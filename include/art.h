@@ -71,7 +71,7 @@ typedef struct ArtConfig {
     uint32_t shard_rank;  /* screen-tile sharding: this context renders the 32x32 tiles owned by shard_rank of */
     uint32_t shard_count; /*   shard_count (0 or 1 = whole frame) */
     uint32_t flags;       /* ART_FLAG_* */
-    uint32_t frames_in_flight; /* 0|1 = one; up to 16: a ring of per-frame streams + buffers like the reference's FrameData
+    uint32_t frames_in_flight; /* 0|1 = one; up to 24 (more than ~22 streams stall the command processor): a ring of per-frame streams + buffers like the reference's FrameData
                                   ring (renderer.rs:135, :300-318); art_trace then returns while up to N-1 older frames run */
 } ArtConfig;
 

@@ -5,7 +5,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, ".")
 import torch
 from araytracingjourney_amd import renderer, scenes
-G, F, GB = int(sys.argv[1]), 16, int(sys.argv[2]) if len(sys.argv) > 2 else 4
+G, F, GB = int(sys.argv[1]), int(os.environ.get("PF", "16")), int(sys.argv[2]) if len(sys.argv) > 2 else 4
 MODE = sys.argv[3] if len(sys.argv) > 3 else "full"   # full | nountile | nocopy | noexchange | nowait
 sc = scenes.sponza_like()
 W, H = 1920, 1080
