@@ -6,7 +6,7 @@
 // (:643-681), copy_model_data_to_ptr (:156-281: the 48-byte interleave, indices, texture array) and
 // get_primitives_bounding_sphere (:283-399, Ritter).  The crate itself is an un-vendored dependency (gltf = "1.0.0",
 // Cargo.toml:40), so its job is restated here: GLB container, glTF JSON, PNG decode (zlib inflate + unfilter).
-// No device code in this file; JPEG images are not decoded (reported as an error).
+// No device code in this file; JPEG images go through art_jpeg.hip (baseline only; progressive streams are reported as an error).
 #include "../../include/art.h"
 #include <zlib.h>
 #include <cmath>
@@ -16,6 +16,9 @@
 #include <memory>
 #include <string>
 #include <vector>
+
+namespace art { bool decode_jpeg(const uint8_t *data, size_t n, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, int &channels, std::string &err); } // art_jpeg.hip
+using art::decode_jpeg;
 
 namespace {
 
@@ -249,7 +252,12 @@ int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce
             if (!views || vi < 0 || (size_t)vi >= views->size()) return gfail(ART_E_INVALID, "image without a buffer view (external URIs are not read)");
             uint64_t o = (uint64_t)views->a[vi].num("byteOffset", 0), l = (uint64_t)views->a[vi].num("byteLength", 0);
             if (o + l > g->buffer.size()) return gfail(ART_E_INVALID, "image buffer view out of range");
-            if (!decode_png(g->buffer.data() + o, (size_t)l, I, err)) return gfail(ART_E_INVALID, "image decode: " + err);
+            const uint8_t *img = g->buffer.data() + o;
+            if (l >= 2 && img[0] == 0xFF && img[1] == 0xD8) { // JPEG: RGB8 or R8, like the image crate's decode of it
+                int ch = 0;
+                if (!decode_jpeg(img, (size_t)l, I.pixels, I.width, I.height, ch, err)) return gfail(ART_E_INVALID, "image decode: " + err);
+                I.format = ch == 1 ? F_R8 : F_R8G8B8;
+            } else if (!decode_png(img, (size_t)l, I, err)) return gfail(ART_E_INVALID, "image decode: " + err);
             g->images.push_back(std::move(I));
         }
     }

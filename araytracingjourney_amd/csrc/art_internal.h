@@ -83,6 +83,8 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
 };
+// art_jpeg.hip: baseline JPEG -> RGB8 (channels 3) or R8 (1), row-major
+bool decode_jpeg(const uint8_t *data, size_t n, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, int &channels, std::string &err);
 hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s); // allocates out.*, frees temporaries
 // the 4-wide collapses (DevNode4, DevNodeW): built on first use -- only the per-ray shadow/AO walks and ART_PACKET_WIDE need them
 hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s);

@@ -56,10 +56,24 @@ def write_glb(path, primitives, png_modes=("RGBA", "RGB", "RGBA"), interleaved=F
                 data = io.BytesIO()
                 Image.fromarray(np.ascontiguousarray(px[..., :3]), "RGB").quantize(256).save(data, format="PNG")
                 data = data.getvalue()
+            elif mode.startswith("JPEG"):   # "JPEG444", "JPEG420", "JPEG422", "JPEGL" (grey), optional "+R<n>" restart interval in MCUs
+                data = io.BytesIO()
+                kind, _, rst = mode.partition("+R")
+                img = Image.fromarray(np.ascontiguousarray(px[..., :3]), "RGB")
+                kw = dict(format="JPEG", quality=92, progressive=kind.endswith("P"))
+                kind = kind.rstrip("P")
+                if kind == "JPEGL":
+                    img = img.convert("L")
+                else:
+                    kw["subsampling"] = {"JPEG444": 0, "JPEG422": 1, "JPEG420": 2}[kind]
+                if rst:
+                    kw["restart_marker_blocks"] = int(rst)
+                img.save(data, **kw)
+                data = data.getvalue()
             else:
                 data = _png(np.ascontiguousarray(px), "RGBA")
             vi = add_view(data)
-            images.append({"bufferView": vi, "mimeType": "image/png"})
+            images.append({"bufferView": vi, "mimeType": "image/jpeg" if mode.startswith("JPEG") else "image/png"})
             textures.append({"source": len(images) - 1})
             tex_ids.append(len(textures) - 1)
         materials.append({"pbrMetallicRoughness": {"baseColorTexture": {"index": tex_ids[0]}, "metallicRoughnessTexture": {"index": tex_ids[1]}},
