@@ -138,6 +138,23 @@ if rank == 0:
     assert np.array_equal(sharding.untile_host(torch.stack(pgathered).numpy().view(np.uint32), w, h, world), packed)
     assert rays.item() == ((w + 31) // 32) * ((h + 31) // 32) * 1024
     print("GLOO_OK")
+# dedicated compositor (bench.py from 4 GPUs on): rank 0 traces nothing, ranks 1.. are the shards 0.. of the frame, several frames per gather
+G = world - 1
+if G >= 1:
+    F = 3
+    frames = [frame * np.float32(1 + j) for j in range(F)]
+    if rank == 0:
+        _, padded = sharding.shard_layout(w, h, G, 0)
+        mine = torch.zeros((F, padded, 32, 32, 4), dtype=torch.float32)              # a dummy of the right size
+    else:
+        mine = torch.from_numpy(np.stack([sharding.tile_host(f, G, rank - 1) for f in frames]))
+    parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, parts, dst=0)
+    if rank == 0:
+        got = torch.stack(parts[1:]).numpy()                                          # [shard][frame][padded]...
+        for j in range(F):
+            assert np.array_equal(sharding.untile_host(got[:, j], w, h, G), frames[j]), j
+        print("COMPOSITOR_OK")
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -150,7 +167,17 @@ def test_two_rank_gather_over_gloo(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
                         str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0 and "GLOO_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "GLOO_OK" in r.stdout and "COMPOSITOR_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_three_rank_dedicated_compositor_over_gloo(tmp_path):
+    """world_size 3: rank 0 composites, ranks 1-2 are the two shards (the N >= 4 mode of bench.py), frames batched per gather"""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1", "--master-port", "29542",
+                        str(script), ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "GLOO_OK" in r.stdout and "COMPOSITOR_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_model_residency_state_machine():
