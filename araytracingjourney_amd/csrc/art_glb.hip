@@ -6,7 +6,7 @@
 // (:643-681), copy_model_data_to_ptr (:156-281: the 48-byte interleave, indices, texture array) and
 // get_primitives_bounding_sphere (:283-399, Ritter).  The crate itself is an un-vendored dependency (gltf = "1.0.0",
 // Cargo.toml:40), so its job is restated here: GLB container, glTF JSON, PNG decode (zlib inflate + unfilter).
-// No device code in this file; JPEG images go through art_jpeg.hip (baseline only; progressive streams are reported as an error).
+// No device code in this file; JPEG images go through art_jpeg.hip (baseline and progressive Huffman streams).
 #include "../../include/art.h"
 #include <zlib.h>
 #include <cmath>

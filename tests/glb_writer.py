@@ -61,7 +61,7 @@ def write_glb(path, primitives, png_modes=("RGBA", "RGB", "RGBA"), interleaved=F
                 kind, _, rst = mode.partition("+R")
                 img = Image.fromarray(np.ascontiguousarray(px[..., :3]), "RGB")
                 kw = dict(format="JPEG", quality=92, progressive=kind.endswith("P"))
-                kind = kind.rstrip("P")
+                kind = kind[:-1] if kind.endswith("P") else kind
                 if kind == "JPEGL":
                     img = img.convert("L")
                 else:

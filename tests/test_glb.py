@@ -95,7 +95,7 @@ def test_png_decode_matches_pillow():
 
 
 def test_jpeg_textures_decode_close_to_pillow(tmp_path, get_scene):
-    """baseline JPEG in a GLB (the gltf crate's import() decodes JPEG as well as PNG): 4:4:4 / 4:2:2 / 4:2:0, grey, restart intervals.
+    """JPEG in a GLB (the gltf crate's import() decodes JPEG as well as PNG): baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0, grey, restart intervals.
     Decoders differ by an LSB or two in the inverse DCT and the chroma filter: mean |diff| < 0.6, max <= 6 against Pillow (libjpeg-turbo)"""
     from PIL import Image
     from glb_writer import write_glb
@@ -107,7 +107,7 @@ def test_jpeg_textures_decode_close_to_pillow(tmp_path, get_scene):
     pic = np.stack([127 + 120 * np.sin(xx / 17) * np.cos(yy / 23), 127 + 100 * np.cos(xx / 9 + yy / 31), 40 + xx * 0.9 + 20 * np.sin(yy / 5), 255 + 0 * xx], -1)
     tex = np.broadcast_to(np.clip(pic, 0, 255).astype(np.uint8), (3, 120, 200, 4)).copy()
     prim = scenes.Primitive(p.verts, p.indices, tex, p.model)
-    for modes in (("JPEG444", "JPEG420", "JPEG422"), ("JPEG420+R3", "JPEG444+R1", "JPEG422+R7")):
+    for modes in (("JPEG444", "JPEG420", "JPEG422"), ("JPEG420+R3", "JPEG444+R1", "JPEG422+R7"), ("JPEG444P", "JPEG420P", "JPEG422P"), ("JPEG420P+R2", "JPEG444P+R5", "JPEG422P")):
         path = tmp_path / ("j_" + "_".join(m.replace("+", "") for m in modes) + ".glb")
         write_glb(str(path), [prim], png_modes=modes)
         doc, bin_ = _parse(str(path))
@@ -130,10 +130,7 @@ def test_jpeg_textures_decode_close_to_pillow(tmp_path, get_scene):
     assert infos[0].image_format == 0 and np.abs(got - ref).max() <= 2
     with pytest.raises(ArtError, match="Unsupported source format"):
         mr.GltfModelReader(str(path), True, mr.COERCE_R8G8B8A8).copy_model_data_to_ptr(0, mr.ALBEDO)
-    path = tmp_path / "progressive.glb"
-    write_glb(str(path), [prim], png_modes=("JPEG444P", "JPEG444", "JPEG444"))
-    with pytest.raises(ArtError, match="progressive"):
-        mr.GltfModelReader(str(path), True, mr.COERCE_R8G8B8A8)
+
 
 
 def test_missing_attributes_and_textures_are_errors_like_the_reference_panics():
