@@ -21,10 +21,11 @@ sys.path.insert(0, ROOT)
 # Several frames are kept in flight (the reference keeps 3: renderer.rs:135); each ring slot's stream needs a hardware queue of
 # its own to overlap with the others, and the runtime's default is 4.  Must be set before the HIP runtime starts.
 # A share of a sharded frame is bound by its slowest 8x8 block (a launch lasts as long as that wave) and gains from more launches in
-# flight: 20 slots on 20 queues (1/8 share: 42 -> 36 us per frame).  From 23 streams on the command processor falls off a cliff
-# (3x slower), so the count stays capped; the whole frame on one GPU is the same at 16 and 20.
+# flight: 20 slots (1/8 share: 42 -> 36 us per frame) on 22 hardware queues, so that the exchange stream and RCCL's get queues of their
+# own.  With 24 queues in use the command processor falls off a cliff (3x slower: profiles/README.md r1k), and 22 is never exceeded
+# whatever else creates streams.  The whole frame on one GPU is the same at 16 and 20 slots.
 _SHARDED = int(os.environ.get("WORLD_SIZE", "1")) > 1
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "20" if _SHARDED else "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "22" if _SHARDED else "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 
