@@ -909,6 +909,8 @@ template <bool WIDE, int WAVES, bool ONE_LIGHT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
+    // multi-light instance: the surface record waits in LDS while a shadow packet walks, so the walk runs on as few live registers as the one-light form
+    __shared__ float surf[ONE_LIGHT ? 1 : 14 * kBlock]; // 8 blocks of 4 waves per CU must fit 160 KB with it
     if (blockIdx.x * kBlock >= a.n_local) return;
     const uint32_t p = a.block_order[blockIdx.x] * kBlock + threadIdx.x;
     uint32_t x = 0, y = 0;
@@ -942,9 +944,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     float rx = 0.f, ry = 0.f, rz = 0.f;
     uint32_t sbits = 0;
     // ONE_LIGHT: no loop, so the surface record is dead once the light is evaluated and the shadow walk runs on few live registers
+    if (!ONE_LIGHT) {
+        float *q = &surf[threadIdx.x];
+        q[0 * kBlock] = S.world_pos.x; q[1 * kBlock] = S.world_pos.y; q[2 * kBlock] = S.world_pos.z;
+        q[3 * kBlock] = S.N.x; q[4 * kBlock] = S.N.y; q[5 * kBlock] = S.N.z;
+        q[6 * kBlock] = S.Vv.x; q[7 * kBlock] = S.Vv.y; q[8 * kBlock] = S.Vv.z;
+        q[9 * kBlock] = S.albedo.x; q[10 * kBlock] = S.albedo.y; q[11 * kBlock] = S.albedo.z;
+        q[12 * kBlock] = S.metallic; q[13 * kBlock] = S.alpha; // the two N.V terms are recomputed (same operations as shade_surface)
+    }
     for (uint32_t i = 0; i < (ONE_LIGHT ? 1u : a.n_lights); i++) { // uniform loop: the shadow packet needs the whole wave
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
         bool want = false;
+        if (!ONE_LIGHT) {
+            asm volatile("" ::: "memory"); // reload, do not carry the record across the walk
+            const float *q = &surf[threadIdx.x];
+            S.world_pos = mk(q[0 * kBlock], q[1 * kBlock], q[2 * kBlock]); S.N = mk(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
+            S.Vv = mk(q[6 * kBlock], q[7 * kBlock], q[8 * kBlock]); S.albedo = mk(q[9 * kBlock], q[10 * kBlock], q[11 * kBlock]);
+            S.metallic = q[12 * kBlock]; S.alpha = q[13 * kBlock]; S.nc_NdotV = dot3(S.N, S.Vv); S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
+        }
         if (hit) want = shade_light(a.lights[i], S, c4, ro, rd);
         if (want) sbits |= 1u << (16 + i);
         Ray sr;
@@ -1063,7 +1080,7 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
 void launch_frame(const FrameArgs &a, hipStream_t s) {
-    const int waves = a.frame_waves; // multi-light instance, registers: 6 waves/SIMD -> 80, 7 -> 72 (5 spilled), 8 -> 64 (17 spilled); measured 13.19 / 13.78 / 13.85 Gray/s
+    const int waves = a.frame_waves; // both instances fit 63 registers without spills (the multi-light one parks its surface record in LDS during the shadow walks)
     const uint32_t g = blocks_for(a.n_local);
     const bool one = a.n_lights == 1;
     if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); return; }
