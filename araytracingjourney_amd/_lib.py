@@ -11,6 +11,7 @@ ART_OK, ART_E_INVALID, ART_E_STATE, ART_E_NO_DEVICE, ART_E_HIP, ART_E_NOMEM = 0,
 ART_FLAG_KEEP_DEBUG = 1
 ART_FLAG_PACKED_TILES = 4  # sharded: the gather payload is the B10G11R11 colour (4 B per pixel)
 ART_FLAG_DEVICE_TREE = 8  # the PREFER_FAST_TRACE tree by PLOC on the device instead of the host's binned SAH
+ART_FLAG_FIXED_WAVES = 16  # one wave per 8x8 block always (default: the adaptive wave plan of the fused frame)
 ART_FLAG_FAST_BUILD = 2  # keep the LBVH topology in the traversal nodes (default: binned-SAH rebuild, PREFER_FAST_TRACE)
 
 
@@ -45,7 +46,7 @@ class ArtStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("hit_pixels", C.c_uint64), ("ao_rays", C.c_uint64),
                 ("num_triangles", C.c_uint32), ("num_primitives", C.c_uint32), ("num_nodes", C.c_uint32), ("frame_launches", C.c_uint32),
                 ("build_ms", C.c_float), ("frame_ms", C.c_float), ("trace_primary_ms", C.c_float), ("shade_ms", C.c_float),
-                ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float), ("ao_ms", C.c_float), ("reserved2", C.c_uint32)]
+                ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float), ("ao_ms", C.c_float), ("split_blocks", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}

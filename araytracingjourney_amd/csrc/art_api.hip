@@ -50,6 +50,7 @@ struct FrameSlot {
     DevBuf<float> d_depth;
     DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; bool ao_valid = false;
     DevBuf<int> d_ao_entry;            // per local pixel: the node its AO rays start from
+    DevBuf<uint32_t> d_wave_cost;      // fused frame: packet steps of each wave of the slot's last launch (feedback for the wave plan)
     DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     hipEvent_t done_alias = nullptr;   // the latest frame's completion is this ring event (fused frames: one record less per frame) instead of `done`
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
@@ -62,10 +63,41 @@ struct FrameSlot {
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
-        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_entry.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
+        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_entry.release(); d_wave_cost.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
     }
 };
 constexpr uint32_t kMaxFrames = 24;
+
+// Which wave of the fused frame's launch traces what.  A launch lasts as long as its slowest wave, and an 8x8 packet that crosses dense
+// distant geometry walks the union of 64 unrelated paths: up to 0.5 ms where the rest of the launch is done after 0.1 ms.  Every wave
+// reports its packet steps; blocks that took many are dealt to four waves (4x4 pixels each) or sixteen (2x2) from the next plan on, heaviest first.
+// The image does not depend on the plan (closest / any hit are structure- and packet-independent), only the launch's tail does.
+struct WavePlan {
+    bool enabled = true;               // ART_SPLIT=0: every 8x8 block is one wave, always
+    // A block is split when its wave makes more packet steps (nodes + triangles visited, all its walks) than the launch's fair share of the
+    // machine would take anyway: alpha * (steps of the whole launch) * (launches in flight) / (wave slots of the GPU), at least min_steps.
+    // With 16 full frames in flight nothing is split (a straggler hides behind the other launches, and split waves cost more steps in
+    // total); one frame at a time, or a 1/8 share of a frame, is where the tail is the launch.
+    float alpha = 0.7f;                // ART_SPLIT_ALPHA (0.5 .. 1 measured alike on 1/8 shares)
+    uint32_t min_steps = 150;          // ART_SPLIT_STEPS
+    uint32_t fixed_steps = 0;          // ART_SPLIT_FIXED: a fixed target instead (experiments)
+    uint32_t in_flight = 1;            // min(frames in flight, hardware queues)
+    std::vector<uint32_t> order;       // launch order of the 256-pixel blocks (setup_frame)
+    std::vector<uint8_t> level;        // per 8x8 block: 0 = one wave, 1 = four quadrant waves, 2 = sixteen cell waves
+    std::vector<uint2> items[2];       // host copies of the two device tables
+    DevBuf<uint2> d_items[2]; uint32_t n_items[2] = {0, 0}; int cur = 0;
+    uint64_t last_use[2] = {0, 0};     // 1 + the last frame launched with table i (0: never)
+    uint32_t cap = 0;                  // items the cost buffers hold
+    uint32_t *h_cost = nullptr; size_t h_cost_n = 0; // pinned
+    hipEvent_t cost_ready = nullptr; bool pending = false; int pending_table = 0;
+    uint64_t next_sample = 0; uint32_t interval = 1;
+    uint32_t replans = 0;
+    void release() {
+        d_items[0].release(); d_items[1].release();
+        if (h_cost) (void)hipHostFree(h_cost); h_cost = nullptr; h_cost_n = 0;
+        if (cost_ready) (void)hipEventDestroy(cost_ready); cost_ready = nullptr;
+    }
+};
 
 struct ArtContext {
     ArtConfig cfg{};
@@ -92,8 +124,10 @@ struct ArtContext {
     // frame
     std::vector<uint32_t> tile_list; uint32_t tiles_x = 0, tiles_y = 0, padded_tiles = 0, n_local = 0;
     DevBuf<uint32_t> d_tile_list;
+    DevBuf<uint32_t> d_tile_xy;     // owned tile -> x | y << 16 (fused frame: no division per pixel lookup)
     DevBuf<uint32_t> d_tile_slot;   // un-tile table: tile -> owner << 24 | index among the owner's tiles (every shard's layout, setup_frame)
     DevBuf<uint32_t> d_block_order; // launch block -> 256-pixel block of the frame: one L2 (XCD) per screen region (setup_frame)
+    WavePlan plan;                  // fused frame: wave -> (8x8 block, cells)
     static constexpr int kRing = 128;          // per-frame stage events kept for art_collect_timings
     hipEvent_t ev[kRing][5] = {};
     bool ev_fused[kRing] = {};                 // the frame was one launch: only ev[0] and ev[4] were recorded
@@ -175,6 +209,104 @@ int32_t sync_all(ArtContext *c) {
     return ART_OK;
 }
 
+
+// ---- wave plan of the fused frame ----------------------------------------------------------------------------------------------------
+static void plan_build_items(const WavePlan &P, const std::vector<uint32_t> &cost_of_block, std::vector<uint2> &out) {
+    out.clear();
+    std::vector<std::pair<uint32_t, uint32_t>> heavy; // (cost, block), split blocks
+    for (uint32_t b = 0; b < P.level.size(); b++) if (P.level[b]) heavy.push_back({cost_of_block.empty() ? 0u : cost_of_block[b], b});
+    std::stable_sort(heavy.begin(), heavy.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) { return x.first > y.first; });
+    for (const auto &h : heavy) { // the long poles start first
+        if (P.level[h.second] == 1) { static const uint32_t quad[4] = {0x0033u, 0x00CCu, 0x3300u, 0xCC00u}; for (uint32_t q : quad) out.push_back(make_uint2(h.second, q)); }
+        else for (uint32_t cell = 0; cell < 16; cell++) out.push_back(make_uint2(h.second, 1u << cell));
+    }
+    while (out.size() & 3u) out.push_back(make_uint2(0, 0)); // whole workgroups: the blocks after them keep their place in a workgroup
+    for (uint32_t blk : P.order)
+        for (uint32_t w = 0; w < 4; w++) { uint32_t b = blk * 4 + w; out.push_back(make_uint2(b, P.level[b] ? 0u : 0xFFFFu)); } // a split block leaves an idle wave behind: the XCD order of the rest is untouched
+}
+static int32_t plan_reset(ArtContext *c) {
+    WavePlan &P = c->plan;
+    static const bool off = std::getenv("ART_SPLIT") && std::atoi(std::getenv("ART_SPLIT")) == 0;
+    P.enabled = !off && !(c->cfg.flags & ART_FLAG_FIXED_WAVES);
+    if (const char *e = std::getenv("ART_SPLIT_STEPS")) { int v = std::atoi(e); if (v > 0) P.min_steps = (uint32_t)v; }
+    if (const char *e = std::getenv("ART_SPLIT_FIXED")) { int v = std::atoi(e); if (v > 0) P.fixed_steps = (uint32_t)v; }
+    if (const char *e = std::getenv("ART_SPLIT_ALPHA")) { float v = (float)std::atof(e); if (v > 0.f) P.alpha = v; }
+    uint32_t hwq = 4; // HIP's default number of hardware queues per process
+    if (const char *e = std::getenv("GPU_MAX_HW_QUEUES")) { int v = std::atoi(e); if (v > 0) hwq = (uint32_t)v; }
+    P.in_flight = std::max(1u, std::min(c->F, hwq));
+    const uint32_t n64 = c->n_local / 64;
+    P.level.assign(n64, 0);
+    P.cap = n64 + n64 / 2 + 64;       // at most half as many waves again
+    plan_build_items(P, {}, P.items[0]);
+    P.items[1].clear();
+    for (int i = 0; i < 2; i++) { HIPC(P.d_items[i].ensure(P.cap)); P.n_items[i] = 0; P.last_use[i] = 0; }
+    if (!P.items[0].empty()) HIPC(hipMemcpy(P.d_items[0].p, P.items[0].data(), P.items[0].size() * sizeof(uint2), hipMemcpyHostToDevice));
+    P.n_items[0] = (uint32_t)P.items[0].size(); P.cur = 0;
+    if (P.h_cost_n < P.cap) { if (P.h_cost) (void)hipHostFree(P.h_cost); P.h_cost = nullptr; HIPC(hipHostMalloc((void **)&P.h_cost, (size_t)P.cap * 4, hipHostMallocDefault)); P.h_cost_n = P.cap; }
+    if (!P.cost_ready) HIPC(hipEventCreateWithFlags(&P.cost_ready, hipEventDisableTiming));
+    P.pending = false; P.next_sample = c->frame_no; P.interval = 1; P.replans = 0;
+    return ART_OK;
+}
+// A sampled frame's wave times have arrived: decide every block's level, and if anything changed write the other table and switch to it.
+static int32_t plan_poll(ArtContext *c) {
+    WavePlan &P = c->plan;
+    if (!P.pending || hipEventQuery(P.cost_ready) != hipSuccess) return ART_OK;
+    P.pending = false;
+    const std::vector<uint2> &items = P.items[P.pending_table];
+    std::vector<uint32_t> worst(P.level.size(), 0); // slowest wave of each block in the sampled frame
+    for (size_t i = 0; i < items.size(); i++) if (items[i].y) worst[items[i].x] = std::max(worst[items[i].x], P.h_cost[i]);
+    uint64_t sum = 0;
+    for (size_t i = 0; i < items.size(); i++) if (items[i].y) sum += P.h_cost[i];
+    constexpr double kWaveSlots = 256.0 * 32.0; // CUs x waves per CU
+    uint32_t T = P.fixed_steps ? P.fixed_steps : std::max(P.min_steps, (uint32_t)(P.alpha * (double)sum * P.in_flight / kWaveSlots));
+    std::vector<uint8_t> next;
+    std::vector<uint32_t> est(P.level.size(), 0);
+    for (int attempt = 0; attempt < 8; attempt++, T += T / 2) {
+        next = P.level;
+        size_t extra = 0;
+        for (size_t b = 0; b < next.size(); b++) {
+            const uint32_t w = worst[b];
+            uint8_t lv = P.level[b];
+            // going down needs a clear margin (the parts of a split block share the top of their walks: n parts cost less than n times one part)
+            if (lv == 0) lv = w > 4 * T ? 2 : w > T ? 1 : 0;
+            else if (lv == 1) lv = w > T ? 2 : (w * 4 < T / 2 ? 0 : 1);
+            else lv = w * 4 < T / 2 ? 1 : 2;
+            next[b] = lv;
+            est[b] = P.level[b] == 0 ? w : P.level[b] == 1 ? w * 4 : w * 16;
+            extra += lv == 1 ? 4 : lv == 2 ? 16 : 0;
+        }
+        if (P.level.size() + (P.level.size() & 3u) + extra + 4 <= P.cap) break;
+        next = P.level; // does not fit: a more tolerant target
+    }
+    const bool changed = next != P.level;
+    if (changed) {
+        const int other = P.cur ^ 1;
+        if (P.last_use[other]) { // frames launched with that table must have finished
+            const uint64_t f = P.last_use[other] - 1;
+            const bool done = c->frame_no - f <= (uint64_t)ArtContext::kRing ? hipEventQuery(c->ev[f % ArtContext::kRing][4]) == hipSuccess
+                                                                              : hipStreamQuery(c->stream_of((uint32_t)(f % c->F))) == hipSuccess;
+            if (!done) { P.next_sample = c->frame_no; return ART_OK; } // ask again with a fresh sample
+        }
+        P.level = next;
+        plan_build_items(P, est, P.items[other]);
+        HIPC(hipMemcpy(P.d_items[other].p, P.items[other].data(), P.items[other].size() * sizeof(uint2), hipMemcpyHostToDevice));
+        P.n_items[other] = (uint32_t)P.items[other].size();
+        P.cur = other; P.replans++;
+        static const bool log = std::getenv("ART_SPLIT_LOG") != nullptr;
+        if (log) {
+            size_t n1 = 0, n2 = 0;
+            for (size_t b = 0; b < P.level.size(); b++) { n1 += P.level[b] == 1; n2 += P.level[b] == 2; }
+            std::vector<uint32_t> w(worst); std::sort(w.begin(), w.end());
+            auto pc = [&](double q) { return w.empty() ? 0u : w[(size_t)(q * (w.size() - 1))]; };
+            std::fprintf(stderr, "[art] wave plan %u at frame %llu: %zu blocks in 4, %zu in 16, of %zu; steps of the sampled waves p50 %u p90 %u p99 %u max %u, target %u\n", P.replans,
+                         (unsigned long long)c->frame_no, n1, n2, P.level.size(), pc(0.5), pc(0.9), pc(0.99), pc(1.0), T);
+        }
+        P.interval = c->F + 1;        // let frames of the new plan come back before judging it
+    } else P.interval = P.interval < 128 ? P.interval * 2 : 256;
+    P.next_sample = c->frame_no + P.interval;
+    return ART_OK;
+}
+
 int32_t setup_frame(ArtContext *c) {
     // tile ownership + per-frame buffers for the current extent / light count
     c->tiles_x = (c->W + kTile - 1) / kTile; c->tiles_y = (c->H + kTile - 1) / kTile;
@@ -198,6 +330,12 @@ int32_t setup_frame(ArtContext *c) {
     size_t nl = c->lights.size() ? c->lights.size() : 1;
     HIPC(c->d_tile_list.ensure(c->tile_list.size()));
     if (!c->tile_list.empty()) HIPC(hipMemcpy(c->d_tile_list.p, c->tile_list.data(), c->tile_list.size() * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> xy(c->tile_list.size());
+        for (size_t i = 0; i < xy.size(); i++) xy[i] = (c->tile_list[i] % c->tiles_x) | ((c->tile_list[i] / c->tiles_x) << 16);
+        HIPC(c->d_tile_xy.ensure(xy.size()));
+        if (!xy.empty()) HIPC(hipMemcpy(c->d_tile_xy.p, xy.data(), xy.size() * 4, hipMemcpyHostToDevice));
+    }
     {   // Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2.  Group the owned tiles into macro-blocks of
         // kMacro x kMacro tiles, deal the macro-blocks round-robin to the XCDs (balance: every XCD gets pieces from all over the
         // frame) and order the launch so that XCD x works through ITS macro-blocks: its L2 then holds the BVH of a few screen
@@ -226,9 +364,14 @@ int32_t setup_frame(ArtContext *c) {
         }
         HIPC(c->d_block_order.ensure(nb ? nb : 1));
         if (nb) HIPC(hipMemcpy(c->d_block_order.p, order.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+        c->plan.order = order;
+    }
+    {
+        int32_t pr = plan_reset(c); if (pr) return pr;
     }
     for (uint32_t k = 0; k < c->F; k++) {
         FrameSlot &S = c->slot[k];
+        HIPC(S.d_wave_cost.ensure(c->plan.cap ? c->plan.cap : 1));
         HIPC(S.d_counters.ensure(kCounterWords)); HIPC(hipMemset(S.d_counters.p, 0, kCounterWords * 4)); // packet frames keep them clear themselves (k_accumulate)
         const bool staged = !(c->fused && c->kind_primary == 8 && c->kind_shadow == 8); // the fused frame keeps these records in registers
         if (staged || (c->cfg.flags & ART_FLAG_KEEP_DEBUG)) HIPC(S.d_hits.ensure(c->n_local));
@@ -348,7 +491,7 @@ int32_t art_destroy(ArtContext *c) {
     drop_graphs(c);
     lbvh_free(c->bvh);
     c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release();
-    c->d_lights[0].release(); c->d_lights[1].release(); c->d_tile_list.release();
+    c->d_lights[0].release(); c->d_lights[1].release(); c->d_tile_list.release(); c->d_tile_xy.release(); c->plan.release();
     for (uint32_t k = 0; k < kMaxFrames; k++) {
         c->slot[k].release();
         if (c->slot[k].done) (void)hipEventDestroy(c->slot[k].done);
@@ -488,6 +631,7 @@ int32_t art_scene_build(ArtContext *c) {
 int32_t art_set_camera(ArtContext *c, const ArtCamera *cam) {
     if (!c || !cam) return fail(ART_E_INVALID, "art_set_camera: null argument");
     if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) drop_graphs(c); // the camera block is a kernel argument
+    if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) { c->plan.next_sample = c->frame_no; c->plan.interval = 1; } // the heavy blocks move with the view
     c->camera = *cam; c->have_camera = true;
     return ART_OK;
 }
@@ -587,6 +731,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     a.color_tiles = c->cfg.shard_count > 1 ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
     a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0; a.frame_waves = c->frame_waves;
+    a.tile_xy = c->d_tile_xy.p; a.wave_items = c->plan.d_items[c->plan.cur].p; a.n_wave_items = c->plan.n_items[c->plan.cur]; a.wave_cost = nullptr; // art_trace sets it for the frames the wave plan samples
     return a;
 }
 
@@ -602,6 +747,7 @@ int32_t art_trace(ArtContext *c) {
     FrameSlot &S = c->slot[k];
     hipStream_t s = c->stream_of(k);
     if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
+    if (c->plan.enabled) { r = plan_poll(c); if (r) return r; }
     FrameArgs a = make_frame_args(c, S);
     if (c->cfg.shard_count > 1) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
@@ -630,10 +776,19 @@ int32_t art_trace(ArtContext *c) {
     }
     if (fused) { // one launch; its time is booked on the first stage
         HIPC(hipEventRecord(ev[0], s));
-        if (a.n_local) launch_frame(a, s);
+        WavePlan &P = c->plan;
+        const bool sample = P.enabled && !P.pending && c->frame_no >= P.next_sample && a.n_wave_items;
+        if (sample) a.wave_cost = S.d_wave_cost.p;
+        const bool counted = a.n_local ? launch_frame(a, s) : false;
         HIPC(hipEventRecord(ev[4], s));
         S.done_alias = ev[4];           // also the frame's completion event (a record is a packet in the frame's queue: 1/8 share 33 -> 29 us)
         HIPC(hipGetLastError());
+        P.last_use[P.cur] = c->frame_no + 1;
+        if (counted) { // now and then a frame counts its waves' packet steps and they go to the host
+            HIPC(hipMemcpyAsync(P.h_cost, S.d_wave_cost.p, (size_t)a.n_wave_items * 4, hipMemcpyDeviceToHost, s));
+            HIPC(hipEventRecord(P.cost_ready, s));
+            P.pending = true; P.pending_table = P.cur;
+        }
         S.ao_valid = false; S.presented = false;
         c->last = k; c->frame_no++; c->traced = true;
         return ART_OK;
@@ -915,6 +1070,8 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         }
         c->stats.primary_rays = owned; c->stats.shadow_rays = cnt[0]; c->stats.hit_pixels = cnt[1];
         c->stats.frame_launches = (c->fused && c->kind_primary == 8 && c->kind_shadow == 8) ? 1u : 4u;
+        c->stats.split_blocks = 0;
+        for (uint8_t lv : c->plan.level) c->stats.split_blocks += lv != 0;
         c->stats.ao_rays = (uint64_t)c->ao_spp * cnt[1];
         if (c->ao_spp) { float ams = 0; if (hipEventElapsedTime(&ams, c->slot[c->last].ao_ev[0], c->slot[c->last].ao_ev[1]) == hipSuccess) c->stats.ao_ms = ams; }
         float ms = 0;

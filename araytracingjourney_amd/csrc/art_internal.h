@@ -148,12 +148,17 @@ struct FrameArgs {
     uint32_t *pix_bits;        // fused frame: [n_local] shadowed / traced bits per pixel (always written)
     bool keep_hits;            // fused frame: also store the hit records (art_read_hits)
     int frame_waves;           // fused frame: occupancy target of the instance to launch (ART_FRAME_WAVES, default 8)
+    // fused frame: what each wave of the launch traces.  x = 8x8 pixel block (local pixel id / 64), y = which of its sixteen 2x2 cells
+    // (bit = (y/2)*4 + x/2).  A block whose packet crawls (dense distant geometry: up to 0.5 ms for one wave) is dealt to 4 or 16 waves.
+    const uint2 *wave_items; uint32_t n_wave_items;
+    const uint32_t *tile_xy;   // [n_tiles_owned] x | y << 16 of each owned tile (tile units)
+    uint32_t *wave_cost;       // [n_wave_items] packet steps each wave made, or nullptr
 };
 void launch_primary(const FrameArgs &a, hipStream_t s);
 void launch_shade(const FrameArgs &a, hipStream_t s);
 void launch_shadow(const FrameArgs &a, hipStream_t s);
 void launch_accumulate(const FrameArgs &a, hipStream_t s);
-void launch_frame(const FrameArgs &a, hipStream_t s);      // the fused frame: primary + shade + shadow + accumulate in one launch
+bool launch_frame(const FrameArgs &a, hipStream_t s);      // the fused frame: primary + shade + shadow + accumulate in one launch; true: it also wrote a.wave_cost (a.wave_cost set and a counting instance exists)
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s); // out[0] += shadow rays, out[1] += hit pixels
 // ambient occlusion on the frame's depth/normal outputs; occl: n_local*spp bytes; lut: spp+1 output values; cursors at counters[64+512..] are reused (queries never overlap a frame)
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, int *entry, uint32_t *ao, const uint32_t *lut, hipStream_t s); // entry: n_local ints of scratch (per-pixel start node) or null

@@ -291,11 +291,12 @@ template <int OCT> __device__ __forceinline__ bool slab_oct(const Ray &r, float 
     return fmaxf(tn, r.tmin) <= fminf(tf, tlimit);
 }
 
-template <bool ANY, bool WIDE, int OCT>
-__device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid) {
+template <bool ANY, bool WIDE, int OCT, bool COUNT = false>
+__device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps) {
     int cur = 0, sp = 0; // wave-uniform
     constexpr int kPop = (int)0x80000000; // "take the next node from the stack" (no leaf has position 2^31 - 1)
     for (;;) {
+        if (COUNT) steps++; // wave-uniform: nodes + triangles the packet visited (the fused frame's wave plan feeds on it; one s_add here costs 3.5 %, so only sampled frames count)
         if (cur >= 0 && WIDE) {
             const float4 *nq = reinterpret_cast<const float4 *>(a.widef + cur);
             float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
@@ -373,8 +374,8 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
 }
 
 // one packet through the walk that fits its rays' direction signs
-template <bool ANY, bool WIDE>
-__device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid) {
+template <bool ANY, bool WIDE, bool COUNT = false>
+__device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps) {
     uint64_t act = ballot64(on);
     if (act == 0ull) return;
     // direction signs per axis: all set, none set, or mixed over the packet's rays
@@ -382,15 +383,15 @@ __device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, 
     bool uniform = (nx == 0ull || nx == act) && (ny == 0ull || ny == act) && (nz == 0ull || nz == act);
     int oct = !uniform || WIDE ? 8 : (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
     switch (oct) {
-    case 0: packet_walk<ANY, WIDE, WIDE ? 8 : 0>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    case 1: packet_walk<ANY, WIDE, WIDE ? 8 : 1>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    case 2: packet_walk<ANY, WIDE, WIDE ? 8 : 2>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    case 3: packet_walk<ANY, WIDE, WIDE ? 8 : 3>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    case 4: packet_walk<ANY, WIDE, WIDE ? 8 : 4>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    case 5: packet_walk<ANY, WIDE, WIDE ? 8 : 5>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    case 6: packet_walk<ANY, WIDE, WIDE ? 8 : 6>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    case 7: packet_walk<ANY, WIDE, WIDE ? 8 : 7>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
-    default: packet_walk<ANY, WIDE, 8>(a, r, on, stk, tbest, bu, bv, bpos, bgid); break;
+    case 0: packet_walk<ANY, WIDE, WIDE ? 8 : 0, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 1: packet_walk<ANY, WIDE, WIDE ? 8 : 1, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 2: packet_walk<ANY, WIDE, WIDE ? 8 : 2, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 3: packet_walk<ANY, WIDE, WIDE ? 8 : 3, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 4: packet_walk<ANY, WIDE, WIDE ? 8 : 4, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 5: packet_walk<ANY, WIDE, WIDE ? 8 : 5, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 6: packet_walk<ANY, WIDE, WIDE ? 8 : 6, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 7: packet_walk<ANY, WIDE, WIDE ? 8 : 7, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    default: packet_walk<ANY, WIDE, 8, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
     }
 }
 
@@ -438,7 +439,8 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
     const bool traced = on;
     float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f; // -1: below every tmin, no box test passes (lanes without a ray, occluded lanes)
     uint32_t bpos = kNoHit, bgid = kNoHit;
-    walk_dispatch<ANY, WIDE>(a, r, on, stk, tbest, bu, bv, bpos, bgid);
+    uint32_t steps = 0;
+    walk_dispatch<ANY, WIDE>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps);
     if (MODE == PK_PRIMARY) {
         if (slot < total) st_nt(&a.hits[slot], bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit)));
     } else if (MODE == PK_SHADOW) {
@@ -905,19 +907,37 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
 // latency and ALU of the shading), which is what the staged frame needed a dozen frames in flight for.  The arithmetic and its
 // order are the staged kernels': the frames are bit-identical.  pix_bits[p]: bit i = light i shadowed, bit 16+i = shadow ray
 // traced (art_get_stats counts rays from it on demand; art_read_shadow_bits).
-template <bool WIDE, int WAVES, bool ONE_LIGHT>
+// the same value, but the compiler cannot know it: what is computed from it is computed again instead of being kept in registers.
+// (A "memory" clobber would do that too, and would turn every wave-uniform node fetch after it from a scalar into a vector load.)
+__device__ __forceinline__ uint32_t launder(uint32_t v) { asm volatile("" : "+s"(v)); return v; }   // wave-uniform values
+__device__ __forceinline__ uint32_t launder_v(uint32_t v) { asm volatile("" : "+v"(v)); return v; } // per-lane values
+// what lane `__lane_id()` of wave item `wid` traces: local pixel id, frame coordinates, whether the item's cell mask covers it; returns "traces a ray"
+__device__ __forceinline__ bool frame_pixel(const FrameArgs &a, uint32_t wid, uint32_t &p, uint32_t &x, uint32_t &y, bool &mine) {
+    const uint2 item = a.wave_items[wid];           // wave-uniform: scalar loads, no divisions
+    const uint32_t txy = a.tile_xy[item.x >> 4];    // the block's 32x32 tile: x | y << 16
+    const uint32_t lane = __lane_id(), sub = item.x & 15u;
+    p = item.x * 64u + lane;
+    mine = (item.y >> (((lane >> 4) << 2) | ((lane >> 1) & 3u))) & 1u; // cell = (y/2)*4 + x/2 of the 8x8 block
+    x = (txy & 0xFFFFu) * kTile + (sub & 3u) * 8u + (lane & 7u);
+    y = (txy >> 16) * kTile + (sub >> 2) * 8u + (lane >> 3);
+    return x < a.W && y < a.H && mine;
+}
+template <bool WIDE, int WAVES, bool ONE_LIGHT, bool COUNT = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
     // multi-light instance: the surface record waits in LDS while a shadow packet walks, so the walk runs on as few live registers as the one-light form
     __shared__ float surf[ONE_LIGHT ? 1 : 14 * kBlock]; // 8 blocks of 4 waves per CU must fit 160 KB with it
-    if (blockIdx.x * kBlock >= a.n_local) return;
-    const uint32_t p = a.block_order[blockIdx.x] * kBlock + threadIdx.x;
-    uint32_t x = 0, y = 0;
-    const bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
-    const size_t pix = (size_t)y * a.W + x;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    if (wid >= a.n_wave_items) return;
+    uint32_t steps = 0; // packet steps of this wave, all walks
+    // The pixel a lane works on is looked up again wherever it is needed (here, at the depth/normal stores, at the end) instead of being
+    // carried through the walks: the walks run at the 64-register edge.
+    bool in;
     Ray r;
     {
+        uint32_t p, x, y; bool mine;
+        in = frame_pixel(a, wid, p, x, y, mine);
         float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
         float dx = (fx / (float)a.W) * 2.0f - 1.0f, dy = (fy / (float)a.H) * 2.0f - 1.0f;
         V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
@@ -928,8 +948,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     bool on = in;
     float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f;
     uint32_t bpos = kNoHit, bgid = kNoHit;
-    walk_dispatch<false, WIDE>(a, r, on, stk, tbest, bu, bv, bpos, bgid);
-    if (a.keep_hits) a.hits[p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+    walk_dispatch<false, WIDE, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps);
+    uint32_t p, x, y; bool mine;
+    frame_pixel(a, wid, p, x, y, mine);
+    if (a.keep_hits && mine) a.hits[p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
     const bool hit = in && bpos != kNoHit;
     float out_depth = 10000.0f;
     V3 out_normal = mk(0.5f, 0.5f, 0.5f);
@@ -938,6 +960,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     S.metallic = 0.f; S.alpha = 0.f; S.nc_NdotV = 0.f; S.NdotV = 0.f;
     if (hit) shade_surface(a, bpos, bu, bv, S, out_depth, out_normal);
     if (in) {
+        const size_t pix = (size_t)y * a.W + x;
         st_nt(&a.depth[pix], out_depth);
         st_nt(&a.normal[pix], make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f));
     }
@@ -956,8 +979,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
         bool want = false;
         if (!ONE_LIGHT) {
-            asm volatile("" ::: "memory"); // reload, do not carry the record across the walk
-            const float *q = &surf[threadIdx.x];
+            const float *q = &surf[launder_v((uint32_t)threadIdx.x)]; // reload, do not carry the record across the walk
             S.world_pos = mk(q[0 * kBlock], q[1 * kBlock], q[2 * kBlock]); S.N = mk(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
             S.Vv = mk(q[6 * kBlock], q[7 * kBlock], q[8 * kBlock]); S.albedo = mk(q[9 * kBlock], q[10 * kBlock], q[11 * kBlock]);
             S.metallic = q[12 * kBlock]; S.alpha = q[13 * kBlock]; S.nc_NdotV = dot3(S.N, S.Vv); S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
@@ -969,7 +991,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
         bool son = want;
         float st = son ? sr.tmax : -1.0f, su = 0.f, sv = 0.f;
         uint32_t spos = kNoHit, sgid = kNoHit;
-        walk_dispatch<true, WIDE>(a, sr, son, stk, st, su, sv, spos, sgid);
+        walk_dispatch<true, WIDE, COUNT>(a, sr, son, stk, st, su, sv, spos, sgid, steps);
         if (want && spos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
             c4 = make_float4(c4.x * 0.05f, c4.y * 0.05f, c4.z * 0.05f, c4.w);
             sbits |= 1u << i;
@@ -978,15 +1000,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     }
     if (!in) { rx = 0.f; ry = 0.f; rz = 0.f; }
     float4 o = make_float4(rx, ry, rz, 1.0f);
-    if (in) st_nt(&a.color[pix], o);
-    if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
+    frame_pixel(a, wid, p, x, y, mine);
+    if (in) st_nt(&a.color[(size_t)y * a.W + x], o);
+    if (a.color_tiles && mine) { // compact tile buffer for the gather: row-major inside each 32x32 tile
         uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
         uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
         size_t ti = (size_t)(p >> 10) * kTilePixels + ly * kTile + lx;
         if (a.tiles_packed) __builtin_nontemporal_store(pack_b10g11r11(o.x, o.y, o.z), reinterpret_cast<uint32_t *>(a.color_tiles) + ti);
         else st_nt(&a.color_tiles[ti], o);
     }
-    a.pix_bits[p] = sbits;
+    if (mine) a.pix_bits[p] = sbits;
+    if (COUNT && __lane_id() == 0) a.wave_cost[wid] = steps; // feedback for the next plan (art_api.hip plan_poll)
 }
 
 // art_get_stats for fused frames: shadow rays = set bits 16..31 of pix_bits, hit pixels = depth < miss depth; on demand only
@@ -1079,15 +1103,21 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
-void launch_frame(const FrameArgs &a, hipStream_t s) {
+bool launch_frame(const FrameArgs &a, hipStream_t s) { // returns whether the launch wrote a.wave_cost
     const int waves = a.frame_waves; // both instances fit 63 registers without spills (the multi-light one parks its surface record in LDS during the shadow walks)
-    const uint32_t g = blocks_for(a.n_local);
+    const uint32_t g = (a.n_wave_items + kBlock / 64 - 1) / (kBlock / 64);
+    if (g == 0) return false;
     const bool one = a.n_lights == 1;
-    if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); return; }
+    if (a.wave_cost && !a.packet_wide && waves >= 8 && a.n_lights > 0) { // a sampled frame of the wave plan: the step-counting instances
+        if (a.n_lights == 1) k_frame<false, 8, true, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 8, false, true><<<g, kBlock, 0, s>>>(a);
+        return true;
+    }
+    if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); return false; }
     if (a.packet_wide) { if (one) k_frame<true, 5, true><<<g, kBlock, 0, s>>>(a); else k_frame<true, 5, false><<<g, kBlock, 0, s>>>(a); }
     else if (waves >= 8) { if (one) k_frame<false, 8, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); }
     else if (waves == 7) { if (one) k_frame<false, 7, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 7, false><<<g, kBlock, 0, s>>>(a); }
     else { if (one) k_frame<false, 6, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 6, false><<<g, kBlock, 0, s>>>(a); }
+    return false;
 }
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s) { k_frame_stats<<<blocks_for(a.n_local), kBlock, 0, s>>>(a, out); }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }

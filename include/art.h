@@ -80,6 +80,9 @@ typedef struct ArtConfig {
                                    image format (renderer.rs:268) -- 4 B per pixel instead of RGBA32F; art_untile_gathered then assembles the packed colour image */
 #define ART_FLAG_DEVICE_TREE 8u /* build the PREFER_FAST_TRACE tree on the device (parallel locally-ordered clustering over the Morton-ordered leaves)
                                   instead of the binned SAH on the host threads: 4x faster build, ~4 % fewer rays/s (profiles/README.md) */
+#define ART_FLAG_FIXED_WAVES 16u /* every 8x8 pixel block of a frame is traced by one wave, always.  Default: adaptive -- now and then a frame counts the packet
+                                  * steps of each of its waves, and blocks whose wave outlasts the launch's fair share of the GPU (a packet crossing dense distant
+                                  * geometry) are dealt to 4 or 16 waves in the following frames.  The image does not depend on it. */
 #define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits) */
 
 typedef struct ArtStats {
@@ -95,7 +98,7 @@ typedef struct ArtStats {
     float frame_ms;             /* last art_trace, device time (events on the context's stream) */
     float trace_primary_ms, shade_ms, trace_shadow_ms, accumulate_ms;
     float ao_ms;                /* last art_trace_ao (ray generation + any-hit + resolve) */
-    uint32_t reserved2;
+    uint32_t split_blocks;      /* fused frame: 8x8 pixel blocks the current wave plan deals to 4 or 16 waves instead of one (see ART_FLAG_FIXED_WAVES) */
 } ArtStats;
 
 typedef struct ArtContext ArtContext;

@@ -363,6 +363,39 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
     assert frame(4, env={"ART_FUSED": "0"})[3]["frame_launches"] == 4
 
 
+def test_wave_plan_changes_the_waves_never_the_image(R, get_scene, monkeypatch):
+    """the fused frame's adaptive wave plan (ART_FLAG_FIXED_WAVES off): after a sampled frame heavy 8x8 blocks are dealt to 4 / 16 waves --
+    the same frame bit for bit before and after, unsharded, sharded, with one light and four, and equal to the fixed-wave frame"""
+    from araytracingjourney_amd import scenes
+    sc = get_scene("sponza_like", 0.12)
+    w, h = 640, 360
+    monkeypatch.setenv("ART_SPLIT_FIXED", "40")          # a low step target, so that plenty of blocks split in this small scene
+    for n_lights, shard in ((1, (0, 1)), (4, (0, 1)), (4, (1, 3))):
+        fixed = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=1, fixed_waves=True, shard=shard)
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=2, shard=shard)
+        for x in (fixed, r):
+            for d in scenes.sponza_lights(n_lights):
+                x.lights_mut().push_dict(d)
+        fixed.render_frame()
+        ref = (fixed.read_color(), fixed.read_depth(), fixed.read_normal(), fixed.stats())
+        assert ref[3]["split_blocks"] == 0
+        seen = set()
+        for i in range(12):                              # the first frame is sampled; a later one runs on the new plan, and is sampled in turn
+            r.render_frame()
+            r.sync()
+            st = r.stats()
+            seen.add(st["split_blocks"])
+            got = (r.read_color(), r.read_depth(), r.read_normal())
+            for k in range(3):
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (n_lights, shard, i, k)
+            assert st["shadow_rays"] == ref[3]["shadow_rays"] and st["hit_pixels"] == ref[3]["hit_pixels"]
+            if shard[1] > 1:
+                assert np.array_equal(r.read_color_tiles().view(np.uint32), fixed.read_color_tiles().view(np.uint32))
+        assert 0 in seen and max(seen) > 20, seen        # it started unsplit and did split
+        fixed.close()
+        r.close()
+
+
 def test_residency_only_device_models_are_traced(R, get_scene):
     """renderer.rs:637-651 + vk_model.rs:334-345: a model farther than 10 units from the camera leaves the acceleration structure
     (the frame equals the one without it), comes back when the camera approaches; with nothing in range every ray misses"""
