@@ -625,6 +625,7 @@ int32_t art_scene_build(ArtContext *c) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     c->stats.build_ms = ms; c->stats.num_triangles = T; c->stats.num_primitives = (uint32_t)dp.size(); c->stats.num_nodes = c->kind_primary == 4 ? c->bvh.n_wide : (T > 1 ? T - 1 : 1);
     c->built = true;
+    c->plan.next_sample = c->frame_no; c->plan.interval = 1; // a new scene: the heavy blocks are elsewhere
     return ART_OK;
 }
 
@@ -670,6 +671,7 @@ int32_t art_set_lights(ArtContext *c, const ArtLight *lights, uint32_t n) {
     bool same = !resized && (n == 0 || std::memcmp(c->lights.data(), lights, (size_t)n * sizeof(ArtLight)) == 0);
     if (same) return ART_OK; // like VkLights' dirty flag (vk_lights.rs:81-139)
     c->lights.assign(lights, lights + n);
+    c->plan.next_sample = c->frame_no; c->plan.interval = 1; // the shadow walks change: look at the waves again
     if (resized) { r = sync_all(c); if (r) return r; } // the per-frame buffers are resized with the light count
     drop_graphs(c);
     c->lights_cur ^= 1; // frames in flight keep reading the previous buffer
