@@ -99,9 +99,11 @@ SYMBOLS = {
     "art_device_color_tiles": (_I32, [_P, _P, _P]),
     "art_bind_color_tiles": (_I32, [_P, _U32, _P, _SZ]),
     "art_bind_color_tiles_pair": (_I32, [_P, _U32, _P, _P, _SZ]),
+    "art_bind_color_tiles_ring": (_I32, [_P, _U32, _P, _U32, _SZ]),
     "art_set_graph_mode": (_I32, [_P, _I32]),
     "art_frames_in_flight": (_I32, [_P, _P, _P]),
     "art_stream_wait_frame": (_I32, [_P, _P]),
+    "art_frames_done": (_I32, [_P, C.c_uint64, _U32, _P, _P]),
     "art_wait_external_event": (_I32, [_P, _P]),
     "art_trace_for_stream": (_I32, [_P, _P, _P]),
     "art_collect_timings": (_I32, [_P, _P, _P]),

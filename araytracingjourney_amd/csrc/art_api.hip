@@ -54,9 +54,10 @@ struct FrameSlot {
     DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     hipEvent_t done_alias = nullptr;   // the latest frame's completion is this ring event (fused frames: one record less per frame) instead of `done`
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
-    float4 *ext_tiles_alt = nullptr;   // second caller-owned buffer: the slot's frames alternate between the two (art_bind_color_tiles_pair)
+    static constexpr uint32_t kTileRing = 8;
+    float4 *ext_ring[kTileRing] = {}; uint32_t ext_ring_n = 0; // caller-owned buffers the slot's frames write in turn, one per trip round the frame ring (art_bind_color_tiles_ring)
     float4 *tiles_of_last = nullptr;   // where the slot's most recent frame wrote its tiles
-    float4 *tiles_for(uint64_t frame_no, uint32_t F) { float4 *t = ext_tiles ? ((ext_tiles_alt && ((frame_no / F) & 1u)) ? ext_tiles_alt : ext_tiles) : d_color_tiles.p; tiles_of_last = t; return t; }
+    float4 *tiles_for(uint64_t frame_no, uint32_t F) { float4 *t = ext_tiles ? (ext_ring_n > 1 ? ext_ring[(frame_no / F) % ext_ring_n] : ext_tiles) : d_color_tiles.p; tiles_of_last = t; return t; }
     float4 *last_tiles() const { return tiles_of_last ? tiles_of_last : (ext_tiles ? ext_tiles : d_color_tiles.p); }
     hipEvent_t done = nullptr;       // recorded after the slot's last frame
     hipGraphExec_t graph = nullptr;  // the frame's launch sequence captured once (graph mode); dropped whenever an input changes
@@ -380,7 +381,7 @@ int32_t setup_frame(ArtContext *c) {
         HIPC(hipMemset(S.d_color.p, 0, npix * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * 4));
         if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes())); }
         if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local)); // fused frames always write their per-pixel shadow bits (stats)
-        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) { S.ext_tiles = nullptr; S.ext_tiles_alt = nullptr; S.tiles_of_last = nullptr; S.ext_tiles_bytes = 0; }
+        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) { S.ext_tiles = nullptr; S.ext_ring_n = 0; S.tiles_of_last = nullptr; S.ext_tiles_bytes = 0; }
     }
     HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
     drop_graphs(c);
@@ -755,7 +756,7 @@ int32_t art_trace(ArtContext *c) {
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     c->ev_fused[c->frame_no % ArtContext::kRing] = fused;
-    if (c->graph_mode && !fused && !S.ext_tiles_alt) { // a fused frame is a single launch: nothing for a graph to save; alternating tile buffers change a kernel argument
+    if (c->graph_mode && !fused && S.ext_ring_n < 2) { // a fused frame is a single launch: nothing for a graph to save; alternating tile buffers change a kernel argument
         if (!S.graph) { // capture the frame once per slot; stage events are not part of it
             hipGraph_t g = nullptr;
             HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -958,14 +959,21 @@ int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t byt
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_bind_color_tiles"); if (r) return r;
     if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
     HIPC(hipStreamSynchronize(c->stream_of(slot)));
-    c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_tiles_alt = nullptr; c->slot[slot].tiles_of_last = nullptr; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
+    c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_ring_n = 0; c->slot[slot].tiles_of_last = nullptr; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
     drop_graphs(c);
     return ART_OK;
 }
 int32_t art_bind_color_tiles_pair(ArtContext *c, uint32_t slot, void *dev_even, void *dev_odd, size_t bytes) {
     if (!dev_even || !dev_odd) return fail(ART_E_INVALID, "art_bind_color_tiles_pair: null buffer");
-    int32_t r = art_bind_color_tiles(c, slot, dev_even, bytes); if (r) return r;
-    c->slot[slot].ext_tiles_alt = (float4 *)dev_odd;
+    void *two[2] = {dev_even, dev_odd};
+    return art_bind_color_tiles_ring(c, slot, two, 2, bytes);
+}
+int32_t art_bind_color_tiles_ring(ArtContext *c, uint32_t slot, void *const *bufs, uint32_t n, size_t bytes) {
+    if (!bufs || n == 0 || n > FrameSlot::kTileRing) return fail(ART_E_INVALID, "art_bind_color_tiles_ring: 1..8 buffers");
+    for (uint32_t i = 0; i < n; i++) if (!bufs[i]) return fail(ART_E_INVALID, "art_bind_color_tiles_ring: null buffer");
+    int32_t r = art_bind_color_tiles(c, slot, bufs[0], bytes); if (r) return r;
+    for (uint32_t i = 0; i < n; i++) c->slot[slot].ext_ring[i] = (float4 *)bufs[i];
+    c->slot[slot].ext_ring_n = n;
     return ART_OK;
 }
 int32_t art_set_graph_mode(ArtContext *c, int32_t on) {
@@ -979,6 +987,22 @@ int32_t art_frames_in_flight(ArtContext *c, uint32_t *frames, uint32_t *next_slo
     if (!c) return fail(ART_E_INVALID, "art_frames_in_flight: null context");
     if (frames) *frames = c->F;
     if (next_slot) *next_slot = (uint32_t)(c->frame_no % c->F);
+    return ART_OK;
+}
+int32_t art_frames_done(ArtContext *c, uint64_t first, uint32_t count, int32_t *done, uint64_t *traced) {
+    if (!c || !done) return fail(ART_E_INVALID, "art_frames_done: null argument");
+    if (traced) *traced = c->frame_no;
+    *done = 0;
+    if (count == 0) { *done = 1; return ART_OK; }
+    if (first + count > c->frame_no) return fail(ART_E_INVALID, "art_frames_done: frames not traced yet");
+    if (c->frame_no - first > (uint64_t)ArtContext::kRing) return fail(ART_E_INVALID, "art_frames_done: older than the 128 frames whose events are kept");
+    int32_t r = use_device(c); if (r) return r;
+    for (uint64_t f = first + count; f-- > first;) { // the newest first: it is the likeliest to be still running
+        hipError_t e = hipEventQuery(c->ev[f % ArtContext::kRing][4]);
+        if (e == hipErrorNotReady) return ART_OK;
+        if (e != hipSuccess) return hipfail(e, "art_frames_done: hipEventQuery");
+    }
+    *done = 1;
     return ART_OK;
 }
 int32_t art_stream_wait_frame(ArtContext *c, void *hip_stream) {

@@ -392,8 +392,24 @@ class Renderer:
         """two tile buffers per ring slot, written alternately: the next frame of a slot does not wait for the exchange of the previous one"""
         check(self._L.art_bind_color_tiles_pair(self._ctx, slot, C.c_void_p(dev_even), C.c_void_p(dev_odd), nbytes))
 
+    def bind_color_tiles_ring(self, slot, dev_ptrs, nbytes):
+        """len(dev_ptrs) tile buffers per ring slot, written in turn (one per trip round the frame ring)"""
+        arr = (C.c_void_p * len(dev_ptrs))(*dev_ptrs)
+        check(self._L.art_bind_color_tiles_ring(self._ctx, slot, arr, len(dev_ptrs), nbytes))
+
     def set_graph_mode(self, on):
         check(self._L.art_set_graph_mode(self._ctx, int(bool(on))))
+
+    def frames_done(self, first, count):
+        """host-side, non-blocking: have frames [first, first + count) (art_trace order, from 0) all finished?"""
+        d = C.c_int32()
+        check(self._L.art_frames_done(self._ctx, first, count, C.byref(d), None))
+        return bool(d.value)
+
+    def frames_traced(self):
+        d, n = C.c_int32(), C.c_uint64()
+        check(self._L.art_frames_done(self._ctx, 0, 0, C.byref(d), C.byref(n)))
+        return n.value
 
     def frames_in_flight(self):
         f, nxt = C.c_uint32(), C.c_uint32()

@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-frames", type=int, default=10, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
+    ap.add_argument("--gather-frames", type=int, default=20, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
     ap.add_argument("--compositor", default="auto", choices=["auto", "dedicated", "shared"],
                     help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
                          "1/(N-1) each (the exchange no longer waits behind rank 0's own frames); auto = dedicated from 4 GPUs on")
@@ -102,25 +102,27 @@ def main():
 
     tiles = gathered = frame = None
     GB = 1
-    consumed = [[None] * F, [None] * F]   # per tile buffer (two per ring slot): event "the exchange that read these tiles has finished"
+    NBUF = 4                          # tile buffers per ring slot, written in turn: a frame waits for the exchange of NBUF trips ago
+    QUEUED = "queued"                 # ... or for that exchange to be submitted at all, if its frames are still running
+    consumed = [[None] * F for _ in range(NBUF)]   # per tile buffer: event "the exchange that read these tiles has finished"
     if world > 1:
         owned, padded = r.shard_tile_count()
         GB = max(1, min(args.gather_frames, F))
         while F % GB:                 # whole gather groups per trip round the ring
             GB -= 1
         tshape, tdtype = ((padded, 32, 32), torch.int32) if packed else ((padded, 32, 32, 4), torch.float32)
-        # slot k renders into tiles[trip parity][k]: GB slots are one contiguous message, and a slot's next frame never waits for the
-        # exchange that still reads its previous tiles
-        tiles = torch.zeros((2, F) + tshape, dtype=tdtype, device="cuda")
+        # slot k renders into tiles[trip % NBUF][k]: GB slots are one contiguous message, and a slot's next frames never wait for the
+        # exchanges that still read its previous tiles
+        tiles = torch.zeros((NBUF, F) + tshape, dtype=tdtype, device="cuda")
         for k in range(F):
-            r.bind_color_tiles_pair(k, tiles[0, k].data_ptr(), tiles[1, k].data_ptr(), tiles[0, k].numel() * 4)
+            r.bind_color_tiles_ring(k, [tiles[b, k].data_ptr() for b in range(NBUF)], tiles[0, k].numel() * 4)
         if rank == 0:
             gathered = torch.empty((world, F) + tshape, dtype=tdtype, device="cuda")   # [peer][slot]: a frame's shards are F * padded tiles apart
             frame = torch.zeros((GB,) + ((H, W) if packed else (H, W, 4)), dtype=tdtype, device="cuda")   # the frames of one exchange, un-tiled by one launch
         torch.cuda.synchronize()
 
-    traced = [0]                      # frames submitted so far (trip parity = (traced // F) & 1)
-    stream_ptr = stream.cuda_stream
+    traced = [0]                      # frames submitted so far (tile buffer = (traced // F) % NBUF)
+    fifo = []                         # gather groups whose frames are still running: (first slot, frames, tile buffer, first frame index)
 
     def step():
         if world == 1:
@@ -128,34 +130,52 @@ def main():
             if args.ao:
                 r.trace_ao(args.ao)
             return
-        k = traced[0] % F                                   # the ring slot this frame takes
-        ev = consumed[(traced[0] // F) & 1][k]
+        k, par = traced[0] % F, (traced[0] // F) % NBUF      # the ring slot and the tile buffer this frame takes
+        while consumed[par][k] is QUEUED:                   # its previous contents have not even been sent: NBUF trips behind, rare
+            poll()
+        ev = consumed[par][k]
         if ev is not None and not ev.query():
             # Gate on the HOST: a cross-stream wait queued in front of every frame costs the frame kernels their L2 contents (an acquire
-            # per launch; measured 115 instead of 55 us per frame on a 1/8 share).  The event is two trips old: it has almost always fired.
+            # per launch; measured 115 instead of 55 us per frame on a 1/8 share).  The event is NBUF trips old: it has almost always fired.
             ev.synchronize()
-        if not renders:
-            pass                                            # the compositor only takes part in the exchange
-        elif args.ao:
+        if renders:                                         # (a dedicated compositor only takes part in the exchange)
             r.trace()
-            r.trace_ao(args.ao)                             # per tile from the local G-buffer: no extra exchange
-            r.stream_wait_frame(stream_ptr)
-        else:
-            r.trace_for_stream(stream_ptr)                  # trace + "torch's stream (hence RCCL) waits for this frame", one call
+            if args.ao:
+                r.trace_ao(args.ao)                         # per tile from the local G-buffer: no extra exchange
         traced[0] += 1
         pending[1] += 1
-        if pending[1] == GB or k + 1 == F:                  # the exchange runs once per GB frames (never across the ring's wrap: one contiguous slice)
+        if pending[1] == GB or k + 1 == F:                  # one exchange per GB frames (never across the ring's wrap: one contiguous slice)
             exchange()
+        elif fifo and traced[0] % 4 == 0:
+            poll()
 
     pending = [0, 0]                  # first slot and number of frames traced but not yet gathered
     newest = [0]                      # where in `frame` the most recent frame sits
 
-    def exchange():
+    def exchange(force=False):
+        # The group is queued and SUBMITTED by poll() once the host sees its frames done (art_frames_done), so the exchange stream carries no
+        # device-side wait: on a GPU that keeps tracing, each hipStreamWaitEvent packet took ~40 us to retire, which held a 1/7 share at
+        # 47 us per frame where 39 are possible (profiles/README.md r1n).  Every rank submits its groups in the same order.
         k0, n = pending
-        if n == 0:
-            return
-        pending[0], pending[1] = (k0 + n) % F, 0
-        par = ((traced[0] - 1) // F) & 1                     # the buffers these frames wrote
+        if n:
+            pending[0], pending[1] = (k0 + n) % F, 0
+            par = ((traced[0] - 1) // F) % NBUF              # the buffers these frames wrote
+            fifo.append((k0, n, par, r.frames_traced() - n if renders else 0))
+            for j in range(k0, k0 + n):
+                consumed[par][j] = QUEUED
+        poll(force)
+
+    def poll(force=False):
+        while fifo:
+            k0, n, par, first = fifo[0]
+            if renders and not r.frames_done(first, n):
+                if not force:
+                    return
+                r.sync()
+            fifo.pop(0)
+            run_exchange(k0, n, par)
+
+    def run_exchange(k0, n, par):
         src = tiles[par, k0:k0 + n]
         if args.backend == "nccl":
             dist.gather(src, [gathered[w, k0:k0 + n] for w in range(world)] if rank == 0 else None, dst=0)
@@ -177,7 +197,7 @@ def main():
 
     def fence():
         if world > 1:
-            exchange()                # frames still waiting for their group: the timed region ends with every frame on the root
+            exchange(force=True)      # frames still waiting for their group: the timed region ends with every frame on the root
         r.sync()
         torch.cuda.synchronize()
         if world > 1:

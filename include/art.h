@@ -118,6 +118,11 @@ int32_t art_set_stream(ArtContext *ctx, void *hip_stream);
 int32_t art_set_graph_mode(ArtContext *ctx, int32_t on);
 /* frame ring: number of slots and the slot the NEXT art_trace will use */
 int32_t art_frames_in_flight(ArtContext *ctx, uint32_t *frames, uint32_t *next_slot);
+/* host-side, non-blocking: have frames [first, first + count) of this context (counted from 0 in art_trace order, at most 128 back) all
+ * finished?  *traced (optional) receives the number of frames traced so far.  An exchange that is SUBMITTED only once its frames are done
+ * needs no device-side wait per frame: on a GPU that keeps tracing, every hipStreamWaitEvent packet in the exchange stream took ~40 us to
+ * retire, which capped a 1/7 share at 46 us per frame (profiles/README.md r1n). */
+int32_t art_frames_done(ArtContext *ctx, uint64_t first, uint32_t count, int32_t *done, uint64_t *traced);
 /* make an external stream wait (on the device) for the most recently traced frame */
 int32_t art_stream_wait_frame(ArtContext *ctx, void *hip_stream);
 /* make the NEXT art_trace wait (on the device) for an external hipEvent_t, e.g. "the gather that read this slot's tiles
@@ -208,6 +213,10 @@ int32_t art_bind_color_tiles(ArtContext *ctx, uint32_t slot, void *dev_ptr, size
  * exchange that is still reading the slot's previous tiles -- only for the one of two trips ago.  art_device_color_tiles and
  * art_read_color_tiles refer to the buffer the latest frame wrote. */
 int32_t art_bind_color_tiles_pair(ArtContext *ctx, uint32_t slot, void *dev_even, void *dev_odd, size_t bytes);
+/* n (1..8) buffers per slot, written in turn: trip t round the frame ring writes bufs[t % n], so a frame waits only for the exchange of n
+ * trips ago.  With two, the host was found waiting at every trip boundary (the whole trip before last must have been exchanged);
+ * four leave the slack a jittery exchange needs (profiles/README.md r1n). */
+int32_t art_bind_color_tiles_ring(ArtContext *ctx, uint32_t slot, void *const *bufs, uint32_t n, size_t bytes);
 int32_t art_read_color_tiles(ArtContext *ctx, void *dst, size_t bytes); /* host copy of the same buffer (tests) */
 /* frame_dev NULL = the context's colour buffer; hip_stream NULL = the latest frame's stream */
 int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream);

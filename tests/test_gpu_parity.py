@@ -209,6 +209,45 @@ def test_tile_buffer_pairs_alternate_per_trip(R, get_scene):
         r.close()
 
 
+def test_tile_buffer_ring_and_host_side_frame_completion(R, get_scene):
+    """art_bind_color_tiles_ring: a slot's frames write its n caller-owned buffers in turn, one per trip round the frame ring;
+    art_frames_done: non-blocking host-side "have frames [first, first + count) finished", which lets an exchange be submitted without
+    device-side waits; argument errors of both"""
+    import torch
+    from araytracingjourney_amd import sharding
+    from araytracingjourney_amd._lib import ArtError
+    sc = get_scene("cornell")
+    w, h, G, F, NB = 160, 96, 2, 2, 3
+    whole = R.renderer_for_scene(sc, (w, h))
+    s = R.renderer_for_scene(sc, (w, h), shard=(1, G), frames_in_flight=F)
+    owned, padded = s.shard_tile_count()
+    b = torch.zeros((NB, F, padded, 32, 32, 4), dtype=torch.float32, device="cuda")
+    for k in range(F):
+        s.bind_color_tiles_ring(k, [b[i, k].data_ptr() for i in range(NB)], b[0, k].numel() * 4)
+    assert s.frames_traced() == 0 and s.frames_done(0, 0)
+    with pytest.raises(ArtError):
+        s.frames_done(0, 1)                                   # not traced yet
+    want = []
+    for i in range(NB * F + 1):                               # frame i lands in buffer [i // F % NB][i % F]; the last one wraps round
+        pos = (0.02 * i, 0.01 * i, -0.95)
+        for r in (whole, s):
+            r.camera_mut().set_pos(pos)
+            r.upload_state()
+            r.trace()
+        want.append(sharding.tile_host(whole.read_color(), G, 1))
+    assert s.frames_traced() == NB * F + 1
+    s.sync()
+    assert s.frames_done(0, NB * F + 1) and s.frames_done(NB * F, 1)
+    for i in range(1, NB * F + 1):                            # frame 0's buffer was rewritten by the last frame
+        assert np.array_equal(b[i // F % NB, i % F, :owned].cpu().numpy().view(np.uint32), want[i][:owned].view(np.uint32)), i
+    with pytest.raises(ArtError):
+        s.bind_color_tiles_ring(0, [b[0, 0].data_ptr()] * 9, b[0, 0].numel() * 4)   # at most 8 buffers
+    with pytest.raises(ArtError):
+        s.bind_color_tiles_ring(0, [b[0, 0].data_ptr(), 0], b[0, 0].numel() * 4)     # null buffer
+    for r in (whole, s):
+        r.close()
+
+
 def test_packed_tiles_gather_to_the_packed_colour_image(R, get_scene):
     """ART_FLAG_PACKED_TILES: the gather payload is B10G11R11 (the reference's colour image format, renderer.rs:268), 4 B per pixel;
     un-tiled on shard 0 it equals the packed colour of the unsharded frame; fused and staged frames"""
