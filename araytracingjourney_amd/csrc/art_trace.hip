@@ -1061,15 +1061,22 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
 // frame.  A thread moves V consecutive pixels of one tile row (16 bytes when the width allows): no divisions, one table lookup.
 template <class T, int V> __global__ __launch_bounds__(kBlock) void k_untile(const T *__restrict__ gathered, const uint32_t *__restrict__ tile_slot, uint32_t shard_stride, uint32_t frame_stride,
                                                                              uint32_t W, uint32_t H, T *__restrict__ frame) {
+    // A block moves a band of 32 x V pixels by 32 rows = one row of tiles: a thread takes V pixels of four rows of ONE tile (one table
+    // lookup, four independent loads, then four stores).  A quarter of the waves of a row per thread: on a root that keeps tracing,
+    // the un-tile of 20 frames was 162 000 one-kilobyte waves competing with the frames' 82 000 for slots.
     const uint32_t tiles_x = (W + kTile - 1) / kTile;
-    const uint32_t x = (blockIdx.x * 32u + (threadIdx.x & 31u)) * V, y = blockIdx.y * 8u + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    const uint32_t ts = tile_slot[(y / kTile) * tiles_x + x / kTile]; // owner << 24 | index among the owner's tiles (host table, setup_frame)
+    const uint32_t x = (blockIdx.x * 32u + (threadIdx.x & 31u)) * V, y0 = blockIdx.y * kTile + (threadIdx.x >> 5);
+    if (x >= W || y0 >= H) return;
+    const uint32_t ts = tile_slot[blockIdx.y * tiles_x + x / kTile]; // owner << 24 | index among the owner's tiles (host table, setup_frame)
     const size_t tile = (size_t)(ts >> 24) * shard_stride + (size_t)blockIdx.z * frame_stride + (ts & 0xFFFFFFu); // shard_stride: tiles between two shards' buffers
-    const T *src = gathered + tile * kTilePixels + (y % kTile) * kTile + (x % kTile);
-    T *dst = frame + (size_t)blockIdx.z * W * H + (size_t)y * W + x;
+    const T *src = gathered + tile * kTilePixels + (threadIdx.x >> 5) * kTile + (x % kTile);
+    T *dst = frame + (size_t)blockIdx.z * W * H + (size_t)y0 * W + x;
     struct alignas(sizeof(T) * V) Pack { T v[V]; };
-    *reinterpret_cast<Pack *>(dst) = *reinterpret_cast<const Pack *>(src);
+    Pack p[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[i] = *reinterpret_cast<const Pack *>(src + (size_t)i * 8u * kTile); // rows y0, y0 + 8, + 16, + 24 of the tile (padding rows of a bottom tile are readable)
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (y0 + 8u * i < H) *reinterpret_cast<Pack *>(dst + (size_t)i * 8u * W) = p[i];
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1165,15 +1172,15 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, in
     k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
 void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
-    dim3 g((W + 31) / 32, (H + 7) / 8, n_frames);
+    dim3 g((W + 31) / 32, (H + kTile - 1) / kTile, n_frames);
     k_untile<float4, 1><<<g, kBlock, 0, s>>>(gathered, tile_slot, shard_stride, frame_stride, W, H, frame);
 }
 void launch_untile_packed(const uint32_t *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, uint32_t *frame, hipStream_t s) {
     if (W % 4 == 0 && ((uintptr_t)frame & 15u) == 0 && ((uintptr_t)gathered & 15u) == 0) { // four pixels (16 bytes) per thread
-        dim3 g((W / 4 + 31) / 32, (H + 7) / 8, n_frames);
+        dim3 g((W / 4 + 31) / 32, (H + kTile - 1) / kTile, n_frames);
         k_untile<uint32_t, 4><<<g, kBlock, 0, s>>>(gathered, tile_slot, shard_stride, frame_stride, W, H, frame);
     } else {
-        dim3 g((W + 31) / 32, (H + 7) / 8, n_frames);
+        dim3 g((W + 31) / 32, (H + kTile - 1) / kTile, n_frames);
         k_untile<uint32_t, 1><<<g, kBlock, 0, s>>>(gathered, tile_slot, shard_stride, frame_stride, W, H, frame);
     }
 }

@@ -55,7 +55,8 @@ def main():
     ap.add_argument("--gather-frames", type=int, default=20, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
     ap.add_argument("--compositor", default="auto", choices=["auto", "dedicated", "shared"],
                     help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
-                         "1/(N-1) each (the exchange no longer waits behind rank 0's own frames); auto = dedicated from 4 GPUs on")
+                         "1/(N-1) each; auto = shared: with the exchange submitted by the host (no device-side waits) a root that also traces a 1/8 share "
+                         "spends 35.5 us per frame, exchange and un-tile included, where the tracers of a 7 + 1 layout need 39.1 (profiles/README.md r1n)")
     ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
     F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (20 if world > 1 else 16)
     packed = world > 1 and args.gather == "packed"
-    dedicated = world > 1 and (args.compositor == "dedicated" or (args.compositor == "auto" and world >= 4))
+    dedicated = world > 1 and args.compositor == "dedicated"
     G = world - 1 if dedicated else world           # shards of the frame = ranks that trace
     renders = not (dedicated and rank == 0)
     shard = ((rank - 1) if dedicated else rank, G) if renders else (0, G)   # the compositor keeps a context for the layout tables and the un-tile

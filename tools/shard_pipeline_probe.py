@@ -48,7 +48,9 @@ def exchange(force=False, form=True):
         run_exchange(k0, n, par)
 def run_exchange(k0, n, par):
     xs = streams[group_no[0] % XS]; group_no[0] += 1
-    if MODE == "noexchange": return
+    if MODE == "noexchange":
+        for j in range(k0, k0 + n): consumed[par][j] = None
+        return
     e0 = torch.cuda.Event(enable_timing=True); e0.record(xs)
     with torch.cuda.stream(xs):
         if MODE != "nocopy": gathered[0, k0:k0 + n].copy_(tiles[par, k0:k0 + n])
