@@ -94,6 +94,7 @@ SYMBOLS = {
     "art_device_color": (_I32, [_P, _P, _P]),
     "art_device_depth": (_I32, [_P, _P, _P]),
     "art_device_normal": (_I32, [_P, _P, _P]),
+    "art_set_root_relief": (_I32, [_U32]),
     "art_shard_layout": (_I32, [_U32, _U32, _U32, _U32, _P, _U32, _P, _P]),
     "art_shard_tile_count": (_I32, [_P, _P, _P]),
     "art_device_color_tiles": (_I32, [_P, _P, _P]),

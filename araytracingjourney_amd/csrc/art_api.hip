@@ -918,6 +918,12 @@ int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_p
 int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
 int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->slot[c->last].d_normal.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 
+static const int g_relief_env_applied = [] { if (const char *e = std::getenv("ART_ROOT_RELIEF")) { int v = std::atoi(e); if (v >= 0 && v <= 255) shard_root_relief() = (uint32_t)v; } return 0; }();
+int32_t art_set_root_relief(uint32_t per_256) {
+    if (per_256 > 255) return fail(ART_E_INVALID, "art_set_root_relief: 0..255");
+    shard_root_relief() = per_256;
+    return ART_OK;
+}
 int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t *tiles, uint32_t cap, uint32_t *owned, uint32_t *padded) {
     if (width == 0 || height == 0) return fail(ART_E_INVALID, "art_shard_layout: zero extent");
     uint32_t count = shard_count > 1 ? shard_count : 1;

@@ -186,9 +186,14 @@ void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t s
 // every group hands its tiles to the shards in a fresh pseudo-random order: each shard holds one tile of every neighbourhood (its work
 // follows the frame's cost everywhere) and no lattice can beat against the scene's regularities -- the diagonal interleave
 // (tx + 5 ty) mod count left the slowest of 8 shards 18 % above the mean on config 2 (profiles/README.md r1k).  Shares differ by <= 1 tile.
+// Root relief (art_set_root_relief): shard 0 composites besides tracing, so in `relief / 256` of the groups its tile goes to one of the other
+// shards instead (each of them in turn).  Process-wide: every rank of a job must use the same value before it creates its contexts.
+inline uint32_t &shard_root_relief() { static uint32_t per_256 = 0; return per_256; }
 inline std::vector<uint8_t> shard_owner_table(uint32_t tiles_x, uint32_t tiles_y, uint32_t count) {
     std::vector<uint8_t> owner((size_t)tiles_x * tiles_y, 0);
     if (count <= 1) return owner;
+    const uint32_t relief = shard_root_relief();
+    uint32_t relieved = 0;
     auto spread = [](uint32_t v) { v &= 0xFFFFu; v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
     std::vector<std::pair<uint32_t, uint32_t>> order; // (Morton key, tile)
     order.reserve(owner.size());
@@ -199,7 +204,12 @@ inline std::vector<uint8_t> shard_owner_table(uint32_t tiles_x, uint32_t tiles_y
         uint32_t state = (uint32_t)g * 2654435761u + 0x9E3779B9u; // one small generator per group: the table is the same on every rank
         for (uint32_t i = 0; i < count; i++) perm[i] = i;
         for (uint32_t i = count - 1; i > 0; i--) { state = state * 1664525u + 1013904223u; uint32_t j = (state >> 8) % (i + 1); std::swap(perm[i], perm[j]); }
-        for (uint32_t i = 0; i < count && g * count + i < order.size(); i++) owner[order[g * count + i].second] = (uint8_t)perm[i];
+        const bool relieve = relief && ((((uint32_t)g * 2246822519u) >> 24) < relief); // a fixed pseudo-random subset of the groups
+        for (uint32_t i = 0; i < count && g * count + i < order.size(); i++) {
+            uint32_t o = perm[i];
+            if (relieve && o == 0) o = 1 + (relieved++ % (count - 1));
+            owner[order[g * count + i].second] = (uint8_t)o;
+        }
     }
     return owner;
 }

@@ -509,6 +509,11 @@ class Renderer:
         return out
 
 
+def set_root_relief(per_256):
+    """process-wide, before contexts are created, the same on every rank: shard 0 gives up per_256 / 256 of its tiles (it also composites)"""
+    check(_lib.load().art_set_root_relief(int(per_256)))
+
+
 def renderer_for_scene(scene, extent, n_lights=None, **kw) -> Renderer:
     """Convenience used by tests and bench: the main.rs:23-66 sequence for a synthetic scene."""
     r = Renderer(extent, **kw)

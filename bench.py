@@ -57,6 +57,7 @@ def main():
                     help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
                          "1/(N-1) each; auto = shared: with the exchange submitted by the host (no device-side waits) a root that also traces a 1/8 share "
                          "spends 35.5 us per frame, exchange and un-tile included, where the tracers of a 7 + 1 layout need 39.1 (profiles/README.md r1n)")
+    ap.add_argument("--root-relief", type=int, default=-1, help="N>1, shared compositor: 1/256ths of rank 0's share handed to the other ranks (default 8 per GPU)")
     ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
     args = ap.parse_args()
@@ -95,6 +96,10 @@ def main():
     dedicated = world > 1 and args.compositor == "dedicated"
     G = world - 1 if dedicated else world           # shards of the frame = ranks that trace
     renders = not (dedicated and rank == 0)
+    # rank 0 also receives and un-tiles every frame: its share shrinks by 1/32 per GPU (2 GPUs: 6 %, 8 GPUs: 25 % of an equal share), which
+    # is what levels its loop with the others' on the rehearsal (profiles/README.md r1n: 35.7 -> 31 us per frame at N = 8)
+    relief = 0 if (world == 1 or dedicated) else min(255, (8 * world if args.root_relief < 0 else args.root_relief))
+    renderer.set_root_relief(relief)
     shard = ((rank - 1) if dedicated else rank, G) if renders else (0, G)   # the compositor keeps a context for the layout tables and the un-tile
     r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=shard if world > 1 else (0, 1), frames_in_flight=F, packed_tiles=packed)
     r.upload_state()
@@ -345,7 +350,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{'bistro_like(seed=0xB157' if args.scene == 'bistro' else 'sponza_like(seed=0x5A0A'}, {sc.n_tris} triangles, {len(sc.primitives)} primitives) {W}x{H}, {len(lights)} light(s), "
                                f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else "") + f", RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {GB} frames per gather") + f", {F} frames in flight"},
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else f" (rank 0 composites too and traces {256 - relief}/256 of a share)") + f", RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {GB} frames per gather") + f", {F} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F, "hip_graph_replay": use_graph,
         "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"],
         "gathered_frame_equals_single_gpu_frame": frame_ok,

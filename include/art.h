@@ -200,6 +200,10 @@ int32_t art_device_normal(ArtContext *ctx, void **dev_ptr, size_t *bytes);
 /* screen-tile sharding (new functionality, BASELINE.json): compact per-shard colour tiles for the RCCL gather, and
  * the un-tile step run by the root on the gathered buffer.  tile = 32x32 px, 16 KiB of RGBA32F each. */
 int32_t art_shard_tile_count(ArtContext *ctx, uint32_t *owned, uint32_t *padded);
+/* Process-wide, before any context is created, the same on every rank of a job: shard 0 (the rank that also receives and un-tiles every
+ * frame) gives up its tile in per_256 / 256 of the tile groups to the other shards in turn, so that its share + compositing takes as long
+ * as the others' shares.  0 (default) = equal shares.  ART_ROOT_RELIEF in the environment sets the initial value. */
+int32_t art_set_root_relief(uint32_t per_256);
 /* host-only (no device needed): the row-major ids of the tiles shard_rank owns for a width x height frame, in the
  * order they sit in its compact buffer; *owned = their number, *padded = the largest count over all shards (the
  * per-rank gather size).  tiles may be NULL to query the counts; cap = capacity of tiles. */

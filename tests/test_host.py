@@ -112,6 +112,29 @@ def test_shard_layout_partitions_the_frame():
     assert padded - len(t) <= 1 and padded * 8 - 2040 <= 8          # near-equal shares: load balance
 
 
+def test_root_relief_moves_tiles_from_shard_0_to_the_others():
+    """art_set_root_relief: the compositing rank's share shrinks by per_256 / 256, the others grow evenly, the frame stays a partition"""
+    from araytracingjourney_amd import sharding, _lib
+    L = _lib.load()
+    w, h, g = 1920, 1080, 8
+    try:
+        _lib.check(L.art_set_root_relief(64))
+        counts, all_tiles = [], []
+        for r in range(g):
+            t, padded = sharding.shard_layout(w, h, g, r)
+            counts.append(len(t)); all_tiles += t.tolist()
+        assert sorted(all_tiles) == list(range(2040))
+        assert 170 <= counts[0] <= 210 and max(counts[1:]) - min(counts[1:]) <= 2 and padded == max(counts)    # 255 * 3/4 = 191 +- the subset's luck
+        frame = np.arange(w * h * 4, dtype=np.float32).reshape(h, w, 4)
+        gathered = np.stack([sharding.tile_host(frame, g, r) for r in range(g)])
+        assert np.array_equal(sharding.untile_host(gathered, w, h, g), frame)
+        with pytest.raises(_lib.ArtError):
+            _lib.check(L.art_set_root_relief(256))
+    finally:
+        _lib.check(L.art_set_root_relief(0))
+    assert len(sharding.shard_layout(w, h, g, 0)[0]) == 255
+
+
 _GLOO_WORKER = r'''
 import os, sys
 import numpy as np, torch, torch.distributed as dist
