@@ -102,6 +102,9 @@ SYMBOLS = {
     "art_bind_color_tiles_pair": (_I32, [_P, _U32, _P, _P, _SZ]),
     "art_bind_color_tiles_ring": (_I32, [_P, _U32, _P, _U32, _SZ]),
     "art_set_graph_mode": (_I32, [_P, _I32]),
+    "art_set_frames_per_launch": (_I32, [_P, _U32]),
+    "art_set_camera_batch": (_I32, [_P, _P, _U32]),
+    "art_set_read_frame": (_I32, [_P, _U32]),
     "art_frames_in_flight": (_I32, [_P, _P, _P]),
     "art_stream_wait_frame": (_I32, [_P, _P]),
     "art_frames_done": (_I32, [_P, C.c_uint64, _U32, _P, _P]),

@@ -120,6 +120,8 @@ struct ArtContext {
     Lbvh bvh{};
     uint32_t T = 0;
     ArtCamera camera{};
+    uint32_t B = 1, read_b = 0;       // frames per launch of the fused frame (art_set_frames_per_launch); which of them the read / device-pointer calls refer to
+    ArtCamera cam_more[kMaxBatch - 1] = {}; // cameras of frames 1.. of a launch (frame 0: camera)
     std::vector<ArtLight> lights;
     DevBuf<ArtLight> d_lights[2]; int lights_cur = 0; // double-buffered: frames in flight may still read the previous records
     // frame
@@ -375,13 +377,14 @@ int32_t setup_frame(ArtContext *c) {
         HIPC(S.d_wave_cost.ensure(c->plan.cap ? c->plan.cap : 1));
         HIPC(S.d_counters.ensure(kCounterWords)); HIPC(hipMemset(S.d_counters.p, 0, kCounterWords * 4)); // packet frames keep them clear themselves (k_accumulate)
         const bool staged = !(c->fused && c->kind_primary == 8 && c->kind_shadow == 8); // the fused frame keeps these records in registers
-        if (staged || (c->cfg.flags & ART_FLAG_KEEP_DEBUG)) HIPC(S.d_hits.ensure(c->n_local));
+        const size_t B = c->B; // frames per launch: every output holds B frames back to back
+        if (staged || (c->cfg.flags & ART_FLAG_KEEP_DEBUG)) HIPC(S.d_hits.ensure(c->n_local * B));
         if (staged) { HIPC(S.d_contrib.ensure(nl * c->n_local)); HIPC(S.d_shadow_rays.ensure(2 * nl * c->n_local)); }
-        HIPC(S.d_color.ensure(npix)); HIPC(S.d_normal.ensure(npix)); HIPC(S.d_depth.ensure(npix));
-        HIPC(hipMemset(S.d_color.p, 0, npix * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * 4));
-        if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes())); }
-        if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local)); // fused frames always write their per-pixel shadow bits (stats)
-        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) { S.ext_tiles = nullptr; S.ext_ring_n = 0; S.tiles_of_last = nullptr; S.ext_tiles_bytes = 0; }
+        HIPC(S.d_color.ensure(npix * B)); HIPC(S.d_normal.ensure(npix * B)); HIPC(S.d_depth.ensure(npix * B));
+        HIPC(hipMemset(S.d_color.p, 0, npix * B * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * B * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * B * 4));
+        if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels * B)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * B * c->tile_px_bytes())); }
+        if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local * B)); // fused frames always write their per-pixel shadow bits (stats)
+        if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() * B) { S.ext_tiles = nullptr; S.ext_ring_n = 0; S.tiles_of_last = nullptr; S.ext_tiles_bytes = 0; }
     }
     HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
     drop_graphs(c);
@@ -635,9 +638,33 @@ int32_t art_set_camera(ArtContext *c, const ArtCamera *cam) {
     if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) drop_graphs(c); // the camera block is a kernel argument
     if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) { c->plan.next_sample = c->frame_no; c->plan.interval = 1; } // the heavy blocks move with the view
     c->camera = *cam; c->have_camera = true;
+    for (uint32_t i = 0; i + 1 < kMaxBatch; i++) c->cam_more[i] = *cam; // every frame of a launch, until art_set_camera_batch says otherwise
     return ART_OK;
 }
 
+int32_t art_set_frames_per_launch(ArtContext *c, uint32_t n) {
+    if (!c || n == 0 || n > kMaxBatch) return fail(ART_E_INVALID, "art_set_frames_per_launch: 1..4");
+    if (n > 1 && !(c->fused && c->kind_primary == 8 && c->kind_shadow == 8 && !c->packet_wide)) return fail(ART_E_STATE, "art_set_frames_per_launch: only the fused frame over the binary nodes traces several frames per launch");
+    if (n == c->B) return ART_OK;
+    int32_t r = use_device(c); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    drop_graphs(c);
+    c->B = n; c->read_b = 0; c->frame_ready = false; c->traced = false; // the per-slot buffers are laid out again, n frames each
+    for (uint32_t k = 0; k < c->F; k++) { c->slot[k].ext_tiles = nullptr; c->slot[k].ext_ring_n = 0; c->slot[k].tiles_of_last = nullptr; c->slot[k].ext_tiles_bytes = 0; }
+    return ART_OK;
+}
+int32_t art_set_camera_batch(ArtContext *c, const ArtCamera *cams, uint32_t n) {
+    if (!c || !cams) return fail(ART_E_INVALID, "art_set_camera_batch: null argument");
+    if (n != c->B) return fail(ART_E_INVALID, "art_set_camera_batch: one camera per frame of a launch (art_set_frames_per_launch)");
+    int32_t r = art_set_camera(c, &cams[0]); if (r) return r;
+    for (uint32_t i = 1; i < n; i++) c->cam_more[i - 1] = cams[i];
+    return ART_OK;
+}
+int32_t art_set_read_frame(ArtContext *c, uint32_t b) {
+    if (!c || b >= c->B) return fail(ART_E_INVALID, "art_set_read_frame: frame >= frames per launch");
+    c->read_b = b;
+    return ART_OK;
+}
 int32_t art_camera_from_params(const float pos[3], const float dir[3], float aspect, float fovy, float znear, float zfar, ArtCamera *out) {
     if (!pos || !dir || !out) return fail(ART_E_INVALID, "art_camera_from_params: null argument");
     // VkCamera::set_dir normalises (vk_camera.rs:133-136); view = look_at_rh(pos, pos + dir, up = (0,-1,0)) (:182-189)
@@ -734,6 +761,8 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     a.color_tiles = c->cfg.shard_count > 1 ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
     a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0; a.frame_waves = c->frame_waves;
+    a.batch = c->B; a.tiles_stride = c->padded_tiles * kTilePixels;
+    for (uint32_t i = 0; i + 1 < kMaxBatch; i++) std::memcpy(&a.cam_more[i], &c->cam_more[i], sizeof(ArtCamera));
     a.tile_xy = c->d_tile_xy.p; a.wave_items = c->plan.d_items[c->plan.cur].p; a.n_wave_items = c->plan.n_items[c->plan.cur]; a.wave_cost = nullptr; // art_trace sets it for the frames the wave plan samples
     return a;
 }
@@ -754,6 +783,7 @@ int32_t art_trace(ArtContext *c) {
     FrameArgs a = make_frame_args(c, S);
     if (c->cfg.shard_count > 1) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
+    if (c->B > 1 && (!fused || c->packet_wide || c->frame_waves < 8)) return fail(ART_E_STATE, "art_trace: several frames per launch need the default fused frame");
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     c->ev_fused[c->frame_no % ArtContext::kRing] = fused;
     if (c->graph_mode && !fused && S.ext_ring_n < 2) { // a fused frame is a single launch: nothing for a graph to save; alternating tile buffers change a kernel argument
@@ -826,6 +856,7 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     if (!c) return fail(ART_E_INVALID, "art_trace_ao: null context");
     if (!c->traced || !c->frame_ready) return fail(ART_E_STATE, "art_trace_ao: call art_trace first (AO consumes that frame's depth + normal outputs)");
     if (spp == 0 || spp > 64 || !(radius > 0.0f)) return fail(ART_E_INVALID, "art_trace_ao: spp must be 1..64 and radius > 0");
+    if (c->B > 1) return fail(ART_E_STATE, "art_trace_ao: not with several frames per launch");
     int32_t r = use_device(c); if (r) return r;
     r = ensure_wide(c, c->kind_ao == 4 || (c->kind_ao == 8 && c->packet_wide)); if (r) return r;
     FrameSlot &S = c->slot[c->last];
@@ -852,6 +883,7 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
 int32_t art_present(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "art_present: null context");
     if (!c->traced || !c->frame_ready) return fail(ART_E_STATE, "art_present: call art_trace first");
+    if (c->B > 1) return fail(ART_E_STATE, "art_present: not with several frames per launch");
     int32_t r = use_device(c); if (r) return r;
     FrameSlot &S = c->slot[c->last];
     hipStream_t s = c->stream_of(c->last);
@@ -882,9 +914,9 @@ static int32_t read_back(ArtContext *c, const void *src, size_t have, void *dst,
     HIPC(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return ART_OK;
 }
-int32_t art_read_color(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_color.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_color"); }
-int32_t art_read_depth(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_depth.p : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_depth"); }
-int32_t art_read_normal(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_normal.p : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_normal"); }
+int32_t art_read_color(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_color.p + (size_t)c->read_b * c->W * c->H : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_color"); }
+int32_t art_read_depth(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_depth.p + (size_t)c->read_b * c->W * c->H : nullptr, c ? (size_t)c->W * c->H * 4 : 0, dst, bytes, "art_read_depth"); }
+int32_t art_read_normal(ArtContext *c, void *dst, size_t bytes) { return read_back(c, c ? c->slot[c->last].d_normal.p + (size_t)c->read_b * c->W * c->H : nullptr, c ? (size_t)c->W * c->H * 16 : 0, dst, bytes, "art_read_normal"); }
 
 static int32_t dev_ptr(ArtContext *c, void *p, size_t n, void **out, size_t *bytes, const char *who) {
     if (!c || !out) return fail(ART_E_INVALID, std::string(who) + ": null argument");
@@ -914,9 +946,9 @@ int32_t art_read_packed(ArtContext *c, void *color_b10g11r11, void *normal_b10g1
     if (depth_f16) { r = read_back(c, c->slot[c->last].d_pdepth.p, npix * 2, depth_f16, npix * 2, "art_read_packed"); if (r) return r; }
     return ART_OK;
 }
-int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color"); if (r) return r; *p = c->slot[c->last].d_color.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
-int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
-int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->slot[c->last].d_normal.p; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
+int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color"); if (r) return r; *p = c->slot[c->last].d_color.p + (size_t)c->read_b * c->W * c->H; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
+int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p + (size_t)c->read_b * c->W * c->H; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
+int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->slot[c->last].d_normal.p + (size_t)c->read_b * c->W * c->H; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 
 static const int g_relief_env_applied = [] { if (const char *e = std::getenv("ART_ROOT_RELIEF")) { int v = std::atoi(e); if (v >= 0 && v <= 255) shard_root_relief() = (uint32_t)v; } return 0; }();
 int32_t art_set_root_relief(uint32_t per_256) {
@@ -955,7 +987,8 @@ int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
     int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color_tiles"); if (r) return r;
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
     FrameSlot &S = c->slot[c->last];
-    *p = S.last_tiles(); if (b) *b = (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes();
+    const size_t one = (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes();
+    *p = (char *)S.last_tiles() + c->read_b * one; if (b) *b = one;
     return ART_OK;
 }
 int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t bytes) {
@@ -963,7 +996,7 @@ int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t byt
     if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_bind_color_tiles: context is not sharded");
     if (slot >= c->F) return fail(ART_E_INVALID, "art_bind_color_tiles: slot >= frames in flight");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_bind_color_tiles"); if (r) return r;
-    if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes()) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch");
+    if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() * c->B) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch (padded tiles x tile bytes x frames per launch)");
     HIPC(hipStreamSynchronize(c->stream_of(slot)));
     c->slot[slot].ext_tiles = (float4 *)dev; c->slot[slot].ext_ring_n = 0; c->slot[slot].tiles_of_last = nullptr; c->slot[slot].ext_tiles_bytes = dev ? bytes : 0;
     drop_graphs(c);
@@ -1051,7 +1084,8 @@ int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames)
 int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
     if (c && c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
     FrameSlot *S = c ? &c->slot[c->last] : nullptr;
-    return read_back(c, S ? S->last_tiles() : nullptr, c ? (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() : 0, dst, bytes, "art_read_color_tiles");
+    const size_t one = c ? (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() : 0;
+    return read_back(c, S ? (const char *)S->last_tiles() + c->read_b * one : nullptr, one, dst, bytes, "art_read_color_tiles");
 }
 int32_t art_untile_gathered_frames(ArtContext *c, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, uint32_t n_frames, void *frames_dev, void *hip_stream) {
     if (!c || !gathered_dev) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
@@ -1088,7 +1122,11 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         if (c->fused && c->kind_primary == 8 && c->kind_shadow == 8) { // fused frames keep no counters: count from the frame's per-pixel bits + depth, here
             FrameSlot &S = c->slot[c->last];
             HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, c->stream_of(c->last)));
-            if (c->n_local) { launch_frame_stats(make_frame_args(c, S), S.d_counters.p, c->stream_of(c->last)); HIPC(hipGetLastError()); }
+            if (c->n_local) { // of the frame the read calls refer to
+                FrameArgs fa = make_frame_args(c, S);
+                fa.pix_bits += (size_t)c->read_b * c->n_local; fa.depth += (size_t)c->read_b * c->W * c->H;
+                launch_frame_stats(fa, S.d_counters.p, c->stream_of(c->last)); HIPC(hipGetLastError());
+            }
             HIPC(hipStreamSynchronize(c->stream_of(c->last)));
         }
         HIPC(hipMemcpy(raw.data(), c->slot[c->last].d_counters.p, kCounterWords * 4, hipMemcpyDeviceToHost));
@@ -1133,7 +1171,7 @@ int32_t art_read_hits(ArtContext *c, float *tuv, int32_t *ids, size_t n_pixels) 
     r = sync_all(c); if (r) return r;
     std::vector<float4> h(c->n_local);
     std::vector<DevTri> tris(c->T);
-    HIPC(hipMemcpy(h.data(), c->slot[c->last].d_hits.p, (size_t)c->n_local * 16, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(h.data(), c->slot[c->last].d_hits.p + (size_t)c->read_b * c->n_local, (size_t)c->n_local * 16, hipMemcpyDeviceToHost));
     HIPC(hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n_pixels; i++) { tuv[4 * i] = 0; tuv[4 * i + 1] = 0; tuv[4 * i + 2] = 0; tuv[4 * i + 3] = 0; ids[2 * i] = -2; ids[2 * i + 1] = -2; } // -2: not owned
     for (uint32_t p = 0; p < c->n_local; p++) {
@@ -1157,7 +1195,7 @@ int32_t art_read_shadow_bits(ArtContext *c, uint32_t *bits, size_t n_pixels) {
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
     std::vector<uint32_t> sb(c->n_local);
-    HIPC(hipMemcpy(sb.data(), c->slot[c->last].d_shadow_bits.p, (size_t)c->n_local * 4, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(sb.data(), c->slot[c->last].d_shadow_bits.p + (size_t)c->read_b * c->n_local, (size_t)c->n_local * 4, hipMemcpyDeviceToHost));
     std::memset(bits, 0, n_pixels * 4);
     for (uint32_t p = 0; p < c->n_local; p++) {
         uint32_t tile = c->tile_list[p >> 10], q = p & 1023u, sub = q >> 6, l = q & 63u;

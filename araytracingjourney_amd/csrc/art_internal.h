@@ -153,7 +153,12 @@ struct FrameArgs {
     const uint2 *wave_items; uint32_t n_wave_items;
     const uint32_t *tile_xy;   // [n_tiles_owned] x | y << 16 of each owned tile (tile units)
     uint32_t *wave_cost;       // [n_wave_items] packet steps each wave made, or nullptr
+    // fused frame, several frames per launch (art_set_frames_per_launch): grid.y = frame b of the launch.  Frame b uses cam (b = 0) or
+    // cam_more[b - 1], and writes its outputs b * (W * H) pixels (color, depth, normal), b * n_local (pix_bits, hits) and
+    // b * tiles_stride (color_tiles) further on.  A launch costs ~7 us of machine time whatever it traces (profiles/README.md r1o).
+    uint32_t batch; uint32_t tiles_stride; CameraArg cam_more[3];
 };
+constexpr uint32_t kMaxBatch = 4;
 void launch_primary(const FrameArgs &a, hipStream_t s);
 void launch_shade(const FrameArgs &a, hipStream_t s);
 void launch_shadow(const FrameArgs &a, hipStream_t s);

@@ -795,7 +795,7 @@ __device__ float4 sample_tex(const uint32_t *__restrict__ pool, const DevPrim &P
 struct Surface { V3 world_pos, N, Vv, albedo; float metallic, alpha, nc_NdotV, NdotV; };
 
 // rgen:107-150: the hit triangle's attributes, normal mapping, material; also the frame's depth / view-space normal outputs
-__device__ __forceinline__ void shade_surface(const FrameArgs &a, uint32_t pos, float hu, float hv, Surface &S, float &out_depth, V3 &out_normal) {
+__device__ __forceinline__ void shade_surface(const FrameArgs &a, const CameraArg &cam, uint32_t pos, float hu, float hv, Surface &S, float &out_depth, V3 &out_normal) {
     // one dependent fetch: the shading record holds what get_indices + three vertex reads would return (rgen:107-114)
     const float4 *sq = reinterpret_cast<const float4 *>(a.shade_tris + pos);
     float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3], s4 = sq[4], s5 = sq[5], s6 = sq[6], s7 = sq[7], s8 = sq[8];
@@ -819,13 +819,13 @@ __device__ __forceinline__ void shade_surface(const FrameArgs &a, uint32_t pos, 
     tx = sample_tex(a.tex_pool, P, 1, tu, tv);
     float roughness = tx.y, metallic = tx.z;
     S.world_pos = world_pos; S.N = N; S.albedo = albedo; S.metallic = metallic;
-    S.Vv = nrm3(ld3(a.cam.camera_pos) - world_pos); // exact: V + L cancels at grazing angles and would amplify a 1-ulp rsq
+    S.Vv = nrm3(ld3(cam.camera_pos) - world_pos); // exact: V + L cancels at grazing angles and would amplify a 1-ulp rsq
     S.alpha = roughness * roughness;
     S.nc_NdotV = dot3(N, S.Vv);
     S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
-    V3 vp = mat4_mul(a.cam.view, world_pos.x, world_pos.y, world_pos.z, 1.0f);
+    V3 vp = mat4_mul(cam.view, world_pos.x, world_pos.y, world_pos.z, 1.0f);
     out_depth = -vp.z;
-    const float *VI = a.cam.view_inv;
+    const float *VI = cam.view_inv;
     V3 on = mk((VI[0] * N.x + VI[1] * N.y) + VI[2] * N.z, (VI[4] * N.x + VI[5] * N.y) + VI[6] * N.z, (VI[8] * N.x + VI[9] * N.y) + VI[10] * N.z);
     on.y = -on.y; on.z = -on.z;
     on = nrm3(on);
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
         }
     } else {
         Surface S;
-        shade_surface(a, pos, h.y, h.z, S, out_depth, out_normal);
+        shade_surface(a, a.cam, pos, h.y, h.z, S, out_depth, out_normal);
         for (uint32_t i = 0; i < a.n_lights; i++) {
             float4 c4, ro, rd;
             bool want = shade_light(a.lights[i], S, c4, ro, rd);
@@ -922,7 +922,7 @@ __device__ __forceinline__ bool frame_pixel(const FrameArgs &a, uint32_t wid, ui
     y = (txy >> 16) * kTile + (sub >> 2) * 8u + (lane >> 3);
     return x < a.W && y < a.H && mine;
 }
-template <bool WIDE, int WAVES, bool ONE_LIGHT, bool COUNT = false>
+template <bool WIDE, int WAVES, bool ONE_LIGHT, bool COUNT = false, bool BATCH = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
@@ -931,6 +931,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
     if (wid >= a.n_wave_items) return;
     uint32_t steps = 0; // packet steps of this wave, all walks
+    const uint32_t fb = BATCH ? blockIdx.y : 0u;   // which frame of the launch (wave-uniform)
+    const CameraArg &cam = (BATCH && fb) ? a.cam_more[fb - 1] : a.cam;
+    const size_t frame_px = (size_t)fb * a.W * a.H, frame_local = (size_t)fb * a.n_local;
     // The pixel a lane works on is looked up again wherever it is needed (here, at the depth/normal stores, at the end) instead of being
     // carried through the walks: the walks run at the 64-register edge.
     bool in;
@@ -940,9 +943,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
         in = frame_pixel(a, wid, p, x, y, mine);
         float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
         float dx = (fx / (float)a.W) * 2.0f - 1.0f, dy = (fy / (float)a.H) * 2.0f - 1.0f;
-        V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
-        V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
-        V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
+        V3 org = mat4_mul(cam.view_inv, 0.f, 0.f, 0.f, 1.f);
+        V3 tgt = nrm3(mat4_mul(cam.proj_inv, dx, dy, 1.f, 1.f));
+        V3 dir = mat4_mul(cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
         ray_init(r, org, dir, 0.001f, 10000.0f);
     }
     bool on = in;
@@ -951,16 +954,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     walk_dispatch<false, WIDE, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps);
     uint32_t p, x, y; bool mine;
     frame_pixel(a, wid, p, x, y, mine);
-    if (a.keep_hits && mine) a.hits[p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
+    if (a.keep_hits && mine) a.hits[frame_local + p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
     const bool hit = in && bpos != kNoHit;
     float out_depth = 10000.0f;
     V3 out_normal = mk(0.5f, 0.5f, 0.5f);
     Surface S;
     S.world_pos = mk(0.f, 0.f, 0.f); S.N = mk(0.f, 0.f, 1.f); S.Vv = mk(0.f, 0.f, 1.f); S.albedo = mk(0.f, 0.f, 0.f);
     S.metallic = 0.f; S.alpha = 0.f; S.nc_NdotV = 0.f; S.NdotV = 0.f;
-    if (hit) shade_surface(a, bpos, bu, bv, S, out_depth, out_normal);
+    if (hit) shade_surface(a, cam, bpos, bu, bv, S, out_depth, out_normal);
     if (in) {
-        const size_t pix = (size_t)y * a.W + x;
+        const size_t pix = frame_px + (size_t)y * a.W + x;
         st_nt(&a.depth[pix], out_depth);
         st_nt(&a.normal[pix], make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f));
     }
@@ -1001,15 +1004,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     if (!in) { rx = 0.f; ry = 0.f; rz = 0.f; }
     float4 o = make_float4(rx, ry, rz, 1.0f);
     frame_pixel(a, wid, p, x, y, mine);
-    if (in) st_nt(&a.color[(size_t)y * a.W + x], o);
+    if (in) st_nt(&a.color[frame_px + (size_t)y * a.W + x], o);
     if (a.color_tiles && mine) { // compact tile buffer for the gather: row-major inside each 32x32 tile
         uint32_t q = p & 1023u, sub = q >> 6, l = q & 63u;
         uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
-        size_t ti = (size_t)(p >> 10) * kTilePixels + ly * kTile + lx;
+        size_t ti = (size_t)fb * a.tiles_stride + (size_t)(p >> 10) * kTilePixels + ly * kTile + lx;
         if (a.tiles_packed) __builtin_nontemporal_store(pack_b10g11r11(o.x, o.y, o.z), reinterpret_cast<uint32_t *>(a.color_tiles) + ti);
         else st_nt(&a.color_tiles[ti], o);
     }
-    if (mine) a.pix_bits[p] = sbits;
+    if (mine) a.pix_bits[frame_local + p] = sbits;
     if (COUNT && __lane_id() == 0) a.wave_cost[wid] = steps; // feedback for the next plan (art_api.hip plan_poll)
 }
 
@@ -1115,6 +1118,13 @@ bool launch_frame(const FrameArgs &a, hipStream_t s) { // returns whether the la
     const uint32_t g = (a.n_wave_items + kBlock / 64 - 1) / (kBlock / 64);
     if (g == 0) return false;
     const bool one = a.n_lights == 1;
+    if (a.batch > 1) { // several frames per launch (art_api.hip checks: packets over the binary nodes, at least one light)
+        const dim3 gb(g, a.batch);
+        const bool count = a.wave_cost != nullptr;
+        if (a.n_lights == 1) { if (count) k_frame<false, 8, true, true, true><<<gb, kBlock, 0, s>>>(a); else k_frame<false, 8, true, false, true><<<gb, kBlock, 0, s>>>(a); }
+        else { if (count) k_frame<false, 8, false, true, true><<<gb, kBlock, 0, s>>>(a); else k_frame<false, 8, false, false, true><<<gb, kBlock, 0, s>>>(a); }
+        return count;
+    }
     if (a.wave_cost && !a.packet_wide && waves >= 8 && a.n_lights > 0) { // a sampled frame of the wave plan: the step-counting instances
         if (a.n_lights == 1) k_frame<false, 8, true, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 8, false, true><<<g, kBlock, 0, s>>>(a);
         return true;

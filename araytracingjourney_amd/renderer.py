@@ -400,6 +400,21 @@ class Renderer:
     def set_graph_mode(self, on):
         check(self._L.art_set_graph_mode(self._ctx, int(bool(on))))
 
+    def set_frames_per_launch(self, n):
+        """n frames per art_trace launch (fused frame); a ring slot then holds n frames"""
+        check(self._L.art_set_frames_per_launch(self._ctx, n))
+        self.frames_per_launch = n
+
+    def set_camera_batch(self, cameras):
+        """one Camera per frame of a launch"""
+        arr = (ArtCamera * len(cameras))()
+        for i, cam in enumerate(cameras):
+            C.memmove(C.byref(arr[i]), C.byref(cam.update_host_buffer()), C.sizeof(ArtCamera))
+        check(self._L.art_set_camera_batch(self._ctx, arr, len(cameras)))
+
+    def set_read_frame(self, b):
+        check(self._L.art_set_read_frame(self._ctx, b))
+
     def frames_done(self, first, count):
         """host-side, non-blocking: have frames [first, first + count) (art_trace order, from 0) all finished?"""
         d = C.c_int32()

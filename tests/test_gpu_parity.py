@@ -435,6 +435,59 @@ def test_wave_plan_changes_the_waves_never_the_image(R, get_scene, monkeypatch):
         r.close()
 
 
+def test_several_frames_per_launch_equal_the_single_frames(R, get_scene):
+    """art_set_frames_per_launch: one launch traces n frames, each with its own camera (art_set_camera_batch); every frame -- colour,
+    depth, normal, ray counts, and the compact tiles of a sharded context -- equals the frame traced alone; 1 and 4 lights"""
+    import torch
+    from araytracingjourney_amd import scenes
+    from araytracingjourney_amd._lib import ArtError
+    sc = get_scene("sponza_like", 0.12)
+    w, h, B = 320, 200, 3
+    for n_lights, shard in ((1, (0, 1)), (4, (1, 2))):
+        one = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=1, shard=shard)
+        many = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=2, shard=shard)
+        for x in (one, many):
+            for d in scenes.sponza_lights(n_lights):
+                x.lights_mut().push_dict(d)
+        many.set_frames_per_launch(B)
+        many.upload_state()
+        cams = []
+        for b in range(B):
+            p0, c0 = sc.camera["pos"], many.camera_mut()
+            cams.append(R.Camera((p0[0] + 0.05 * b, p0[1] + 0.02 * b, p0[2] - 0.03 * b), c0.dir(), c0.aspect(), c0.fovy(), c0._znear, c0._zfar))
+        tiles = None
+        if shard[1] > 1:
+            owned, padded = many.shard_tile_count()
+            tiles = torch.zeros((2, B, padded, 32, 32, 4), dtype=torch.float32, device="cuda")
+            with pytest.raises(ArtError):
+                many.bind_color_tiles(0, tiles[0, 0].data_ptr(), tiles[0, 0].numel() * 4)      # one frame's worth: too small
+            for k in range(2):
+                many.bind_color_tiles(k, tiles[k].data_ptr(), tiles[k].numel() * 4)
+        for trip in range(3):                                 # the second and third launches run on the wave plan of the first
+            many.set_camera_batch(cams)
+            many.trace()
+            many.sync()
+            for b in range(B):
+                one.camera_mut().set_pos(cams[b].pos())
+                one.render_frame()
+                many.set_read_frame(b)
+                for name in ("read_color", "read_depth", "read_normal"):
+                    assert np.array_equal(getattr(many, name)().view(np.uint32), getattr(one, name)().view(np.uint32)), (n_lights, shard, trip, b, name)
+                so, sm = one.stats(), many.stats()
+                assert sm["shadow_rays"] == so["shadow_rays"] and sm["hit_pixels"] == so["hit_pixels"]
+                if tiles is not None:
+                    assert np.array_equal(many.read_color_tiles().view(np.uint32), one.read_color_tiles().view(np.uint32))
+                    assert np.array_equal(tiles[trip % 2, b].cpu().numpy().view(np.uint32), one.read_color_tiles().view(np.uint32))
+        with pytest.raises(ArtError):
+            many.trace_ao(4)
+        with pytest.raises(ArtError):
+            many.set_read_frame(B)
+        with pytest.raises(ArtError):
+            many.set_frames_per_launch(5)
+        one.close()
+        many.close()
+
+
 def test_residency_only_device_models_are_traced(R, get_scene):
     """renderer.rs:637-651 + vk_model.rs:334-345: a model farther than 10 units from the camera leaves the acceleration structure
     (the frame equals the one without it), comes back when the camera approaches; with nothing in range every ray misses"""
