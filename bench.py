@@ -57,6 +57,7 @@ def main():
                     help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
                          "1/(N-1) each; auto = shared: with the exchange submitted by the host (no device-side waits) a root that also traces a 1/8 share "
                          "spends 35.5 us per frame, exchange and un-tile included, where the tracers of a 7 + 1 layout need 39.1 (profiles/README.md r1n)")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="N>1: frames one launch traces (1..4; default: the largest of 4, 2, 1 that divides --steps; a launch costs ~7 us of machine time whatever it traces, which a 1/8 share feels)")
     ap.add_argument("--root-relief", type=int, default=-1, help="N>1, shared compositor: 1/256ths of rank 0's share handed to the other ranks (default 8 per GPU)")
     ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
@@ -102,6 +103,12 @@ def main():
     renderer.set_root_relief(relief)
     shard = ((rank - 1) if dedicated else rank, G) if renders else (0, G)   # the compositor keeps a context for the layout tables and the un-tile
     r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=shard if world > 1 else (0, 1), frames_in_flight=F, packed_tiles=packed)
+    B = 1                             # frames per launch
+    if world > 1 and not args.ao:
+        B = args.frames_per_launch if args.frames_per_launch > 0 else next(b for b in (4, 2, 1) if args.steps % b == 0)
+        if args.steps % B:
+            raise SystemExit(f"--steps {args.steps} is not a multiple of --frames-per-launch {B}")
+        r.set_frames_per_launch(B)
     r.upload_state()
     stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
     torch.cuda.set_stream(stream)
@@ -119,12 +126,12 @@ def main():
         tshape, tdtype = ((padded, 32, 32), torch.int32) if packed else ((padded, 32, 32, 4), torch.float32)
         # slot k renders into tiles[trip % NBUF][k]: GB slots are one contiguous message, and a slot's next frames never wait for the
         # exchanges that still read its previous tiles
-        tiles = torch.zeros((NBUF, F) + tshape, dtype=tdtype, device="cuda")
+        tiles = torch.zeros((NBUF, F, B) + tshape, dtype=tdtype, device="cuda")   # [buffer][slot = launch][frame of the launch]
         for k in range(F):
             r.bind_color_tiles_ring(k, [tiles[b, k].data_ptr() for b in range(NBUF)], tiles[0, k].numel() * 4)
         if rank == 0:
-            gathered = torch.empty((world, F) + tshape, dtype=tdtype, device="cuda")   # [peer][slot]: a frame's shards are F * padded tiles apart
-            frame = torch.zeros((GB,) + ((H, W) if packed else (H, W, 4)), dtype=tdtype, device="cuda")   # the frames of one exchange, un-tiled by one launch
+            gathered = torch.empty((world, F, B) + tshape, dtype=tdtype, device="cuda")   # [peer][slot][frame]: a frame's shards are F * B * padded tiles apart
+            frame = torch.zeros((GB * B,) + ((H, W) if packed else (H, W, 4)), dtype=tdtype, device="cuda")   # the frames of one exchange, un-tiled by one launch
         torch.cuda.synchronize()
 
     traced = [0]                      # frames submitted so far (tile buffer = (traced // F) % NBUF)
@@ -194,8 +201,8 @@ def main():
                     gathered[w, k0:k0 + n].copy_(parts[w])
         if rank == 0:                                       # every frame of the exchange is un-tiled, by one launch
             first = 1 if dedicated else 0                   # shard s of the frame came from rank first + s
-            r.untile_gathered(gathered[first, k0].data_ptr(), G, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * padded, n_frames=n)
-            newest[0] = n - 1
+            r.untile_gathered(gathered[first, k0].data_ptr(), G, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * B * padded, n_frames=n * B)
+            newest[0] = n * B - 1
         ev = torch.cuda.Event()
         ev.record(stream)
         for j in range(k0, k0 + n):
@@ -212,12 +219,16 @@ def main():
 
     use_graph = (world > 1) if args.graph < 0 else bool(args.graph)
     r.set_graph_mode(use_graph)
-    for _ in range(args.warmup):
+    if world > 1:                     # two trips round the ring before anything is counted: the wave plan has seen a frame and settled
+        for _ in range(2 * F):
+            step()
+        fence()
+    for _ in range((args.warmup + B - 1) // B):   # a step() is one launch = B frames
         step()
     fence()
     r.collect_timings()  # drop the warm-up frames from the per-stage event sums
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // B):
         step()
     fence()
     wall = time.perf_counter() - t0
@@ -327,7 +338,7 @@ def main():
         dom = "frame" if fused else ("primary" if stage_max["primary_ms"] >= stage_max["shadow_ms"] else "shadow")
         kname = {"frame": "k_frame", "primary": "k_primary", "shadow": "k_shadow"}[dom]
         dur_ms = stage_max["primary_ms" if fused else f"{dom}_ms"]
-        per_launch = ab[dom] / world  # each rank's launch handles 1/world of the frame's rays
+        per_launch = ab[dom] / world * B  # each rank's launch handles 1/world of the rays of B frames
         achieved = per_launch / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         iso_ms = iso["primary_ms" if fused else f"{dom}_ms"]
         traffic, traffic_src = None, None   # PMC counters cannot be read from inside this process: the committed separate-pass measurement of this exact workload
@@ -350,8 +361,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{'bistro_like(seed=0xB157' if args.scene == 'bistro' else 'sponza_like(seed=0x5A0A'}, {sc.n_tris} triangles, {len(sc.primitives)} primitives) {W}x{H}, {len(lights)} light(s), "
                                f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else f" (rank 0 composites too and traces {256 - relief}/256 of a share)") + f", RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {GB} frames per gather") + f", {F} frames in flight"},
-        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F, "hip_graph_replay": use_graph,
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else f" (rank 0 composites too and traces {256 - relief}/256 of a share)") + f", RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {B} frames per launch, {GB * B} frames per gather") + f", {F * B} frames in flight"},
+        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B, "hip_graph_replay": use_graph,
         "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"],
         "gathered_frame_equals_single_gpu_frame": frame_ok,
         "roofline": roof, "cpu_baseline": cpu,

@@ -10,6 +10,8 @@ MODE = sys.argv[3] if len(sys.argv) > 3 else "full"   # full | nountile | nocopy
 sc = scenes.sponza_like()
 W, H = 1920, 1080
 r = renderer.renderer_for_scene(sc, (W, H), shard=(0, G), frames_in_flight=F, packed_tiles=True)
+PB = int(os.environ.get('PB', '1'))   # frames per launch
+if PB > 1: r.set_frames_per_launch(PB)
 r.upload_state()
 PRIO = -1 if os.environ.get('HIPRIO', '1') == '1' else 0
 XS = int(os.environ.get('XS', '1'))   # exchange streams used in turn (one exchange = one gather group)
@@ -19,12 +21,12 @@ group_no = [0]
 owned, padded = r.shard_tile_count()
 PAIR = os.environ.get('PAIR', '1') == '1'
 NB = int(os.environ.get('NB', '2')) if PAIR else 1   # tile buffers per ring slot
-tiles = torch.zeros((NB, F, padded, 32, 32), dtype=torch.int32, device="cuda")
+tiles = torch.zeros((NB, F, PB, padded, 32, 32), dtype=torch.int32, device="cuda")
 for k in range(F):
     if PAIR: r.bind_color_tiles_ring(k, [tiles[b, k].data_ptr() for b in range(NB)], tiles[0, k].numel() * 4)
     else: r.bind_color_tiles(k, tiles[0, k].data_ptr(), tiles[0, k].numel() * 4)
-gathered = torch.zeros((G, F, padded, 32, 32), dtype=torch.int32, device="cuda")
-frames = [torch.zeros((GB, H, W), dtype=torch.int32, device="cuda") for _ in range(XS)]
+gathered = torch.zeros((G, F, PB, padded, 32, 32), dtype=torch.int32, device="cuda")
+frames = [torch.zeros((GB * PB, H, W), dtype=torch.int32, device="cuda") for _ in range(XS)]
 consumed = [[None] * F for _ in range(NB)]
 pending = [0, 0]
 frame_no = [0]
@@ -56,7 +58,7 @@ def run_exchange(k0, n, par):
         if MODE != "nocopy": gathered[0, k0:k0 + n].copy_(tiles[par, k0:k0 + n])
         e1 = torch.cuda.Event(enable_timing=True); e1.record(xs)
         if MODE != "nountile":
-            r.untile_gathered(gathered[0, k0].data_ptr(), G, frames[(group_no[0] - 1) % XS].data_ptr(), xs.cuda_stream, shard_stride_tiles=F * padded, n_frames=n)
+            r.untile_gathered(gathered[0, k0].data_ptr(), G, frames[(group_no[0] - 1) % XS].data_ptr(), xs.cuda_stream, shard_stride_tiles=F * PB * padded, n_frames=n * PB)
     ev = torch.cuda.Event(enable_timing=True); ev.record(xs)
     xlog.append((e0, e1, ev))
     for j in range(k0, k0 + n): consumed[par][j] = ev
@@ -100,4 +102,4 @@ if xlog:
     med = lambda v: sorted(v)[len(v) // 2]
     print("exchange kernels, median us: copy", round(med([a.elapsed_time(b) for a, b, c in xlog]) * 1e3), "un-tile", round(med([b.elapsed_time(c) for a, b, c in xlog]) * 1e3),
           "| from one exchange's end to the next", round(med([xlog[i][2].elapsed_time(xlog[i + 1][2]) for i in range(len(xlog) - 1)]) * 1e3))
-print(f"G={G} GB={GB} {MODE}: host loop {(t1-t0)/K*1e6:.1f} us/frame, pipeline {(t2-t0)/K*1e6:.1f} us/frame", flush=True)
+print(f"G={G} GB={GB} B={PB} {MODE}: host loop {(t1-t0)/K/PB*1e6:.1f} us/frame, pipeline {(t2-t0)/K/PB*1e6:.1f} us/frame", flush=True)
