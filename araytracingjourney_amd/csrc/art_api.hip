@@ -261,7 +261,7 @@ static int32_t plan_poll(ArtContext *c) {
     uint64_t sum = 0;
     for (size_t i = 0; i < items.size(); i++) if (items[i].y) sum += P.h_cost[i];
     constexpr double kWaveSlots = 256.0 * 32.0; // CUs x waves per CU
-    uint32_t T = P.fixed_steps ? P.fixed_steps : std::max(P.min_steps, (uint32_t)(P.alpha * (double)sum * P.in_flight / kWaveSlots));
+    uint32_t T = P.fixed_steps ? P.fixed_steps : std::max(P.min_steps, (uint32_t)(P.alpha * (double)sum * c->B * P.in_flight / kWaveSlots)); // sum: one frame's steps; a launch traces B frames
     std::vector<uint8_t> next;
     std::vector<uint32_t> est(P.level.size(), 0);
     for (int attempt = 0; attempt < 8; attempt++, T += T / 2) {
