@@ -9,7 +9,7 @@ G, F, GB = int(sys.argv[1]), int(os.environ.get("PF", "16")), int(sys.argv[2]) i
 MODE = sys.argv[3] if len(sys.argv) > 3 else "full"   # full | nountile | nocopy | noexchange | nowait
 sc = scenes.sponza_like()
 W, H = 1920, 1080
-r = renderer.renderer_for_scene(sc, (W, H), shard=(0, G), frames_in_flight=F, packed_tiles=True)
+r = renderer.renderer_for_scene(sc, (W, H), shard=(int(os.environ.get("PK", "0")), G), frames_in_flight=F, packed_tiles=True)
 PB = int(os.environ.get('PB', '1'))   # frames per launch
 if PB > 1: r.set_frames_per_launch(PB)
 r.upload_state()
