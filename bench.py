@@ -297,7 +297,7 @@ def main():
 
     # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame
     cpu = None
-    if not args.no_cpu_baseline and not args.ao:
+    if not args.no_cpu_baseline and not args.ao and world == 1:   # rank 0 at N = 1 only (the contract)
         from oracle import orc
         ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
         try:  # a cgroup CPU quota (e.g. 16 CPUs of a 256-thread host) is the real core budget

@@ -89,7 +89,7 @@ xlog = []
 prof = dict(gate=0.0, trace=0.0, swf=0.0, xchg=0.0, waits=0, poll=0.0, polls=0)
 for _ in range(64): step()
 exchange(True); r.sync(); torch.cuda.synchronize()
-K = 800
+K = int(os.environ.get("PKN", "800"))   # launches timed
 xlog.clear()
 prof = dict(gate=0.0, trace=0.0, swf=0.0, xchg=0.0, waits=0, poll=0.0, polls=0)
 t0 = time.perf_counter()
