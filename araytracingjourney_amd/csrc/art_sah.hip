@@ -174,12 +174,27 @@ struct Builder {
         std::vector<Task> open; open.push_back(Task{0, T, 0, 0});
         const size_t want = threads > 1 ? (size_t)threads * 8 : 1;
         wide_threads = threads < kMaxThreads ? threads : kMaxThreads;
+        // Rounds: every open range of >= 4096 leaves is split once per round.  While there are few of them each split runs its passes on
+        // all threads (chunks()); from four ranges on the ranges themselves are the parallel work, one thread each (the serial middle of the
+        // tree -- ranges between 4 096 and 65 535 leaves split one after another -- used to be about half of the build).
         while (threads > 1 && open.size() < want) {
-            size_t big = 0;
-            for (size_t i = 1; i < open.size(); i++) if (open[i].e - open[i].b > open[big].e - open[big].b) big = i;
-            if (open[big].e - open[big].b < 4096) break;
-            Task t = open[big]; open.erase(open.begin() + (long)big);
-            node(t, [&](Task c) { open.push_back(c); });
+            std::vector<Task> big, rest;
+            for (const Task &t : open) (t.e - t.b >= 4096 ? big : rest).push_back(t);
+            if (big.empty()) break;
+            std::vector<std::vector<Task>> out(big.size());
+            if (big.size() < 4) {
+                wide_threads = threads < kMaxThreads ? threads : kMaxThreads;
+                for (size_t i = 0; i < big.size(); i++) node(big[i], [&](Task c) { out[i].push_back(c); });
+            } else {
+                wide_threads = 1;
+                std::atomic<size_t> next{0};
+                std::vector<std::thread> pool;
+                for (unsigned w = 0; w < threads && w < big.size(); w++)
+                    pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < big.size();) node(big[i], [&, i](Task c) { out[i].push_back(c); }); });
+                for (auto &th : pool) th.join();
+            }
+            open = rest;
+            for (const auto &v : out) open.insert(open.end(), v.begin(), v.end());
         }
         wide_threads = 1;
         if (threads <= 1 || open.size() < 2) { for (const Task &t : open) subtree(t); return; }
