@@ -6,6 +6,9 @@
 #include "art_internal.h"
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -212,19 +215,25 @@ struct Builder {
 hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s) {
     if (T < 3) return hipSuccess; // one node at most: nothing to choose
     const uint32_t NI = T - 1;
+    const bool log = std::getenv("ART_BUILD_LOG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now();
     std::vector<float> llo((size_t)T * 3), lhi((size_t)T * 3);
     HIPS(hipStreamSynchronize(s));
     HIPS(hipMemcpy(llo.data(), l.leaf_lo, (size_t)T * 12, hipMemcpyDeviceToHost));
     HIPS(hipMemcpy(lhi.data(), l.leaf_hi, (size_t)T * 12, hipMemcpyDeviceToHost));
+    auto t1 = now();
     Builder B; B.llo = llo.data(); B.lhi = lhi.data();
     unsigned hw = std::thread::hardware_concurrency();
     B.build(T, T < 20000 ? 1u : std::min(hw ? hw : 1u, 16u));
+    auto t2 = now();
     std::vector<DevNode> nodes(NI);
     auto box = [&](int32_t ref, const float *&lo, const float *&hi) {
         if (ref < 0) { lo = llo.data() + 3 * (size_t)(~ref); hi = lhi.data() + 3 * (size_t)(~ref); }
         else { lo = B.nlo.data() + 3 * (size_t)ref; hi = B.nhi.data() + 3 * (size_t)ref; }
     };
-    for (uint32_t n = 0; n < NI; n++) { // the layout k_emit_nodes writes
+    auto emit = [&](uint32_t n0, uint32_t n1) { for (uint32_t n = n0; n < n1; n++) { // the layout k_emit_nodes writes
         int32_t c0 = B.child[2 * (size_t)n], c1 = B.child[2 * (size_t)n + 1];
         const float *l0, *h0, *l1, *h1; box(c0, l0, h0); box(c1, l1, h1);
         DevNode &d = nodes[n];
@@ -233,7 +242,14 @@ hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s) {
         d.q[2] = make_float4(l1[2], h1[0], h1[1], h1[2]);
         int32_t cc[2] = {c0, c1}; float cf[2]; std::memcpy(cf, cc, 8);
         d.q[3] = make_float4(cf[0], cf[1], 0.f, 0.f);
+    } };
+    {
+        unsigned nt = NI >= 65536 ? std::min(hw ? hw : 1u, 16u) : 1u;
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < nt; w++) pool.emplace_back(emit, (uint32_t)((uint64_t)NI * w / nt), (uint32_t)((uint64_t)NI * (w + 1) / nt));
+        for (auto &th : pool) th.join();
     }
+    auto t3 = now();
     HIPS(hipMemcpy(l.nodes, nodes.data(), (size_t)NI * sizeof(DevNode), hipMemcpyHostToDevice));
     if (!l.trav_child) {
         HIPS(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPS(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPS(hipMalloc(&l.trav_hi, (size_t)NI * 12));
@@ -241,6 +257,7 @@ hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s) {
     HIPS(hipMemcpy(l.trav_child, B.child.data(), (size_t)NI * 8, hipMemcpyHostToDevice));
     HIPS(hipMemcpy(l.trav_lo, B.nlo.data(), (size_t)NI * 12, hipMemcpyHostToDevice));
     HIPS(hipMemcpy(l.trav_hi, B.nhi.data(), (size_t)NI * 12, hipMemcpyHostToDevice));
+    if (log) std::fprintf(stderr, "[art] sah_build %u leaves: wait + read-back %.1f ms, build %.1f, node records %.1f, upload %.1f\n", T, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
     return hipSuccess;
 }
 
