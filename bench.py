@@ -342,10 +342,10 @@ def main():
         achieved = per_launch / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         iso_ms = iso["primary_ms" if fused else f"{dom}_ms"]
         traffic, traffic_src = None, None   # PMC counters cannot be read from inside this process: the committed separate-pass measurement of this exact workload
-        tf = os.path.join(ROOT, "profiles", "r1m_pmc_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r1p_pmc_traffic.json")
         if fused and world == 1 and tag == "c2_sponza_like_1080p_1light" and os.path.exists(tf):
             tj = json.load(open(tf))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r1m_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH_SIZE + WRITE_SIZE)"
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r1p_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH_SIZE + WRITE_SIZE)"
         roof = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=per_launch, kernel_ms=dur_ms, frames_timed=n_timed, frames_in_flight=F,
                     kernel_ms_alone=iso_ms, frac_alone=(per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else None,

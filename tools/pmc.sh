@@ -23,7 +23,7 @@ for d in sorted(glob.glob("$OUT/p*/")):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
             if "art::" not in k: continue
-            k = k.split("(")[0][-28:]
+            k = k.split("(")[0][-44:]
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in agg.items():
             print(k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=%d" % len(next(iter(cs.values()))))
