@@ -87,7 +87,7 @@ struct WavePlan {
     std::vector<uint8_t> level;        // per 8x8 block: 0 = one wave, 1 = four quadrant waves, 2 = sixteen cell waves
     std::vector<uint2> items[2];       // host copies of the two device tables
     DevBuf<uint2> d_items[2]; uint32_t n_items[2] = {0, 0}; int cur = 0;
-    uint64_t last_use[2] = {0, 0};     // 1 + the last frame launched with table i (0: never)
+    hipEvent_t retire[2][kMaxFrames] = {}; bool retire_set[2] = {false, false}; // recorded on every frame stream when table i was left: it may be rewritten once they have all fired
     uint32_t cap = 0;                  // items the cost buffers hold
     uint32_t *h_cost = nullptr; size_t h_cost_n = 0; // pinned
     hipEvent_t cost_ready = nullptr; bool pending = false; int pending_table = 0;
@@ -97,6 +97,7 @@ struct WavePlan {
         d_items[0].release(); d_items[1].release();
         if (h_cost) (void)hipHostFree(h_cost); h_cost = nullptr; h_cost_n = 0;
         if (cost_ready) (void)hipEventDestroy(cost_ready); cost_ready = nullptr;
+        for (int i = 0; i < 2; i++) for (uint32_t k = 0; k < kMaxFrames; k++) if (retire[i][k]) { (void)hipEventDestroy(retire[i][k]); retire[i][k] = nullptr; }
     }
 };
 
@@ -242,7 +243,7 @@ static int32_t plan_reset(ArtContext *c) {
     P.cap = n64 + n64 / 2 + 64;       // at most half as many waves again
     plan_build_items(P, {}, P.items[0]);
     P.items[1].clear();
-    for (int i = 0; i < 2; i++) { HIPC(P.d_items[i].ensure(P.cap)); P.n_items[i] = 0; P.last_use[i] = 0; }
+    for (int i = 0; i < 2; i++) { HIPC(P.d_items[i].ensure(P.cap)); P.n_items[i] = 0; P.retire_set[i] = false; }
     if (!P.items[0].empty()) HIPC(hipMemcpy(P.d_items[0].p, P.items[0].data(), P.items[0].size() * sizeof(uint2), hipMemcpyHostToDevice));
     P.n_items[0] = (uint32_t)P.items[0].size(); P.cur = 0;
     if (P.h_cost_n < P.cap) { if (P.h_cost) (void)hipHostFree(P.h_cost); P.h_cost = nullptr; HIPC(hipHostMalloc((void **)&P.h_cost, (size_t)P.cap * 4, hipHostMallocDefault)); P.h_cost_n = P.cap; }
@@ -282,18 +283,28 @@ static int32_t plan_poll(ArtContext *c) {
         next = P.level; // does not fit: a more tolerant target
     }
     const bool changed = next != P.level;
+    static const int verbose = std::getenv("ART_SPLIT_LOG") ? std::atoi(std::getenv("ART_SPLIT_LOG")) : 0;
+    if (verbose > 1) {
+        size_t d = 0; uint32_t mx = 0;
+        for (size_t b = 0; b < next.size(); b++) { d += next[b] != P.level[b]; mx = std::max(mx, worst[b]); }
+        std::fprintf(stderr, "[art] plan poll at frame %llu: table %d sampled, %zu blocks would change, slowest wave %u steps, target %u, interval %u\n", (unsigned long long)c->frame_no, P.pending_table, d, mx, T, P.interval);
+    }
     if (changed) {
         const int other = P.cur ^ 1;
-        if (P.last_use[other]) { // frames launched with that table must have finished
-            const uint64_t f = P.last_use[other] - 1;
-            const bool done = c->frame_no - f <= (uint64_t)ArtContext::kRing ? hipEventQuery(c->ev[f % ArtContext::kRing][4]) == hipSuccess
-                                                                              : hipStreamQuery(c->stream_of((uint32_t)(f % c->F))) == hipSuccess;
-            if (!done) { P.next_sample = c->frame_no; return ART_OK; } // ask again with a fresh sample
+        if (P.retire_set[other]) { // every launch that used that table must have finished: the events recorded on all frame streams when it was left
+            bool done = true;
+            for (uint32_t k = 0; k < c->F && done; k++) done = hipEventQuery(P.retire[other][k]) == hipSuccess;
+            if (!done) { if (verbose > 1) std::fprintf(stderr, "[art] plan poll: the other table is still in use\n"); P.next_sample = c->frame_no + 2 * c->F; return ART_OK; } // ask again later, with a fresh sample
         }
         P.level = next;
         plan_build_items(P, est, P.items[other]);
         HIPC(hipMemcpy(P.d_items[other].p, P.items[other].data(), P.items[other].size() * sizeof(uint2), hipMemcpyHostToDevice));
         P.n_items[other] = (uint32_t)P.items[other].size();
+        for (uint32_t k = 0; k < c->F; k++) { // the table being left: in use until every frame stream has passed this point
+            if (!P.retire[P.cur][k]) HIPC(hipEventCreateWithFlags(&P.retire[P.cur][k], hipEventDisableTiming));
+            HIPC(hipEventRecord(P.retire[P.cur][k], c->stream_of(k)));
+        }
+        P.retire_set[P.cur] = true;
         P.cur = other; P.replans++;
         static const bool log = std::getenv("ART_SPLIT_LOG") != nullptr;
         if (log) {
@@ -816,7 +827,6 @@ int32_t art_trace(ArtContext *c) {
         HIPC(hipEventRecord(ev[4], s));
         S.done_alias = ev[4];           // also the frame's completion event (a record is a packet in the frame's queue: 1/8 share 33 -> 29 us)
         HIPC(hipGetLastError());
-        P.last_use[P.cur] = c->frame_no + 1;
         if (counted) { // now and then a frame counts its waves' packet steps and they go to the host
             HIPC(hipMemcpyAsync(P.h_cost, S.d_wave_cost.p, (size_t)a.n_wave_items * 4, hipMemcpyDeviceToHost, s));
             HIPC(hipEventRecord(P.cost_ready, s));
