@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libart.so")
 ART_OK, ART_E_INVALID, ART_E_STATE, ART_E_NO_DEVICE, ART_E_HIP, ART_E_NOMEM = 0, -1, -2, -3, -4, -5
 ART_FLAG_KEEP_DEBUG = 1
 ART_FLAG_PACKED_TILES = 4  # sharded: the gather payload is the B10G11R11 colour (4 B per pixel)
-ART_FLAG_DEVICE_TREE = 8  # the PREFER_FAST_TRACE tree by PLOC on the device instead of the host's binned SAH
+ART_FLAG_DEVICE_TREE = 8  # the PREFER_FAST_TRACE tree by PLOC instead of the binned SAH (both built on the device)
 ART_FLAG_FIXED_WAVES = 16  # one wave per 8x8 block always (default: the adaptive wave plan of the fused frame)
 ART_FLAG_FAST_BUILD = 2  # keep the LBVH topology in the traversal nodes (default: binned-SAH rebuild, PREFER_FAST_TRACE)
 

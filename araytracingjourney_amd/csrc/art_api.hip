@@ -112,7 +112,7 @@ struct ArtContext {
     bool built = false, have_camera = false, frame_ready = false;
     int frame_waves = 8;      // ART_FRAME_WAVES: occupancy target of the fused frame kernel's instance (6 | 7 | 8)
     bool fused = true;        // packet frames run as ONE launch (k_frame); ART_FUSED=0: the four staged launches
-    int tree_builder = 1;     // with fast_trace: 1 = binned SAH on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip); ART_SAH=<n>
+    int tree_builder = 3;     // with fast_trace: 3 = binned SAH on the device (art_sahdev.hip), 1 = the same on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip); ART_SAH=<n>
     bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD / ART_SAH=0: keep the Karras tree)
     bool packet_wide = false; // ART_PACKET_WIDE=1: packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
@@ -489,7 +489,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     if (const char *pw = std::getenv("ART_PACKET_WIDE")) c->packet_wide = std::atoi(pw) != 0;
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
     if (cfg->flags & ART_FLAG_DEVICE_TREE) c->tree_builder = 2;
-    if (const char *sh = std::getenv("ART_SAH")) { c->fast_trace = std::atoi(sh) != 0; if (std::atoi(sh) == 2) c->tree_builder = 2; else if (std::atoi(sh) == 1) c->tree_builder = 1; }
+    if (const char *sh = std::getenv("ART_SAH")) { c->fast_trace = std::atoi(sh) != 0; if (std::atoi(sh) == 2) c->tree_builder = 2; else if (std::atoi(sh) == 3) c->tree_builder = 3; else if (std::atoi(sh) == 1) c->tree_builder = 1; }
     if (const char *fu = std::getenv("ART_FUSED")) c->fused = std::atoi(fu) != 0;
     if (const char *fw = std::getenv("ART_FRAME_WAVES")) c->frame_waves = std::atoi(fw);
     if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
@@ -629,6 +629,11 @@ int32_t art_scene_build(ArtContext *c) {
             e = ploc_build(c->bvh, T, c->main_stream(), &depth);
             if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "ploc_build"); }
             done = depth <= 80;
+        }
+        if (!done && c->tree_builder == 3) { // the binned SAH on the device
+            e = sah_build_device(c->bvh, T, c->main_stream());
+            if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "sah_build_device"); }
+            done = true;
         }
         if (!done) {
             e = sah_build(c->bvh, T, c->main_stream());

@@ -501,6 +501,11 @@ __global__ __launch_bounds__(256) void k_ploc_permute(uint32_t NI, const uint32_
     for (int k = 0; k < 3; k++) { lo2[3 * (size_t)at + k] = lo[3 * (size_t)n + k]; hi2[3 * (size_t)at + k] = hi[3 * (size_t)n + k]; }
 }
 
+void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s) { // traversal records from l.trav_child / trav_lo / trav_hi
+    const uint32_t NI = T - 1;
+    k_emit_nodes<<<(NI + 255) / 256, 256, 0, s>>>(T, l.trav_child, l.trav_lo, l.trav_hi, l.leaf_lo, l.leaf_hi, l.nodes);
+}
+
 // returns hipSuccess with *depth_out = the tree's depth (the caller falls back to another builder when it exceeds the walks' stacks)
 hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out) {
     *depth_out = 0;

@@ -92,6 +92,9 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s);
 hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s);
 // the same purpose on the device: parallel locally-ordered clustering over the Morton-ordered leaves; *depth_out = depth of the tree
 hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out);
+// the binned SAH of sah_build, level by level on the device (art_sahdev.hip)
+hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s);
+void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s);
 void lbvh_free(Lbvh &l);
 
 // float32 -> unsigned small float (5 exponent bits, MB mantissa bits), round to nearest even; negatives -> 0, overflow -> +Inf

@@ -1,0 +1,233 @@
+// The PREFER_FAST_TRACE traversal tree built on the device: the same binned surface-area heuristic as art_sah.hip (32 bins on each of the
+// three axes, binned by box centroid, pre-order node numbering: the left subtree follows its parent, the right one starts nl nodes on),
+// level by level over ALL open ranges at once.  Every node box is an exact min/max union of leaf boxes (unions go through an
+// order-preserving float <-> uint key, so the atomics are integer min / max), hence frames cannot depend on which builder ran.
+//
+// One level = a handful of launches over the T leaf positions:
+//   k_centroid_bounds   per position -> atomic min/max into its range's centroid box
+//   k_bin               per position -> its bin on each axis: leaf box + count (21 atomics; the top levels contend on 672 words, ~0.4 ms each)
+//   k_choose            per range    -> node box, best (axis, bin) by SAH or the median past the depth guard; opens the child ranges
+//   k_flags + scan + k_scatter       -> stable partition of every range at once (one exclusive scan over T flags)
+//   k_leaf_refs         per range    -> child references of one-leaf sides (known only after the partition)
+// and one 4-byte read-back (how many ranges the next level has).
+#include "art_internal.h"
+#include <rocprim/rocprim.hpp>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace art {
+namespace {
+
+#define HIPQ(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+constexpr int kBins = 32;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kSahDepth = 48; // past it ranges are halved: the tree stays within kSahDepth + log2(T) levels (the walks' stacks)
+constexpr uint32_t kBlockB = 256;
+
+struct Range { uint32_t b, e, k, depth; };               // leaves idx[b, e) -> internal node k
+struct Split { uint32_t axis, bin, nl, left, right; };   // axis 3: by position (median); left / right: the child ranges' ids in the next level, or kNone
+
+__device__ __forceinline__ uint32_t fkey(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+__device__ __forceinline__ float centroid(const float *lo, const float *hi, uint32_t leaf, int a) { return 0.5f * lo[3 * (size_t)leaf + a] + 0.5f * hi[3 * (size_t)leaf + a]; }
+__device__ __forceinline__ int bin_of(float c, float c0, float sc) { int b = (int)((c - c0) * sc); return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b); }
+
+// cb: [range][6] keys (lo xyz initialised to ~0, hi xyz to 0); bins: [range][axis][bin][7] = lo xyz keys, hi xyz keys, count
+__global__ void k_init_level(uint32_t n_ranges, uint32_t *cb, uint32_t *bins) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)n_ranges * 6) cb[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    if (i < (size_t)n_ranges * 3 * kBins * 7) { uint32_t w = (uint32_t)(i % 7); bins[i] = w < 3 ? 0xFFFFFFFFu : 0u; }
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m)); return v; }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) { for (int m = 32; m > 0; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m)); return v; }
+// Near the root thousands of leaves share a range: a wave (centroid bounds) or a block (bins, in LDS) whose leaves all belong to ONE range
+// reduces first and sends one atomic per word -- 262 k leaves on the root's six words took 3.3 ms of serialised atomics otherwise.
+__global__ __launch_bounds__(kBlockB) void k_centroid_bounds(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi, uint32_t *cb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = i < T ? range_of[i] : kNone;
+    const bool valid = r != kNone;
+    uint32_t klo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, khi[3] = {0u, 0u, 0u};
+    if (valid) { uint32_t leaf = idx[i]; for (int a = 0; a < 3; a++) klo[a] = khi[a] = fkey(centroid(lo, hi, leaf, a)); }
+    const uint32_t rmin = wave_min(valid ? r : 0xFFFFFFFFu), rmax = wave_max(valid ? r : 0u);
+    if (rmin == 0xFFFFFFFFu) return;                      // no leaf of an open range in this wave
+    if (rmin == rmax) {                                   // one range: reduce, lane 0 sends
+        for (int a = 0; a < 3; a++) { klo[a] = wave_min(klo[a]); khi[a] = wave_max(khi[a]); }
+        if ((threadIdx.x & 63u) == 0) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)rmin * 6 + a], klo[a]); atomicMax(&cb[(size_t)rmin * 6 + 3 + a], khi[a]); }
+        return;
+    }
+    if (valid) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)r * 6 + a], klo[a]); atomicMax(&cb[(size_t)r * 6 + 3 + a], khi[a]); }
+}
+__global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
+                                                 const uint32_t *__restrict__ cb, uint32_t *bins) {
+    __shared__ uint32_t s_lo, s_hi, s_bins[3 * kBins * 7];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t r = i < T ? range_of[i] : kNone;
+    const bool valid = r != kNone;
+    if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
+    for (uint32_t w = threadIdx.x; w < 3 * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    if (valid) { atomicMin(&s_lo, r); atomicMax(&s_hi, r); }
+    __syncthreads();
+    if (s_lo == 0xFFFFFFFFu) return;                      // nothing open in this block
+    const bool one = s_lo == s_hi;                        // the whole block bins into ONE range: histogram in LDS, then one global atomic per touched word
+    uint32_t *base = one ? s_bins : bins + (size_t)r * 3 * kBins * 7;
+    if (valid) {
+        uint32_t leaf = idx[i];
+        uint32_t kl[3], kh[3];
+        for (int a = 0; a < 3; a++) { kl[a] = fkey(lo[3 * (size_t)leaf + a]); kh[a] = fkey(hi[3 * (size_t)leaf + a]); }
+        for (int a = 0; a < 3; a++) {
+            float c0 = fkey_inv(cb[(size_t)r * 6 + a]), c1 = fkey_inv(cb[(size_t)r * 6 + 3 + a]), ext = c1 - c0;
+            int b = ext > 0.0f ? bin_of(centroid(lo, hi, leaf, a), c0, (float)kBins / ext) : 0; // a flat axis: everything in bin 0, never chosen
+            uint32_t *w = base + ((size_t)a * kBins + b) * 7;
+            for (int k = 0; k < 3; k++) { atomicMin(&w[k], kl[k]); atomicMax(&w[3 + k], kh[k]); }
+            atomicAdd(&w[6], 1u);
+        }
+    }
+    if (!one) return;
+    __syncthreads();
+    uint32_t *g = bins + (size_t)s_lo * 3 * kBins * 7;
+    for (uint32_t w = threadIdx.x; w < 3 * kBins * 7; w += kBlockB) {
+        const uint32_t k = w % 7, v = s_bins[w];
+        if (s_bins[w - k + 6] == 0) continue;             // empty bin
+        if (k < 3) atomicMin(&g[w], v); else if (k < 6) atomicMax(&g[w], v); else atomicAdd(&g[w], v);
+    }
+}
+struct Box { float lo[3], hi[3]; };
+__device__ __forceinline__ void box_empty(Box &b) { for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; } }
+__device__ __forceinline__ void box_grow(Box &b, const uint32_t *w) { for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], fkey_inv(w[k])); b.hi[k] = fmaxf(b.hi[k], fkey_inv(w[3 + k])); } }
+__device__ __forceinline__ double half_area(const Box &b) { double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2]; return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
+
+__global__ void k_choose(uint32_t n_ranges, const Range *__restrict__ ranges, const uint32_t *__restrict__ cb, const uint32_t *__restrict__ bins, Split *splits, Range *next, uint32_t *n_next,
+                         int32_t *child, float *nlo, float *nhi) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranges) return;
+    const Range R = ranges[r];
+    const uint32_t n = R.e - R.b;
+    Box node; box_empty(node);
+    for (int i = 0; i < kBins; i++) { const uint32_t *w = bins + (((size_t)r * 3 + 0) * kBins + i) * 7; if (w[6]) box_grow(node, w); }
+    for (int k = 0; k < 3; k++) { nlo[3 * (size_t)R.k + k] = node.lo[k]; nhi[3 * (size_t)R.k + k] = node.hi[k]; }
+    int best_axis = -1, best_bin = 0; uint32_t best_left = 0; double best_cost = INFINITY;
+    if (n > 2 && R.depth < kSahDepth) {
+        for (int a = 0; a < 3; a++) {
+            if (!(fkey_inv(cb[(size_t)r * 6 + 3 + a]) > fkey_inv(cb[(size_t)r * 6 + a]))) continue;
+            const uint32_t *wa = bins + ((size_t)r * 3 + a) * kBins * 7;
+            double right_area[kBins]; uint32_t right_cnt[kBins];
+            Box acc; box_empty(acc); uint32_t c = 0;
+            for (int i = kBins - 1; i > 0; i--) { if (wa[i * 7 + 6]) box_grow(acc, wa + i * 7); c += wa[i * 7 + 6]; right_area[i] = half_area(acc); right_cnt[i] = c; }
+            box_empty(acc); c = 0;
+            for (int i = 0; i < kBins - 1; i++) {
+                if (wa[i * 7 + 6]) box_grow(acc, wa + i * 7);
+                c += wa[i * 7 + 6];
+                if (c == 0 || right_cnt[i + 1] == 0) continue;
+                double cost = half_area(acc) * c + right_area[i + 1] * right_cnt[i + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = i; best_left = c; }
+            }
+        }
+    }
+    Split S;
+    if (best_axis < 0) { S.axis = 3; S.bin = 0; S.nl = n / 2; }       // two leaves, coincident centroids, or past the depth guard
+    else { S.axis = (uint32_t)best_axis; S.bin = (uint32_t)best_bin; S.nl = best_left; }
+    const uint32_t nl = S.nl, nr = n - nl;
+    S.left = kNone; S.right = kNone;
+    if (nl > 1) { S.left = atomicAdd(n_next, 1u); next[S.left] = Range{R.b, R.b + nl, R.k + 1, R.depth + 1}; child[2 * (size_t)R.k] = (int32_t)(R.k + 1); }
+    if (nr > 1) { S.right = atomicAdd(n_next, 1u); next[S.right] = Range{R.b + nl, R.e, R.k + nl, R.depth + 1}; child[2 * (size_t)R.k + 1] = (int32_t)(R.k + nl); }
+    splits[r] = S;
+}
+__global__ __launch_bounds__(kBlockB) void k_flags(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
+                                                   const Range *__restrict__ ranges, const Split *__restrict__ splits, const uint32_t *__restrict__ cb, uint32_t *flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    uint32_t r = range_of[i], f = 0;
+    if (r != kNone) {
+        const Split S = splits[r];
+        if (S.axis == 3) f = (i - ranges[r].b) < S.nl;
+        else {
+            float c0 = fkey_inv(cb[(size_t)r * 6 + S.axis]), c1 = fkey_inv(cb[(size_t)r * 6 + 3 + S.axis]);
+            f = bin_of(centroid(lo, hi, idx[i], (int)S.axis), c0, (float)kBins / (c1 - c0)) <= (int)S.bin;
+        }
+    }
+    flags[i] = f;
+}
+__global__ __launch_bounds__(kBlockB) void k_scatter(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const Range *__restrict__ ranges, const Split *__restrict__ splits,
+                                                     const uint32_t *__restrict__ flags, const uint32_t *__restrict__ scan, uint32_t *idx2, uint32_t *range_of2) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    uint32_t r = range_of[i];
+    if (r == kNone) { idx2[i] = idx[i]; range_of2[i] = kNone; return; }
+    const Range R = ranges[r]; const Split S = splits[r];
+    uint32_t left_before = scan[i] - scan[R.b];                        // left-going leaves of this range in front of i
+    uint32_t dst = flags[i] ? R.b + left_before : R.b + S.nl + ((i - R.b) - left_before);
+    idx2[dst] = idx[i];
+    range_of2[dst] = flags[i] ? S.left : S.right;
+}
+__global__ void k_leaf_refs(uint32_t n_ranges, const Range *__restrict__ ranges, const Split *__restrict__ splits, const uint32_t *__restrict__ idx2, int32_t *child) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranges) return;
+    const Range R = ranges[r]; const Split S = splits[r];
+    if (S.nl == 1) child[2 * (size_t)R.k] = ~(int32_t)idx2[R.b];
+    if (R.e - R.b - S.nl == 1) child[2 * (size_t)R.k + 1] = ~(int32_t)idx2[R.b + S.nl];
+}
+__global__ void k_iota(uint32_t T, uint32_t *idx, uint32_t *range_of) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < T) { idx[i] = i; range_of[i] = 0; } }
+
+} // namespace
+
+hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
+    if (T < 3) return hipSuccess;
+    const uint32_t NI = T - 1, max_ranges = T / 2 + 1;
+    uint32_t *idx[2] = {nullptr, nullptr}, *range_of[2] = {nullptr, nullptr}, *cb = nullptr, *bins = nullptr, *flags = nullptr, *scan = nullptr, *n_next = nullptr;
+    Range *ranges[2] = {nullptr, nullptr}; Split *splits = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
+    const bool log = std::getenv("ART_BUILD_LOG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now(); auto t1 = t0, t2 = t0; uint32_t levels = 0, widest = 0;
+    auto body = [&]() -> hipError_t {
+        for (int k = 0; k < 2; k++) { HIPQ(hipMalloc(&idx[k], (size_t)T * 4)); HIPQ(hipMalloc(&range_of[k], (size_t)T * 4)); HIPQ(hipMalloc(&ranges[k], (size_t)max_ranges * sizeof(Range))); }
+        HIPQ(hipMalloc(&cb, (size_t)max_ranges * 6 * 4)); HIPQ(hipMalloc(&bins, (size_t)max_ranges * 3 * kBins * 7 * 4)); HIPQ(hipMalloc(&splits, (size_t)max_ranges * sizeof(Split)));
+        HIPQ(hipMalloc(&flags, (size_t)T * 4)); HIPQ(hipMalloc(&scan, (size_t)T * 4)); HIPQ(hipMalloc(&n_next, 4));
+        if (!l.trav_child) { HIPQ(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPQ(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&l.trav_hi, (size_t)NI * 12)); }
+        HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
+        HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+        HIPQ(hipStreamSynchronize(s)); t1 = now();
+        const uint32_t gT = (T + kBlockB - 1) / kBlockB;
+        k_iota<<<gT, kBlockB, 0, s>>>(T, idx[0], range_of[0]);
+        Range root{0, T, 0, 0};
+        HIPQ(hipMemcpyAsync(ranges[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
+        uint32_t n = 1; int cur = 0;
+        for (uint32_t level = 0; n > 0 && level < 4096; level++) {
+            const size_t words = (size_t)n * 3 * kBins * 7;
+            k_init_level<<<(uint32_t)((words + kBlockB - 1) / kBlockB), kBlockB, 0, s>>>(n, cb, bins);
+            HIPQ(hipMemsetAsync(n_next, 0, 4, s));
+            k_centroid_bounds<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb);
+            k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb, bins);
+            k_choose<<<(n + 63) / 64, 64, 0, s>>>(n, ranges[cur], cb, bins, splits, ranges[cur ^ 1], n_next, l.trav_child, l.trav_lo, l.trav_hi);
+            k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, cb, flags);
+            size_t tb = tmp_bytes;
+            HIPQ(rocprim::exclusive_scan(tmp, tb, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
+            k_scatter<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], ranges[cur], splits, flags, scan, idx[cur ^ 1], range_of[cur ^ 1]);
+            k_leaf_refs<<<(n + 255) / 256, 256, 0, s>>>(n, ranges[cur], splits, idx[cur ^ 1], l.trav_child);
+            uint32_t nn = 0;
+            HIPQ(hipMemcpyAsync(&nn, n_next, 4, hipMemcpyDeviceToHost, s));
+            HIPQ(hipStreamSynchronize(s));
+            if (nn > max_ranges) return hipErrorUnknown;
+            n = nn; cur ^= 1; levels++; widest = n > widest ? n : widest;
+        }
+        t2 = now();
+        if (n != 0) return hipErrorUnknown;
+        HIPQ(hipGetLastError());
+        launch_emit_nodes(l, T, s);
+        HIPQ(hipGetLastError());
+        HIPQ(hipStreamSynchronize(s));
+        return hipSuccess;
+    };
+    hipError_t err = body();
+    auto t3 = now();
+    for (int k = 0; k < 2; k++) { hipFree(idx[k]); hipFree(range_of[k]); hipFree(ranges[k]); }
+    hipFree(cb); hipFree(bins); hipFree(splits); hipFree(flags); hipFree(scan); hipFree(n_next); hipFree(tmp);
+    if (log) std::fprintf(stderr, "[art] sah_build_device %u leaves: wait + allocations %.1f ms, %u levels (at most %u open ranges) %.1f, node records %.1f, frees %.1f\n", T, ms(t0, t1), levels, widest, ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    return err;
+}
+
+} // namespace art

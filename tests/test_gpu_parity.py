@@ -395,7 +395,7 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
     for name, got in (("staged packets", frame(4, env={"ART_FUSED": "0"})), ("per-ray", frame(1, env={"ART_BVH": "24"})), ("fused, one frame in flight", frame(1)),
                       ("fused on the LBVH topology", frame(4, fast_build=True)), ("fused on the device-built (PLOC) tree", frame(4, device_tree=True)),
                       ("per-ray on the PLOC tree", frame(1, device_tree=True, env={"ART_BVH": "24"})), ("per-ray on the LBVH topology", frame(1, fast_build=True, env={"ART_BVH": "24"})),
-                      ("fused, 7 waves/SIMD", frame(4, env={"ART_FRAME_WAVES": "7"})), ("fused, no block reordering", frame(4, env={"ART_MACRO": "0"}))):
+                      ("fused on the host-built SAH tree", frame(4, env={"ART_SAH": "1"})), ("fused, 7 waves/SIMD", frame(4, env={"ART_FRAME_WAVES": "7"})), ("fused, no block reordering", frame(4, env={"ART_MACRO": "0"}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
         assert got[3]["shadow_rays"] == ref[3]["shadow_rays"] and got[3]["hit_pixels"] == ref[3]["hit_pixels"], name
@@ -525,12 +525,15 @@ def test_residency_only_device_models_are_traced(R, get_scene):
     both.close(); only.close()
 
 
-@pytest.mark.parametrize("device_tree", [False, True])
+@pytest.mark.parametrize("builder", ["sah-device", "sah-host", "ploc-device"])
 @pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12), ("sponza_like", 1.0)])
-def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail, device_tree):
+def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, monkeypatch, name, detail, builder):
     """what makes the SAH rebuild invisible: every leaf of the canonical LBVH hangs in the traversal tree exactly once,
     every node box is the exact min/max union of its children's boxes, the root is node 0, the depth stays inside the walks' stacks"""
-    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=device_tree)   # binned SAH on the host / PLOC on the device
+    if builder == "sah-host":
+        monkeypatch.setenv("ART_SAH", "1")
+    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=builder == "ploc-device")   # binned SAH on the device (default) / on the host threads / PLOC
+    monkeypatch.delenv("ART_SAH", raising=False)
     lb, tr = r.get_lbvh(), r.get_traversal_tree()
     T = lb["leaf_gid"].size
     child = tr["child"]
