@@ -42,23 +42,26 @@ __global__ void k_init_level(uint32_t n_ranges, uint32_t *cb, uint32_t *bins) {
     if (i < (size_t)n_ranges * 3 * kBins * 7) { uint32_t w = (uint32_t)(i % 7); bins[i] = w < 3 ? 0xFFFFFFFFu : 0u; }
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m)); return v; }
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) { for (int m = 32; m > 0; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m)); return v; }
-// Near the root thousands of leaves share a range: a wave (centroid bounds) or a block (bins, in LDS) whose leaves all belong to ONE range
-// reduces first and sends one atomic per word -- 262 k leaves on the root's six words took 3.3 ms of serialised atomics otherwise.
+// Near the root thousands of leaves share a range: the centroid bounds are reduced per wave (segmented), the bins per block in LDS when the block has ONE range
+// -- 262 k leaves on the root's six words took 3.3 ms of serialised atomics otherwise.
 __global__ __launch_bounds__(kBlockB) void k_centroid_bounds(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi, uint32_t *cb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t r = i < T ? range_of[i] : kNone;
     const bool valid = r != kNone;
     uint32_t klo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, khi[3] = {0u, 0u, 0u};
     if (valid) { uint32_t leaf = idx[i]; for (int a = 0; a < 3; a++) klo[a] = khi[a] = fkey(centroid(lo, hi, leaf, a)); }
-    const uint32_t rmin = wave_min(valid ? r : 0xFFFFFFFFu), rmax = wave_max(valid ? r : 0u);
-    if (rmin == 0xFFFFFFFFu) return;                      // no leaf of an open range in this wave
-    if (rmin == rmax) {                                   // one range: reduce, lane 0 sends
-        for (int a = 0; a < 3; a++) { klo[a] = wave_min(klo[a]); khi[a] = wave_max(khi[a]); }
-        if ((threadIdx.x & 63u) == 0) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)rmin * 6 + a], klo[a]); atomicMax(&cb[(size_t)rmin * 6 + 3 + a], khi[a]); }
-        return;
+    if (wave_min(valid ? r : 0xFFFFFFFFu) == 0xFFFFFFFFu) return; // no leaf of an open range in this wave
+    // A range is an interval of positions, so the lanes of one range are neighbours: a segmented scan over the wave leaves each range's
+    // bounds in its last lane, and only that lane sends atomics (up to 64 times fewer; all of them near the root).
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t ro = (uint32_t)__shfl_up((int)r, off);
+        uint32_t ol[3], oh[3];
+        for (int a = 0; a < 3; a++) { ol[a] = (uint32_t)__shfl_up((int)klo[a], off); oh[a] = (uint32_t)__shfl_up((int)khi[a], off); }
+        if (lane >= (uint32_t)off && ro == r) for (int a = 0; a < 3; a++) { klo[a] = min(klo[a], ol[a]); khi[a] = max(khi[a], oh[a]); }
     }
-    if (valid) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)r * 6 + a], klo[a]); atomicMax(&cb[(size_t)r * 6 + 3 + a], khi[a]); }
+    const uint32_t rn = (uint32_t)__shfl_down((int)r, 1);
+    if (valid && (lane == 63u || rn != r)) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)r * 6 + a], klo[a]); atomicMax(&cb[(size_t)r * 6 + 3 + a], khi[a]); }
 }
 __global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
                                                  const uint32_t *__restrict__ cb, uint32_t *bins) {
