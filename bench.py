@@ -250,6 +250,21 @@ def main():
             spans.append(r.collect_timings()[0]["frame_ms"])
         spans.sort()
         alone = dict(median_ms=spans[50], p10_ms=spans[10], p90_ms=spans[90], frames=100)
+        if not args.ao and F > 1:
+            # the same frame in a context that keeps ONE frame in flight: there the wave plan splits the blocks whose packets crawl (with 16 in
+            # flight nothing needs splitting), which is what a caller that wants a frame's latency rather than frames per second would use
+            one = renderer.renderer_for_scene(sc, (W, H), device=local_rank, frames_in_flight=1)
+            one.upload_state()
+            for _ in range(24):               # the plan settles within a few frames
+                one.trace(); one.sync()
+            one.collect_timings()
+            spans = []
+            for _ in range(60):
+                one.trace(); one.sync()
+                spans.append(one.collect_timings()[0]["frame_ms"])
+            spans.sort()
+            alone["single_frame_context"] = dict(median_ms=spans[30], p10_ms=spans[6], p90_ms=spans[54], frames=60, split_blocks=one.stats()["split_blocks"])
+            one.close()
 
     st = r.stats()
     if not renders:                   # the compositor traced nothing
