@@ -20,12 +20,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Several frames are kept in flight (the reference keeps 3: renderer.rs:135); each ring slot's stream needs a hardware queue of
 # its own to overlap with the others, and the runtime's default is 4.  Must be set before the HIP runtime starts.
-# A share of a sharded frame is bound by its slowest 8x8 block (a launch lasts as long as that wave) and gains from more launches in
-# flight: 20 slots (1/8 share: 42 -> 36 us per frame) on 22 hardware queues, so that the exchange stream and RCCL's get queues of their
-# own.  With 24 queues in use the command processor falls off a cliff (3x slower: profiles/README.md r1k), and 22 is never exceeded
-# whatever else creates streams.  The whole frame on one GPU is the same at 16 and 20 slots.
-_SHARDED = int(os.environ.get("WORLD_SIZE", "1")) > 1
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "22" if _SHARDED else "16")
+# N > 1: 12 launches of 4 frames each in flight on 16 hardware queues -- the exchange stream and RCCL's streams get queues of their own, and
+# the command processor's cliff at 24 queues in use (3x slower: profiles/README.md r1k) stays far away.  (Before the wave plan and the
+# 4-frame launches a share needed 20 slots on 22 queues to hide its slowest block; now 12 / 16 measure the same as 20 / 22: r1o.)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 
@@ -52,7 +50,7 @@ def main():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-frames", type=int, default=20, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
+    ap.add_argument("--gather-frames", type=int, default=12, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
     ap.add_argument("--compositor", default="auto", choices=["auto", "dedicated", "shared"],
                     help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
                          "1/(N-1) each; auto = shared: with the exchange submitted by the host (no device-side waits) a root that also traces a 1/8 share "
@@ -92,7 +90,7 @@ def main():
         sc = scenes.sponza_like(args.detail)
         lights = scenes.sponza_lights(args.lights)
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (20 if world > 1 else 16)
+    F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (12 if world > 1 else 16)
     packed = world > 1 and args.gather == "packed"
     dedicated = world > 1 and args.compositor == "dedicated"
     G = world - 1 if dedicated else world           # shards of the frame = ranks that trace
