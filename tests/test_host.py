@@ -203,6 +203,20 @@ def test_three_rank_dedicated_compositor_over_gloo(tmp_path):
     assert r.returncode == 0 and "GLOO_OK" in r.stdout and "COMPOSITOR_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_bench_and_tools_parse_and_bench_refuses_to_run_without_a_gpu():
+    """bench.py: its argument parser loads, and without a GPU it stops with a message instead of falling back to anything; tools compile"""
+    import glob, py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--frames-per-launch" in out.stdout and "--root-relief" in out.stdout
+    for f in glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "__graft_entry__.py")]:
+        py_compile.compile(f, doraise=True)
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "no CPU fallback" in (out.stderr + out.stdout)
+
+
 def test_model_residency_state_machine():
     """vk_model.rs:334-345 with the camera positions of the reference's own test (vk_model.rs:1082-1152): a model goes
     Storage / Host / Device by the distance between the camera and its bounding sphere (<= 10: Device, <= 20: Host)"""
