@@ -14,6 +14,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -35,9 +37,17 @@ struct JV {
     size_t size() const { return t == Arr ? a.size() : 0; }
 };
 struct JP {
-    const char *p, *e; bool ok = true;
+    const char *p, *e; bool ok = true; int depth = 0;
+    static constexpr int kMaxDepth = 64; // glTF documents nest a handful of levels; a crafted file must not recurse the stack away
     void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
     JV val() {
+        JV v;
+        if (++depth > kMaxDepth) ok = false;
+        if (ok) v = val_body();
+        depth--;
+        return v;
+    }
+    JV val_body() {
         JV v; ws();
         if (p >= e) { ok = false; return v; }
         if (*p == '{') {
@@ -66,7 +76,7 @@ struct JP {
                 if (*p == '\\' && p + 1 < e) {
                     p++;
                     switch (*p) { case 'n': v.s += '\n'; break; case 't': v.s += '\t'; break; case 'r': v.s += '\r'; break; case 'b': v.s += '\b'; break; case 'f': v.s += '\f'; break;
-                                  case 'u': v.s += '?'; p += 4; break; default: v.s += *p; }
+                                  case 'u': if (e - p < 5) { ok = false; return v; } v.s += '?'; p += 4; break; default: v.s += *p; }
                     p++;
                 } else v.s += *p++;
             }
@@ -83,6 +93,7 @@ struct JP {
 enum ImgFormat { F_R8 = 0, F_R8G8, F_R8G8B8, F_R8G8B8A8, F_B8G8R8, F_B8G8R8A8, F_R16, F_R16G16, F_R16G16B16, F_R16G16B16A16 }; // gltf::image::Format
 struct Image { std::vector<uint8_t> pixels; int format = F_R8; uint32_t width = 0, height = 0; };
 
+constexpr uint32_t kMaxImageEdge = 16384;
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 bool decode_png(const uint8_t *d, size_t n, Image &out, std::string &err) {
@@ -102,6 +113,7 @@ bool decode_png(const uint8_t *d, size_t n, Image &out, std::string &err) {
         p += 12 + (size_t)len;
     }
     if (!w || !h) { err = "PNG without IHDR"; return false; }
+    if (w > kMaxImageEdge || h > kMaxImageEdge || (size_t)w * h > ((size_t)1 << 26)) { err = "PNG extent beyond 16384 / 64 Mpixel"; return false; }
     if (interlace) { err = "interlaced PNG not supported"; return false; }
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch || (depth != 8 && depth != 16 && !(ctype == 3 && (depth == 1 || depth == 2 || depth == 4)) && !(ctype == 0 && (depth == 1 || depth == 2 || depth == 4)))) { err = "unsupported PNG colour type / bit depth"; return false; }
@@ -177,27 +189,69 @@ int32_t gfail(int32_t code, const std::string &m) { g_glb_err = m; return code; 
 int type_components(const std::string &t) { return t == "SCALAR" ? 1 : t == "VEC2" ? 2 : t == "VEC3" ? 3 : t == "VEC4" ? 4 : t == "MAT2" ? 4 : t == "MAT3" ? 9 : t == "MAT4" ? 16 : 0; }
 int component_bytes(int ct) { return ct == 5120 || ct == 5121 ? 1 : ct == 5122 || ct == 5123 ? 2 : ct == 5125 || ct == 5126 ? 4 : 0; }
 
-bool accessor_attr(const JV &doc, int acc_idx, Attr &out, std::string &err) { // get_mesh_attribute_from_accessor, :403-412
+// a JSON number that is a non-negative integer a double holds exactly (anything else -- negative, fractional, NaN, 1e300 -- is refused
+// before it is cast: the cast of such a double is undefined behaviour, and a wrapped offset passes every later check)
+bool json_u64(const JV *v, uint64_t &out) {
+    if (!v || v->t != JV::Num || !(v->n >= 0.0) || !(v->n <= 9007199254740992.0) || v->n != std::floor(v->n)) return false;
+    out = (uint64_t)v->n;
+    return true;
+}
+// obj[key] as an index into a table of `limit` entries; false when absent, not an integer or out of range
+bool json_index(const JV &obj, const char *key, size_t limit, size_t &out) {
+    uint64_t v = 0;
+    if (!json_u64(obj.get(key), v) || v >= limit) return false;
+    out = (size_t)v;
+    return true;
+}
+// optional non-negative integer member with a default
+bool json_opt_u64(const JV &obj, const char *key, uint64_t dflt, uint64_t &out) {
+    if (!obj.has(key)) { out = dflt; return true; }
+    return json_u64(obj.get(key), out);
+}
+
+// get_mesh_attribute_from_accessor, :403-412.  The window [start, start + (count - 1) * stride + elem_size) is checked against the
+// binary chunk here, in 64-bit arithmetic that cannot wrap, so that every later reader (normalize_vectors, copy_model_data,
+// bounding_sphere) may index it freely.  The reference indexes Rust slices and panics on such files; this returns an error.
+bool accessor_attr(const JV &doc, size_t acc_idx, uint64_t buffer_size, Attr &out, std::string &err) {
     const JV *accs = doc.get("accessors"), *views = doc.get("bufferViews");
-    if (!accs || acc_idx < 0 || (size_t)acc_idx >= accs->size()) { err = "accessor index out of range"; return false; }
+    if (!accs || acc_idx >= accs->size()) { err = "accessor index out of range"; return false; }
     const JV &a = accs->a[acc_idx];
-    int vi = (int)a.num("bufferView", -1);
-    if (!views || vi < 0 || (size_t)vi >= views->size()) { err = "accessor without a buffer view"; return false; }
+    size_t vi = 0;
+    if (!views || !json_index(a, "bufferView", views->size(), vi)) { err = "accessor without a buffer view"; return false; }
     const JV &v = views->a[vi];
     const JV *ty = a.get("type");
-    int size = type_components(ty && ty->t == JV::Str ? ty->s : "") * component_bytes((int)a.num("componentType", 0));
+    uint64_t ct = 0;
+    if (!json_u64(a.get("componentType"), ct) || ct > 65535) { err = "unsupported accessor type"; return false; }
+    const uint64_t size = (uint64_t)type_components(ty && ty->t == JV::Str ? ty->s : "") * (uint64_t)component_bytes((int)ct);
     if (!size) { err = "unsupported accessor type"; return false; }
-    uint64_t stride = v.has("byteStride") ? (uint64_t)v.num("byteStride", 0) : (uint64_t)size;
-    out.start = (uint64_t)a.num("byteOffset", 0) + (uint64_t)v.num("byteOffset", 0);
-    out.len = (uint64_t)a.num("count", 0) * stride;
+    uint64_t stride = 0, a_off = 0, v_off = 0, count = 0;
+    if (!json_opt_u64(v, "byteStride", size, stride) || !json_opt_u64(a, "byteOffset", 0, a_off) || !json_opt_u64(v, "byteOffset", 0, v_off) || !json_u64(a.get("count"), count)) {
+        err = "accessor: byteStride / byteOffset / count must be non-negative integers"; return false;
+    }
+    if (stride < size || stride > 65536) { err = "accessor: byteStride smaller than the element (or absurdly large)"; return false; }
+    if (count == 0) { err = "accessor: count is zero"; return false; }
+    const uint64_t start = a_off + v_off; // both <= 2^53
+    if (start > buffer_size || size > buffer_size - start || count - 1 > (buffer_size - start - size) / stride) { err = "accessor window out of range"; return false; }
+    out.start = start; out.len = count * stride; // count <= buffer_size: no overflow
     out.elem_size = (uint32_t)size; out.stride = (uint32_t)stride;
     return true;
 }
+
+// the element sizes validate_model (:643-681) insists on
+uint32_t attr_want_size(int type) { return type == A_VERTICES ? 12 : type == A_TEX_COORDS ? 8 : type == A_NORMALS ? 12 : type == A_TANGENTS ? 16 : 0; }
 
 // generate_src_to_dst_map (:529-540) on channel-position arrays: map[src byte] = dst byte or -1
 void src_to_dst_map(const int src_pos[4], const int dst_pos[4], int map[4]) { // index: r g b a; value: byte position or -1
     for (int i = 0; i < 4; i++) map[i] = -1;
     for (int c = 0; c < 4; c++) if (src_pos[c] >= 0 && dst_pos[c] >= 0) map[src_pos[c]] = dst_pos[c];
+}
+
+// nothing unwinds across the C ABI: a file that asks for more memory than there is (huge image extents, vertex counts) is an error code
+template <class F> int32_t glb_guard(const char *who, F f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return gfail(ART_E_NOMEM, std::string(who) + ": out of memory"); }
+    catch (const std::exception &e) { return gfail(ART_E_INVALID, std::string(who) + ": " + e.what()); }
+    catch (...) { return gfail(ART_E_INVALID, std::string(who) + ": unexpected failure"); }
 }
 
 } // namespace
@@ -218,9 +272,7 @@ int32_t art_glb_permute_pixels(const uint8_t *src, size_t src_len, uint32_t src_
     return ART_OK;
 }
 
-int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce_format, ArtGlb **out) {
-    if (!path || !out) return gfail(ART_E_INVALID, "art_glb_open: null argument");
-    *out = nullptr;
+static int32_t glb_open_impl(const char *path, int32_t normalize_vectors, int32_t coerce_format, ArtGlb **out) {
     FILE *f = std::fopen(path, "rb");
     if (!f) return gfail(ART_E_INVALID, std::string("Could not read file ") + path);
     std::vector<uint8_t> file;
@@ -248,14 +300,16 @@ int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce
         const JV *views = doc.get("bufferViews");
         for (const JV &im : imgs->a) {
             Image I; std::string err;
-            int vi = (int)im.num("bufferView", -1);
-            if (!views || vi < 0 || (size_t)vi >= views->size()) return gfail(ART_E_INVALID, "image without a buffer view (external URIs are not read)");
-            uint64_t o = (uint64_t)views->a[vi].num("byteOffset", 0), l = (uint64_t)views->a[vi].num("byteLength", 0);
-            if (o + l > g->buffer.size()) return gfail(ART_E_INVALID, "image buffer view out of range");
+            size_t vi = 0;
+            if (!views || !json_index(im, "bufferView", views->size(), vi)) return gfail(ART_E_INVALID, "image without a buffer view (external URIs are not read)");
+            uint64_t o = 0, l = 0;
+            if (!json_opt_u64(views->a[vi], "byteOffset", 0, o) || !json_u64(views->a[vi].get("byteLength"), l)) return gfail(ART_E_INVALID, "image buffer view: byteOffset / byteLength must be non-negative integers");
+            if (o > g->buffer.size() || l > g->buffer.size() - o) return gfail(ART_E_INVALID, "image buffer view out of range");
             const uint8_t *img = g->buffer.data() + o;
             if (l >= 2 && img[0] == 0xFF && img[1] == 0xD8) { // JPEG: RGB8 or R8, like the image crate's decode of it
                 int ch = 0;
                 if (!decode_jpeg(img, (size_t)l, I.pixels, I.width, I.height, ch, err)) return gfail(ART_E_INVALID, "image decode: " + err);
+                if (!I.width || !I.height || I.pixels.size() != (size_t)I.width * I.height * (size_t)ch) return gfail(ART_E_INVALID, "image decode: JPEG extent and pixel data disagree");
                 I.format = ch == 1 ? F_R8 : F_R8G8B8;
             } else if (!decode_png(img, (size_t)l, I, err)) return gfail(ART_E_INVALID, "image decode: " + err);
             g->images.push_back(std::move(I));
@@ -266,23 +320,28 @@ int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce
     for (size_t pi = 0; prims && pi < prims->size(); pi++) {
         const JV &pd = prims->a[pi];
         Prim P; std::string err;
-        if (pd.has("indices")) { Attr a; if (!accessor_attr(doc, (int)pd.num("indices", -1), a, err)) return gfail(ART_E_INVALID, err); P.attrs[A_INDICES] = a; }
+        const uint64_t bsz = g->buffer.size();
+        uint64_t ai = 0;
+        if (pd.has("indices")) { Attr a; if (!json_u64(pd.get("indices"), ai) || !accessor_attr(doc, (size_t)ai, bsz, a, err)) return gfail(ART_E_INVALID, err.empty() ? "accessor index out of range" : err); P.attrs[A_INDICES] = a; }
         if (const JV *at = pd.get("attributes"))
             for (auto &kv : at->o) {
                 int ty = kv.first == "POSITION" ? A_VERTICES : kv.first == "NORMAL" ? A_NORMALS : kv.first == "TANGENT" ? A_TANGENTS : kv.first == "TEXCOORD_0" ? A_TEX_COORDS : 0;
                 if (!ty) continue;
-                Attr a; if (!accessor_attr(doc, (int)kv.second.n, a, err)) return gfail(ART_E_INVALID, err);
+                Attr a; if (!json_u64(&kv.second, ai) || !accessor_attr(doc, (size_t)ai, bsz, a, err)) return gfail(ART_E_INVALID, err.empty() ? "accessor index out of range" : err);
+                // validate_model's element sizes (:643-681), checked HERE: normalize_vectors below reads and writes 12 bytes per POSITION element
+                if (a.elem_size != attr_want_size(ty)) return gfail(ART_E_INVALID, "validate_model: attribute element size");
                 P.attrs[ty] = a;
             }
-        int mi = (int)pd.num("material", -1);
-        if (materials && mi >= 0 && (size_t)mi < materials->size()) {
+        size_t mi = 0;
+        if (materials && json_index(pd, "material", materials->size(), mi)) {
             const JV &m = materials->a[mi];
             const JV *pbr = m.get("pbrMetallicRoughness");
             auto tex_image = [&](const JV *info) -> int {
                 if (!info) return -1;
-                int ti = (int)info->num("index", -1);
-                if (!textures || ti < 0 || (size_t)ti >= textures->size()) return -1;
-                return (int)textures->a[ti].num("source", -1);
+                size_t ti = 0, src = 0;
+                if (!textures || !json_index(*info, "index", textures->size(), ti)) return -1;
+                if (!json_index(textures->a[ti], "source", g->images.size(), src)) return -1;
+                return (int)src;
             };
             const std::pair<int, const JV *> slots[4] = {{T_ALBEDO, pbr ? pbr->get("baseColorTexture") : nullptr}, {T_ORM, pbr ? pbr->get("metallicRoughnessTexture") : nullptr},
                                                           {T_NORMAL, m.get("normalTexture")}, {T_EMISSIVE, m.get("emissiveTexture")}};
@@ -293,7 +352,6 @@ int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce
                     P.textures[sl.first] = ii;
                 }
         }
-        for (auto &kv : P.attrs) if (kv.second.start + kv.second.len > g->buffer.size() + (kv.second.stride - kv.second.elem_size)) return gfail(ART_E_INVALID, "accessor window out of range");
         g->prims.push_back(std::move(P));
     }
     // normalize_vectors (:415-460): positions of every primitive divided by the largest magnitude, if that exceeds 1
@@ -335,7 +393,7 @@ int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce
     for (auto &P : g->prims) {
         long common = -1;
         for (auto &kv : P.attrs) {
-            uint32_t want = kv.first == A_VERTICES ? 12 : kv.first == A_TEX_COORDS ? 8 : kv.first == A_NORMALS ? 12 : kv.first == A_TANGENTS ? 16 : 0;
+            uint32_t want = attr_want_size(kv.first);
             if (!want) continue;
             if (kv.second.elem_size != want) return gfail(ART_E_INVALID, "validate_model: attribute element size");
             if (common < 0) common = (long)kv.second.count(); else if (common != (long)kv.second.count()) return gfail(ART_E_INVALID, "validate_model: attribute element counts differ");
@@ -348,12 +406,18 @@ int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce
     return ART_OK;
 }
 
+int32_t art_glb_open(const char *path, int32_t normalize_vectors, int32_t coerce_format, ArtGlb **out) {
+    if (!path || !out) return gfail(ART_E_INVALID, "art_glb_open: null argument");
+    *out = nullptr;
+    return glb_guard("art_glb_open", [&] { return glb_open_impl(path, normalize_vectors, coerce_format, out); });
+}
+
 int32_t art_glb_close(ArtGlb *g) { delete g; return ART_OK; }
 
 int32_t art_glb_primitive_count(ArtGlb *g, uint32_t *n) { if (!g || !n) return gfail(ART_E_INVALID, "art_glb_primitive_count: null argument"); *n = (uint32_t)g->prims.size(); return ART_OK; }
 
 // copy_model_data_to_ptr (:156-281).  dst == NULL: sizing pass.  infos: one ArtGlbCopyInfo per primitive (may be NULL).
-int32_t art_glb_copy_model_data(ArtGlb *g, uint32_t attr_mask, uint32_t tex_mask, void *dst, size_t cap, ArtGlbCopyInfo *infos, uint32_t n_infos, size_t *total) {
+static int32_t glb_copy_impl(ArtGlb *g, uint32_t attr_mask, uint32_t tex_mask, void *dst, size_t cap, ArtGlbCopyInfo *infos, uint32_t n_infos, size_t *total) {
     if (!g) return gfail(ART_E_INVALID, "art_glb_copy_model_data: null reader");
     if (infos && n_infos < g->prims.size()) return gfail(ART_E_INVALID, "art_glb_copy_model_data: infos too short");
     std::vector<int> mesh_flags, tex_flags;
@@ -391,8 +455,13 @@ int32_t art_glb_copy_model_data(ArtGlb *g, uint32_t attr_mask, uint32_t tex_mask
             if (ft == P.textures.end()) return gfail(ART_E_INVALID, "Texture type " + std::to_string(tex_flags[0]) + " not found in model");
             const Image &I0 = g->images[ft->second];
             ci.image_width = I0.width; ci.image_height = I0.height;
+            if (!I0.width || !I0.height) return gfail(ART_E_INVALID, "art_glb_copy_model_data: empty image");
             size_t comp = I0.pixels.size() / ((size_t)I0.width * I0.height);
-            written = comp * (size_t)std::ceil((float)written / (float)comp); // align_offset (model_reader.rs:144-146), float arithmetic included
+            if (!comp) return gfail(ART_E_INVALID, "art_glb_copy_model_data: image without pixel data");
+            // align_offset (model_reader.rs:144-146) computes comp * ceil(written as f32 / comp as f32): exact below 2^24 bytes, but past 64 MB the
+            // f32 cast rounds and the offset can move BACKWARDS into the index data just written (the reference has that latent bug; here the
+            // library is its own consumer).  Integer arithmetic: the same value wherever the f32 form is exact.
+            written = (written + comp - 1) / comp * comp;
             ci.image_buffer_offset = written; ci.image_mip_levels = 1; ci.image_layers = (uint32_t)tex_flags.size(); ci.image_format = (uint32_t)I0.format;
             for (int tf : tex_flags) {
                 auto it = P.textures.find(tf);
@@ -407,6 +476,10 @@ int32_t art_glb_copy_model_data(ArtGlb *g, uint32_t attr_mask, uint32_t tex_mask
     }
     if (total) *total = written;
     return ART_OK;
+}
+
+int32_t art_glb_copy_model_data(ArtGlb *g, uint32_t attr_mask, uint32_t tex_mask, void *dst, size_t cap, ArtGlbCopyInfo *infos, uint32_t n_infos, size_t *total) {
+    return glb_guard("art_glb_copy_model_data", [&] { return glb_copy_impl(g, attr_mask, tex_mask, dst, cap, infos, n_infos, total); });
 }
 
 // get_primitives_bounding_sphere (:283-399): Ritter's two-pass sphere, the reference's arithmetic order
@@ -447,7 +520,7 @@ int32_t art_glb_bounding_sphere(ArtGlb *g, float center[3], float *radius) {
 
 // add_model (renderer.rs:346 -> vk_model.rs:494-528, :508: all four vertex attributes + INDICES, textures ALBEDO|ORM|NORMAL):
 // hands every primitive to art_scene_add_primitive in the layout copy_model_data_to_ptr produces
-int32_t art_scene_add_glb(ArtContext *ctx, ArtGlb *g, const float model3x4[12], uint32_t *first_primitive_id, uint32_t *n_primitives) {
+static int32_t glb_add_impl(ArtContext *ctx, ArtGlb *g, const float model3x4[12], uint32_t *first_primitive_id, uint32_t *n_primitives) {
     if (!ctx || !g || !model3x4) return gfail(ART_E_INVALID, "art_scene_add_glb: null argument");
     const uint32_t am = A_VERTICES | A_TEX_COORDS | A_NORMALS | A_TANGENTS | A_INDICES, tm = T_ALBEDO | T_ORM | T_NORMAL;
     size_t total = 0;
@@ -472,6 +545,9 @@ int32_t art_scene_add_glb(ArtContext *ctx, ArtGlb *g, const float model3x4[12], 
     }
     if (n_primitives) *n_primitives = (uint32_t)infos.size();
     return ART_OK;
+}
+int32_t art_scene_add_glb(ArtContext *ctx, ArtGlb *g, const float model3x4[12], uint32_t *first_primitive_id, uint32_t *n_primitives) {
+    return glb_guard("art_scene_add_glb", [&] { return glb_add_impl(ctx, g, model3x4, first_primitive_id, n_primitives); });
 }
 
 } // extern "C"

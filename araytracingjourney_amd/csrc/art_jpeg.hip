@@ -4,8 +4,14 @@
 // Chroma is upsampled with the triangle filter of libjpeg ("fancy upsampling", also what the crate's decoder does for h2v1 / h2v2) and
 // converted with the JFIF matrix; the inverse DCT is the separable float one, so values can differ from another decoder's by an LSB or two.
 // Host code only.
-#include "art_internal.h"
+// (no HIP headers: this file and art_glb.hip also build with g++ under AddressSanitizer, tests/test_glb.py)
 #include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace art { bool decode_jpeg(const uint8_t *data, size_t n, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, int &channels, std::string &err); } // also declared in art_internal.h
 
 namespace art {
 namespace {
@@ -196,6 +202,7 @@ bool decode_jpeg(const uint8_t *d, size_t n, std::vector<uint8_t> &pixels, uint3
             D.progressive = m == 0xC2;
             D.H = (s[1] << 8) | s[2]; D.W = (s[3] << 8) | s[4]; int nc = s[5];
             if ((nc != 1 && nc != 3) || sl < (size_t)(6 + 3 * nc) || D.W == 0 || D.H == 0) { err = "JPEG with an unsupported component count"; return false; }
+            if (D.W > 16384 || D.H > 16384 || (size_t)D.W * (size_t)D.H > ((size_t)1 << 26)) { err = "JPEG extent beyond 16384 / 64 Mpixel"; return false; } // a 100-byte header must not ask for gigabytes of coefficients
             D.comps.resize((size_t)nc);
             for (int k = 0; k < nc; k++) { Comp &c = D.comps[k]; c.id = s[6 + 3 * k]; c.h = s[7 + 3 * k] >> 4; c.v = s[7 + 3 * k] & 15; c.tq = s[8 + 3 * k];
                 if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) { err = "JPEG sampling factors beyond 2x2"; return false; } }

@@ -198,3 +198,172 @@ def _accessor(doc, bin_, i):
     for k in range(a["count"]):
         out[k] = np.frombuffer(bin_, np.float32, n, off + k * stride)
     return out
+
+
+# ---- malformed files: the reference indexes Rust slices and panics; a C++ reader must answer with an error code, never touch
+# memory outside the file.  Every case runs twice: through libart.so (the product build) and through a g++ AddressSanitizer +
+# UBSan build of the same sources (tests/glb_asan_driver.cpp), where an out-of-bounds byte is a report and a non-zero exit.
+def _glb_bytes(doc, bin_):
+    js = (json.dumps(doc) if not isinstance(doc, (bytes, str)) else doc)
+    js = js.encode() if isinstance(js, str) else js
+    js += b" " * (-len(js) % 4)
+    bin_ = bytes(bin_) + b"\0" * (-len(bin_) % 4)
+    return struct.pack("<III", 0x46546C67, 2, 28 + len(js) + len(bin_)) + struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(bin_), 0x004E4942) + bin_
+
+
+def _tri_doc(**over):
+    """one triangle: POSITION vec3 f32 x 3 at 0, indices u16 x 3 at 36; `over` patches accessor / view fields"""
+    doc = {"asset": {"version": "2.0"}, "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}], "buffers": [{"byteLength": 44}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 6}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}]}
+    for path, v in over.items():
+        tab, i, key = path.split("__")
+        if v is None:
+            doc[tab][int(i)].pop(key, None)
+        else:
+            doc[tab][int(i)][key] = v
+    return doc
+
+
+_TRI_BIN = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0], np.float32).tobytes() + np.array([0, 1, 2], np.uint16).tobytes()
+
+
+def _png_header_only(w, h):
+    import zlib
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+
+
+def _jpeg_header_only(w, h):
+    sof = struct.pack(">BBHBHHB", 0xFF, 0xC0, 17, 8, h, w, 3) + bytes([1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])
+    return b"\xFF\xD8" + sof + b"\xFF\xDA" + struct.pack(">H", 12) + bytes([3, 1, 0, 2, 0x11, 3, 0x11, 0, 63, 0]) + b"\0" * 16 + b"\xFF\xD9"
+
+
+def _image_doc(payload):
+    doc = _tri_doc()
+    doc["bufferViews"].append({"buffer": 0, "byteOffset": 44, "byteLength": len(payload)})
+    doc["images"] = [{"bufferView": 2, "mimeType": "image/png"}]
+    doc["textures"] = [{"source": 0}]
+    doc["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+    doc["meshes"][0]["primitives"][0]["material"] = 0
+    return doc, _TRI_BIN + b"\0\0" + payload
+
+
+MALFORMED = {
+    # ADVICE r1 (a): byteStride 4 < the 12-byte element: (stride - elem_size) used to wrap to 0xFFFFFFF8 and wave any offset through
+    "stride_smaller_than_element": (_tri_doc(bufferViews__0__byteStride=4, accessors__0__byteOffset=1 << 20), _TRI_BIN, "byteStride"),
+    # ADVICE r1 (b): a SCALAR/u8 POSITION accessor: normalize_vectors used to copy 12 bytes per element before validate_model had looked
+    "scalar_u8_position": (_tri_doc(accessors__0__type="SCALAR", accessors__0__componentType=5121, accessors__0__count=44), _TRI_BIN, "element size"),
+    "window_past_the_end": (_tri_doc(accessors__0__count=4), _TRI_BIN, "out of range"),
+    "offset_past_the_end": (_tri_doc(accessors__0__byteOffset=40), _TRI_BIN, "out of range"),
+    "huge_offset_wraps": (_tri_doc(accessors__0__byteOffset=2 ** 53, bufferViews__0__byteOffset=2 ** 53), _TRI_BIN, "out of range"),
+    "offset_beyond_double_integers": (_tri_doc(accessors__0__byteOffset=1e300), _TRI_BIN, "non-negative integers"),
+    "negative_offset": (_tri_doc(bufferViews__0__byteOffset=-8), _TRI_BIN, "non-negative integers"),
+    "negative_count": (_tri_doc(accessors__0__count=-3), _TRI_BIN, "non-negative integers"),
+    "fractional_count": (_tri_doc(accessors__0__count=2.5), _TRI_BIN, "non-negative integers"),
+    "zero_count": (_tri_doc(accessors__0__count=0), _TRI_BIN, "count is zero"),
+    "count_times_stride_wraps": (_tri_doc(accessors__0__count=2 ** 52, bufferViews__0__byteStride=65536), _TRI_BIN, "out of range"),
+    "index_window_past_the_end": (_tri_doc(accessors__1__count=5), _TRI_BIN, "out of range"),
+    "accessor_index_negative": ({**_tri_doc(), "meshes": [{"primitives": [{"attributes": {"POSITION": -1}, "indices": 1}]}]}, _TRI_BIN, "accessor index"),
+    "accessor_index_huge": ({**_tri_doc(), "meshes": [{"primitives": [{"attributes": {"POSITION": 7}, "indices": 1}]}]}, _TRI_BIN, "accessor index"),
+    "buffer_view_index_out_of_range": (_tri_doc(accessors__0__bufferView=9), _TRI_BIN, "buffer view"),
+    "no_component_type": (_tri_doc(accessors__0__componentType=None), _TRI_BIN, "accessor type"),
+    "deeply_nested_json": ('{"asset":' + "[" * 100000 + "]" * 100000 + "}", _TRI_BIN, "does not parse"),
+    "unterminated_unicode_escape": ('{"asset":"\\u12', _TRI_BIN, "does not parse"),
+    "image_view_out_of_range": (lambda: (lambda d, b: (dict(d, bufferViews=d["bufferViews"][:2] + [{"buffer": 0, "byteOffset": 40, "byteLength": 1 << 30}]), b))(*_image_doc(b"x")), None, "image buffer view"),
+    "image_view_negative_length": (lambda: (lambda d, b: (dict(d, bufferViews=d["bufferViews"][:2] + [{"buffer": 0, "byteOffset": 44, "byteLength": -1}]), b))(*_image_doc(b"x")), None, "non-negative integers"),
+    "png_of_4_gigapixels": (lambda: _image_doc(_png_header_only(65535, 65535)), None, "extent"),
+    "png_truncated_pixel_data": (lambda: _image_doc(_png_header_only(64, 64)), None, "inflate"),
+    "jpeg_of_4_gigapixels": (lambda: _image_doc(_jpeg_header_only(65535, 65535)), None, "extent"),
+    "jpeg_without_tables": (lambda: _image_doc(_jpeg_header_only(16, 16)), None, "table"),
+    "truncated_chunk": (None, None, "truncated"),
+}
+
+
+def _malformed_file(tmp_path, name):
+    doc, bin_, _ = MALFORMED[name]
+    if name == "truncated_chunk":
+        data = _glb_bytes(_tri_doc(), _TRI_BIN)[:-20]
+    else:
+        if callable(doc):
+            doc, bin_ = doc()
+        data = _glb_bytes(doc, bin_)
+    path = tmp_path / (name + ".glb")
+    path.write_bytes(data)
+    return str(path)
+
+
+@pytest.fixture(scope="module")
+def asan_driver(tmp_path_factory):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path_factory.mktemp("asan") / "glb_asan")
+    src = [os.path.join(root, "araytracingjourney_amd", "csrc", f) for f in ("art_glb.hip", "art_jpeg.hip")] + [os.path.join(root, "tests", "glb_asan_driver.cpp")]
+    subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] + src + ["-lz", "-o", exe])
+    return exe
+
+
+def test_the_well_formed_triangle_reads(tmp_path):
+    """the base document the malformed cases are patches of"""
+    path = tmp_path / "tri.glb"
+    path.write_bytes(_glb_bytes(_tri_doc(), _TRI_BIN))
+    r = mr.GltfModelReader(str(path), True, mr.COERCE_NONE)
+    data, infos = r.copy_model_data_to_ptr(mr.VERTICES | mr.INDICES, 0)
+    assert data[:36].view(np.float32).tolist() == [0, 0, 0, 1, 0, 0, 0, 1, 0] and data[36:42].view(np.uint16).tolist() == [0, 1, 2]
+
+
+@pytest.mark.parametrize("name", sorted(MALFORMED))
+def test_malformed_glb_is_an_error_not_a_memory_fault(tmp_path, asan_driver, name):
+    import subprocess
+    from araytracingjourney_amd._lib import ArtError
+    path = _malformed_file(tmp_path, name)
+    with pytest.raises(ArtError, match=MALFORMED[name][2]):
+        mr.GltfModelReader(path, True, mr.COERCE_B8G8R8A8)
+    out = subprocess.run([asan_driver, path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "rc=-" in out.stdout and "ERROR" not in out.stderr, out.stdout + out.stderr
+
+
+def test_wellformed_assets_are_clean_under_the_sanitizers(tmp_path, asan_driver, get_scene):
+    """the reference's two boxes and a synthetic strided / JPEG / palette file through the sanitizer build: every path, no report"""
+    import subprocess
+    from glb_writer import write_glb
+    sc = get_scene("sponza_like", 0.05)
+    p = sc.primitives[0]
+    from araytracingjourney_amd import scenes
+    small = scenes.Primitive(p.verts, p.indices, p.tex[:, ::8, ::8].copy(), p.model)
+    files = [BOX, BOX_T]
+    for i, (modes, inter) in enumerate(((("RGBA", "RGB", "P"), True), (("JPEG420", "JPEG444P", "JPEG422+R3"), False))):
+        path = tmp_path / f"ok{i}.glb"
+        write_glb(str(path), [small], png_modes=modes, interleaved=inter)
+        files.append(str(path))
+    for f in files:
+        out = subprocess.run([asan_driver, f], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.startswith("rc=0") and "ERROR" not in out.stderr, (f, out.stdout + out.stderr)
+
+
+def test_image_offset_alignment_is_integer_arithmetic():
+    """align_offset (model_reader.rs:144-146) in f32 moves an offset above 2^24 bytes BACKWARDS into the index data; ours is integer.
+    A primitive with 1.4 M vertices puts its texture past 64 MB (sizing pass only: nothing is copied)."""
+    n = 1_400_001                                        # 1 400 001 * 48 = 67 200 048 bytes of vertices: past 2^26
+    doc = {"asset": {"version": "2.0"}, "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1, "NORMAL": 2, "TANGENT": 3}, "indices": 4, "material": 0}]}],
+           "buffers": [{"byteLength": 0}], "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": n * 48, "byteStride": 48}, {"buffer": 0, "byteOffset": n * 48, "byteLength": 18}],
+           "accessors": [{"bufferView": 0, "byteOffset": o, "componentType": 5126, "count": n, "type": t} for o, t in ((0, "VEC3"), (12, "VEC2"), (20, "VEC3"), (32, "VEC4"))]
+                        + [{"bufferView": 1, "componentType": 5123, "count": 9, "type": "SCALAR"}]}
+    import tempfile
+    from PIL import Image
+    buf = io.BytesIO(); Image.fromarray(np.full((2, 2, 4), 200, np.uint8), "RGBA").save(buf, format="PNG"); png = buf.getvalue()
+    bin_ = bytearray(n * 48) + bytearray(np.array([0, 1, 2] * 3, np.uint16).tobytes()) + b"\0\0" + png
+    doc["bufferViews"].append({"buffer": 0, "byteOffset": n * 48 + 20, "byteLength": len(png)})
+    doc["images"] = [{"bufferView": 2}]; doc["textures"] = [{"source": 0}]
+    doc["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 0}}, "normalTexture": {"index": 0}}]
+    with tempfile.NamedTemporaryFile(suffix=".glb") as f:
+        f.write(_glb_bytes(doc, bin_)); f.flush()
+        r = mr.GltfModelReader(f.name, False, mr.COERCE_R8G8B8A8)
+        _, infos = r.copy_model_data_to_ptr(mr.VERTICES | mr.TEX_COORDS | mr.NORMALS | mr.TANGENTS | mr.INDICES, mr.ALBEDO | mr.ORM | mr.NORMAL, copy=False)
+    ci = infos[0]
+    end_of_indices = ci.indices_buffer_offset + ci.indices_size
+    assert end_of_indices == n * 48 + 18 and end_of_indices > 1 << 26
+    assert ci.image_buffer_offset == (end_of_indices + 3) // 4 * 4                       # the next multiple of the 4-byte texel
+    f32 = int(np.float32(4) * np.ceil(np.float32(end_of_indices) / np.float32(4)))       # what the reference's f32 expression gives
+    assert f32 < end_of_indices                                                          # ... which is inside the index data: the latent bug
