@@ -124,7 +124,6 @@ struct ArtContext {
     uint32_t B = 1, read_b = 0;       // frames per launch of the fused frame (art_set_frames_per_launch); which of them the read / device-pointer calls refer to
     ArtCamera cam_more[kMaxBatch - 1] = {}; // cameras of frames 1.. of a launch (frame 0: camera)
     std::vector<ArtLight> lights;
-    DevBuf<ArtLight> d_lights[2]; int lights_cur = 0; // double-buffered: frames in flight may still read the previous records
     // frame
     std::vector<uint32_t> tile_list; uint32_t tiles_x = 0, tiles_y = 0, padded_tiles = 0, n_local = 0;
     DevBuf<uint32_t> d_tile_list;
@@ -482,7 +481,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     }
     for (int f = 0; f < ArtContext::kRing && e == hipSuccess; f++)
         for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&c->ev[f][i]);
-    if (e != hipSuccess) { delete c; return hipfail(e, "art_create"); }
+    if (e != hipSuccess) { (void)art_destroy(c); return hipfail(e, "art_create"); } // releases the streams and events created so far
     c->W = cfg->width; c->H = cfg->height;
     // the fused packet frame is the default at every ring depth (one frame at a time: 0.575 ms against 0.669 ms for the staged per-ray
     // kernels, profiles/README.md r1h); ART_BVH=24 selects the per-ray walks (binary for primary rays, 4-wide for shadow rays)
@@ -502,11 +501,11 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
 int32_t art_destroy(ArtContext *c) {
     if (!c) return ART_OK;
     (void)hipSetDevice(c->device);
-    for (uint32_t k = 0; k < c->F; k++) (void)hipStreamSynchronize(c->stream_of(k));
+    for (uint32_t k = 0; k < c->F; k++) if (c->stream_of(k)) (void)hipStreamSynchronize(c->stream_of(k));
     drop_graphs(c);
     lbvh_free(c->bvh);
     c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release();
-    c->d_lights[0].release(); c->d_lights[1].release(); c->d_tile_list.release(); c->d_tile_xy.release(); c->plan.release();
+    c->d_tile_list.release(); c->d_tile_xy.release(); c->d_tile_slot.release(); c->d_block_order.release(); c->plan.release();
     for (uint32_t k = 0; k < kMaxFrames; k++) {
         c->slot[k].release();
         if (c->slot[k].done) (void)hipEventDestroy(c->slot[k].done);
@@ -717,10 +716,7 @@ int32_t art_set_lights(ArtContext *c, const ArtLight *lights, uint32_t n) {
     c->lights.assign(lights, lights + n);
     c->plan.next_sample = c->frame_no; c->plan.interval = 1; // the shadow walks change: look at the waves again
     if (resized) { r = sync_all(c); if (r) return r; } // the per-frame buffers are resized with the light count
-    drop_graphs(c);
-    c->lights_cur ^= 1; // frames in flight keep reading the previous buffer
-    HIPC(c->d_lights[c->lights_cur].ensure(n));
-    if (n) HIPC(hipMemcpy(c->d_lights[c->lights_cur].p, lights, (size_t)n * sizeof(ArtLight), hipMemcpyHostToDevice));
+    drop_graphs(c); // the records are kernel arguments (FrameArgs::lights): nothing to upload, and frames in flight keep the ones they were launched with
     if (resized) c->frame_ready = false;
     return ART_OK;
 }
@@ -771,7 +767,8 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p; a.fold_counters = c->kind_primary == 8 && c->kind_shadow == 8 && c->n_local != 0;
     a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
-    a.lights = c->d_lights[c->lights_cur].p; a.n_lights = (uint32_t)c->lights.size();
+    a.n_lights = (uint32_t)c->lights.size();
+    if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
     a.color_tiles = c->cfg.shard_count > 1 ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)

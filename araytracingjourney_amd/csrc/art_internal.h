@@ -137,7 +137,9 @@ struct FrameArgs {
     bool packet_wide;          // packet walks use the 128-byte 4-wide nodes (else the binary nodes)
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
     int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised, 1 binary quantised
-    const ArtLight *lights; uint32_t n_lights;
+    // the light records travel BY VALUE with every launch, like the camera block: a frame in flight can never see a later art_set_lights
+    // (a device-side table, however it is double-buffered, is overwritten while launches queued 16 frames ago still hold its address)
+    ArtLight lights[kMaxLights]; uint32_t n_lights;
     float4 *hits;              // [n_local] t,u,v,gid
     float4 *contrib;           // [n_lights][n_local]
     float4 *shadow_rays;       // [2 * n_lights * n_local] dense per (light, pixel): o.xyz,tmax (<=0: none) | d.xyz,-

@@ -36,10 +36,11 @@ __device__ __forceinline__ float centroid(const float *lo, const float *hi, uint
 __device__ __forceinline__ int bin_of(float c, float c0, float sc) { int b = (int)((c - c0) * sc); return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b); }
 
 // cb: [range][6] keys (lo xyz initialised to ~0, hi xyz to 0); bins: [range][axis][bin][7] = lo xyz keys, hi xyz keys, count
-__global__ void k_init_level(uint32_t n_ranges, uint32_t *cb, uint32_t *bins) {
+// n_cb ranges' centroid boxes (0: leave them) and the bins of a window of n_win ranges
+__global__ void k_init_level(uint32_t n_cb, uint32_t n_win, uint32_t *cb, uint32_t *bins) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)n_ranges * 6) cb[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
-    if (i < (size_t)n_ranges * 3 * kBins * 7) { uint32_t w = (uint32_t)(i % 7); bins[i] = w < 3 ? 0xFFFFFFFFu : 0u; }
+    if (i < (size_t)n_cb * 6) cb[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    if (i < (size_t)n_win * 3 * kBins * 7) { uint32_t w = (uint32_t)(i % 7); bins[i] = w < 3 ? 0xFFFFFFFFu : 0u; }
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m)); return v; }
 // Near the root thousands of leaves share a range: the centroid bounds are reduced per wave (segmented), the bins per block in LDS when the block has ONE range
@@ -64,11 +65,12 @@ __global__ __launch_bounds__(kBlockB) void k_centroid_bounds(uint32_t T, const u
     if (valid && (lane == 63u || rn != r)) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)r * 6 + a], klo[a]); atomicMax(&cb[(size_t)r * 6 + 3 + a], khi[a]); }
 }
 __global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
-                                                 const uint32_t *__restrict__ cb, uint32_t *bins) {
+                                                 const uint32_t *__restrict__ cb, uint32_t *bins, uint32_t r0, uint32_t n_win) {
+    // bins holds the ranges [r0, r0 + n_win) of this level (a window: the bins of ALL ranges of a deep level would be 1344 bytes per triangle)
     __shared__ uint32_t s_lo, s_hi, s_bins[3 * kBins * 7];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t r = i < T ? range_of[i] : kNone;
-    const bool valid = r != kNone;
+    const bool valid = r != kNone && r >= r0 && r - r0 < n_win;
     if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
     for (uint32_t w = threadIdx.x; w < 3 * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
     __syncthreads();
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__r
     __syncthreads();
     if (s_lo == 0xFFFFFFFFu) return;                      // nothing open in this block
     const bool one = s_lo == s_hi;                        // the whole block bins into ONE range: histogram in LDS, then one global atomic per touched word
-    uint32_t *base = one ? s_bins : bins + (size_t)r * 3 * kBins * 7;
+    uint32_t *base = one ? s_bins : bins + (size_t)(r - r0) * 3 * kBins * 7;
     if (valid) {
         uint32_t leaf = idx[i];
         uint32_t kl[3], kh[3];
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__r
     }
     if (!one) return;
     __syncthreads();
-    uint32_t *g = bins + (size_t)s_lo * 3 * kBins * 7;
+    uint32_t *g = bins + (size_t)(s_lo - r0) * 3 * kBins * 7;
     for (uint32_t w = threadIdx.x; w < 3 * kBins * 7; w += kBlockB) {
         const uint32_t k = w % 7, v = s_bins[w];
         if (s_bins[w - k + 6] == 0) continue;             // empty bin
@@ -104,9 +106,10 @@ __device__ __forceinline__ void box_grow(Box &b, const uint32_t *w) { for (int k
 __device__ __forceinline__ double half_area(const Box &b) { double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2]; return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
 
 __global__ void k_choose(uint32_t n_ranges, const Range *__restrict__ ranges, const uint32_t *__restrict__ cb, const uint32_t *__restrict__ bins, Split *splits, Range *next, uint32_t *n_next,
-                         int32_t *child, float *nlo, float *nhi) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+                         int32_t *child, float *nlo, float *nhi, uint32_t r0) {
+    uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;   // n_ranges: end of the window [r0, n_ranges) whose bins are in `bins`
     if (r >= n_ranges) return;
+    bins -= (size_t)r0 * 3 * kBins * 7;                        // indexed by r below
     const Range R = ranges[r];
     const uint32_t n = R.e - R.b;
     Box node; box_empty(node);
@@ -180,6 +183,11 @@ __global__ void k_iota(uint32_t T, uint32_t *idx, uint32_t *range_of) { uint32_t
 hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     if (T < 3) return hipSuccess;
     const uint32_t NI = T - 1, max_ranges = T / 2 + 1;
+    // Bins are 3 axes x 32 bins x 7 words = 2688 bytes per open range.  A deep level of a big scene has ~T/4 open ranges (3.8 GB for the
+    // 2.8 M triangles of config 4 if all had bins at once), so a level is binned and split in windows of at most kWindow ranges: 352 MB
+    // whatever T is; config 2 (T/2 = 131 k ranges at most) still takes one pass per level, config 4's deepest levels take up to 11.
+    constexpr uint32_t kWindow = 1u << 17;
+    const uint32_t win_cap = max_ranges < kWindow ? max_ranges : kWindow;
     uint32_t *idx[2] = {nullptr, nullptr}, *range_of[2] = {nullptr, nullptr}, *cb = nullptr, *bins = nullptr, *flags = nullptr, *scan = nullptr, *n_next = nullptr;
     Range *ranges[2] = {nullptr, nullptr}; Split *splits = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
     const bool log = std::getenv("ART_BUILD_LOG") != nullptr;
@@ -188,7 +196,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     auto t0 = now(); auto t1 = t0, t2 = t0; uint32_t levels = 0, widest = 0;
     auto body = [&]() -> hipError_t {
         for (int k = 0; k < 2; k++) { HIPQ(hipMalloc(&idx[k], (size_t)T * 4)); HIPQ(hipMalloc(&range_of[k], (size_t)T * 4)); HIPQ(hipMalloc(&ranges[k], (size_t)max_ranges * sizeof(Range))); }
-        HIPQ(hipMalloc(&cb, (size_t)max_ranges * 6 * 4)); HIPQ(hipMalloc(&bins, (size_t)max_ranges * 3 * kBins * 7 * 4)); HIPQ(hipMalloc(&splits, (size_t)max_ranges * sizeof(Split)));
+        HIPQ(hipMalloc(&cb, (size_t)max_ranges * 6 * 4)); HIPQ(hipMalloc(&bins, (size_t)win_cap * 3 * kBins * 7 * 4)); HIPQ(hipMalloc(&splits, (size_t)max_ranges * sizeof(Split)));
         HIPQ(hipMalloc(&flags, (size_t)T * 4)); HIPQ(hipMalloc(&scan, (size_t)T * 4)); HIPQ(hipMalloc(&n_next, 4));
         if (!l.trav_child) { HIPQ(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPQ(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&l.trav_hi, (size_t)NI * 12)); }
         HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
@@ -200,12 +208,16 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
         HIPQ(hipMemcpyAsync(ranges[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
         uint32_t n = 1; int cur = 0;
         for (uint32_t level = 0; n > 0 && level < 4096; level++) {
-            const size_t words = (size_t)n * 3 * kBins * 7;
-            k_init_level<<<(uint32_t)((words + kBlockB - 1) / kBlockB), kBlockB, 0, s>>>(n, cb, bins);
             HIPQ(hipMemsetAsync(n_next, 0, 4, s));
-            k_centroid_bounds<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb);
-            k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb, bins);
-            k_choose<<<(n + 63) / 64, 64, 0, s>>>(n, ranges[cur], cb, bins, splits, ranges[cur ^ 1], n_next, l.trav_child, l.trav_lo, l.trav_hi);
+            for (uint32_t r0 = 0; r0 < n; r0 += win_cap) {
+                const uint32_t nw = n - r0 < win_cap ? n - r0 : win_cap;
+                const uint32_t n_cb = r0 == 0 ? n : 0u;   // the centroid boxes of the whole level are cleared with its first window
+                const size_t words = std::max((size_t)nw * 3 * kBins * 7, (size_t)n_cb * 6);
+                k_init_level<<<(uint32_t)((words + kBlockB - 1) / kBlockB), kBlockB, 0, s>>>(n_cb, nw, cb, bins);
+                if (r0 == 0) k_centroid_bounds<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb);
+                k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb, bins, r0, nw);
+                k_choose<<<(nw + 63) / 64, 64, 0, s>>>(r0 + nw, ranges[cur], cb, bins, splits, ranges[cur ^ 1], n_next, l.trav_child, l.trav_lo, l.trav_hi, r0);
+            }
             k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, cb, flags);
             size_t tb = tmp_bytes;
             HIPQ(rocprim::exclusive_scan(tmp, tb, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));

@@ -55,3 +55,27 @@ def assert_radiance_close(got, want, rel=1e-4, floor=1e-6, what="radiance"):
     tol = rel * np.abs(want) + floor
     bad = err > tol
     assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values off; worst rel err {float((err / (np.abs(want) + floor)).max()):.3e}"
+
+
+def radiance_margin(got, want, rel=1e-4, floor=1e-6):
+    """how much of the 1e-4 tolerance a frame uses: worst |err| / (rel * |want| + floor) (must stay <= 1), the worst plain relative
+    error over values above 1e-3 (where the floor plays no part), and the mean relative error there"""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    big = np.abs(want) > 1e-3
+    rel_err = err[big] / np.abs(want[big])
+    return dict(worst_tolerance_fraction=float((err / (rel * np.abs(want) + floor)).max()), worst_rel_err=float(rel_err.max()) if rel_err.size else 0.0,
+                mean_rel_err=float(rel_err.mean()) if rel_err.size else 0.0, values_compared=int(err.size), values_off_by_more_than_1e5_rel=int((rel_err > 1e-5).sum()))
+
+
+def record_margin(tag, margin):
+    """measured on the GPU box: kept under gpurun_out/margins/ (merged back by gpurun); the committed copy lives in tests/golden/<tag>.stats.json"""
+    import json
+    d = os.path.join(ROOT, "gpurun_out", "margins")
+    try:
+        os.makedirs(d, exist_ok=True)
+        json.dump(margin, open(os.path.join(d, tag + ".json"), "w"), indent=1)
+    except OSError:
+        pass
+    print(f"\n[margin] {tag}: {json.dumps(margin)}")

@@ -33,3 +33,14 @@ def random_rays(n, seed, radius=2.5):
     inside = (np.arange(n) % 3) == 0
     rays[inside, 0:3] = (tgt[inside] * 0.6).astype(np.float32)
     return rays
+
+
+def device_to_host(ptr, nbytes):
+    """bytes at a raw device pointer (art_device_*) -> numpy uint8; the process's one HIP runtime (loaded by torch / libart)"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.empty(nbytes, np.uint8)
+    rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), nbytes, 2)   # hipMemcpyDeviceToHost
+    assert rc == 0, f"hipMemcpy failed: {rc}"
+    return out

@@ -3,7 +3,7 @@ Bit-exact for geometry (LBVH, t/u/v/primitive/triangle, shadow bits, ray counts)
 import numpy as np
 import pytest
 
-from conftest import assert_radiance_close
+from conftest import assert_radiance_close, radiance_margin, record_margin
 from helpers import oracle_camera, oracle_for, random_rays
 
 pytestmark = pytest.mark.gpu
@@ -77,11 +77,30 @@ def _frame_parity(R, orc, sc, w, h, n_lights, form="fused"):
     assert st["shadow_rays"] == ref["stats"]["shadow_rays"]
     assert st["hit_pixels"] == ref["stats"]["hit_pixels"]
     assert ref["stats"]["nonfinite_pixels"] == 0
-    assert_radiance_close(r.read_color(), ref["color"])
+    color = r.read_color()
+    assert_radiance_close(color, ref["color"])
     assert_radiance_close(r.read_depth(), ref["depth"], what="depth")
     assert_radiance_close(r.read_normal(), ref["normal"], rel=1e-4, floor=1e-5, what="normal")
     r.close()
+    ref["margin"] = radiance_margin(color[..., :3], ref["color"][..., :3])   # how much of the 1e-4 the fast intrinsics (__powf, __fdividef) use
     return ref
+
+
+def _golden_stats(tag):
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", tag + ".stats.json")))
+
+
+def _check_against_golden(tag, ref, keys=("primary_rays", "shadow_rays", "hit_pixels", "n_int_primary", "n_tri_primary", "n_int_shadow", "n_tri_shadow")):
+    """the oracle's counters for this frame are the committed ones (bench.py prices its roofline with them); the GPU frame's margin under
+    the 1e-4 tolerance is recorded, and must not have grown past twice the committed one (same GPU libm: it is deterministic)"""
+    fx = _golden_stats(tag)
+    for k in keys:
+        assert ref["stats"][k] == fx[k], k
+    record_margin(tag, ref["margin"])
+    assert ref["margin"]["worst_tolerance_fraction"] <= 1.0
+    if "gpu_margin" in fx:
+        assert ref["margin"]["worst_rel_err"] <= 2.0 * fx["gpu_margin"]["worst_rel_err"] + 1e-7, (ref["margin"], fx["gpu_margin"])
 
 
 @pytest.mark.parametrize("form", ["fused", "fused-1", "staged", "per-ray"])
@@ -105,9 +124,46 @@ def test_config2_full_size_frame_matches_oracle(R, orc, get_scene):
     import json, os
     _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, "per-ray")
     ref = _frame_parity(R, orc, get_scene("sponza_like", 1.0), 1920, 1080, 1, "fused")   # the fused frame, as bench.py runs it
-    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_sponza_like_1080p_1light.stats.json")))
-    for k in ("primary_rays", "shadow_rays", "hit_pixels", "n_int_primary", "n_tri_primary", "n_int_shadow", "n_tri_shadow"):
-        assert ref["stats"][k] == fx[k], k       # the committed visit counters bench.py prices the roofline with
+    _check_against_golden("c2_sponza_like_1080p_1light", ref)
+
+
+def test_config3_full_size_frame_matches_oracle(R, orc, scenes, get_scene):
+    """BASELINE config 3 at its real size: 262 816 triangles, 3840x2160, point + spot + directional + area light, 17.8 M shadow rays:
+    hit ids / t / u / v / shadow bits / ray counts bit-exact, radiance within 1e-4 (raytrace.rgen.glsl:139-187)"""
+    sc = get_scene("sponza_like", 1.0)
+    sc = scenes.Scene(sc.name, sc.primitives, sc.camera, scenes.sponza_lights(4))
+    ref = _frame_parity(R, orc, sc, 3840, 2160, None, "fused")
+    assert ref["stats"]["shadow_rays"] > 17_000_000
+    _check_against_golden("c3_sponza_like_2160p_4lights", ref)
+
+
+def test_config4_full_size_frame_matches_oracle(R, orc, get_scene):
+    """BASELINE config 4's frame at its real size on one GPU: 2.8 M triangles (63-bit keys on the device, 30-bit in the oracle), 1920x1080"""
+    ref = _frame_parity(R, orc, get_scene("bistro_like", 1.0), 1920, 1080, None, "fused")
+    _check_against_golden("c4_bistro_like_1080p_1light", ref)
+
+
+def test_config5_full_size_ao_matches_oracle(R, orc, get_scene):
+    """BASELINE config 5 at its real size: 3840x2160, 16 AO rays per hit pixel (113 M rays) on the frame's own depth + normal outputs
+    (vk_xe_gtao.rs:17-23): the G-buffer inputs and the 0..255 integer output are bit-exact"""
+    import zlib
+    sc = get_scene("sponza_like", 1.0)
+    w, h, spp, radius = 3840, 2160, 16, 0.2 * 1.457
+    r = R.renderer_for_scene(sc, (w, h), n_lights=1)
+    r.render_frame(sync=False)
+    r.trace_ao(spp, radius)
+    got = r.read_ao()
+    S, L, nl = oracle_for(orc, sc, 1)
+    cam = oracle_camera(orc, sc, w, h)
+    ref = S.render(cam, L, nl, w, h, threads=16)
+    assert np.array_equal(r.read_depth().view(np.uint32), ref["depth"].view(np.uint32))
+    assert np.array_equal(r.read_normal().view(np.uint32), ref["normal"].view(np.uint32))
+    want, st = orc.render_ao(S, cam, ref["depth"], ref["normal"], spp, radius, threads=16)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} AO values differ"
+    fx = _golden_stats("c5_sponza_like_2160p_16spp_ao")
+    assert r.stats()["ao_rays"] == st["ao_rays"] == fx["ao_rays"] == ref["stats"]["hit_pixels"] * spp
+    assert st["n_int_ao"] == fx["n_int_ao"] and st["n_tri_ao"] == fx["n_tri_ao"] and zlib.crc32(want.tobytes()) == fx["ao_crc32"]
+    r.close()
 
 
 def test_config4_bistro_class_scene(R, orc, get_scene):
@@ -128,7 +184,6 @@ def test_config4_bistro_class_scene(R, orc, get_scene):
     seen = np.bincount(idx.reshape(-1), minlength=2 * T - 1)
     assert seen[0] == 0 and np.all(seen[1:] == 1)                # every node and leaf has exactly one parent
     r.close()
-    _frame_parity(R, orc, sc, 960, 540, None, "fused")
 
 
 def test_ragged_extent_and_resize(R, orc, get_scene):
@@ -644,6 +699,39 @@ def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
         for k in range(17):
             r.lights_mut().get_point_lights_mut().append(R.PointLight((0, 0.5, 0), (1, 1, 1), 3.0, False))
         r.upload_state()
+    r.close()
+
+
+def test_lights_change_every_frame_while_sixteen_frames_are_in_flight(R, orc, get_scene, scenes):
+    """a light animated every frame with 16 frames in flight (a double-buffered device table was overwritten while launches queued
+    frames ago still read it): the light records travel by value with each launch, so every frame shows ITS lights -- each one against the oracle"""
+    from helpers import device_to_host
+    import math
+    sc = get_scene("sponza_like", 0.12)
+    w, h, F = 960, 540, 16
+    r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=F)
+    r.lights_mut().get_point_lights_mut().append(R.PointLight((0.0, 1.0, 0.0), (8.0, 8.0, 8.0), 3.0, True))
+    r.lights_mut().get_directional_lights_mut().append(R.DirectionalLight((-0.3, -1.0, -0.2), (3.0, 3.0, 3.0), True))
+    r.render_frame()                                        # buffers allocated, wave plan sampled
+    ptrs, lights = [], []
+    for i in range(F):                                      # F frames back to back, no host sync: the earlier ones are still queued or running
+        pl = r.lights_mut().get_point_lights_mut()[0]
+        pl.pos = (0.5 * math.cos(0.7 * i), 0.6 + 0.05 * i, 0.5 * math.sin(0.7 * i))
+        pl.color = (2.0 + i, 9.0 - 0.5 * i, 1.0 + 0.3 * i)
+        lights.append([dict(kind="point", pos=pl.pos, color=pl.color, falloff=3.0, casts_shadows=True),
+                       dict(kind="directional", dir=(-0.3, -1.0, -0.2), color=(3.0, 3.0, 3.0), casts_shadows=True)])
+        r.upload_state()
+        r.trace()
+        ptrs.append(r.device_color())
+    r.sync()
+    assert len({p for p, _ in ptrs}) == F                   # every frame of the trip has its own slot
+    S = orc.Scene(sc.primitives, morton_bits=30)
+    cam = oracle_camera(orc, sc, w, h)
+    frames = [device_to_host(p, n).view(np.float32).reshape(h, w, 4) for p, n in ptrs]
+    assert not np.array_equal(frames[0], frames[F - 1])
+    for i in range(F):
+        ref = S.render(cam, orc.make_lights(lights[i]), 2, w, h, threads=8)
+        assert_radiance_close(frames[i], ref["color"], what=f"frame {i}")
     r.close()
 
 
