@@ -374,6 +374,17 @@ static inline void tri_box(const float *tv, float *lo, float *hi) {
 
 #define ORC_STACK 256
 
+/* Packet-level accounting (bench.py's roofline): the GPU walks an 8x8 pixel block's rays as ONE packet that fetches every node and
+ * triangle on the union of its rays' paths once.  A recorder, when a thread has one, marks what the rays of the current packet
+ * touch; a node or triangle counts once per packet.  kind 0 = the primary packet, 1 + i = the shadow packet towards light i. */
+typedef struct { uint32_t *stamp[17]; size_t words; uint32_t id; int kind; uint64_t nodes[2], tris[2]; } Visit;
+static __thread Visit *g_visit = NULL;
+static inline void visit_mark(size_t slot, int is_tri) {
+    Visit *v = g_visit;
+    uint32_t *st = v->stamp[v->kind];
+    if (st[slot] != v->id) { st[slot] = v->id; if (is_tri) v->tris[v->kind != 0]++; else v->nodes[v->kind != 0]++; }
+}
+
 static Best closest_bvh(const OrcScene *s, const Ray *r, uint64_t *n_int, uint64_t *n_tri) {
     Best b; b.t = r->tmax; b.u = b.v = 0; b.gid = 0; b.hit = 0;
     uint32_t T = s->T;
@@ -388,6 +399,7 @@ static Best closest_bvh(const OrcScene *s, const Ray *r, uint64_t *n_int, uint64
         int32_t n = stack[--sp];
         if (fmaxf(stack_t[sp], r->tmin) > b.t) continue;
         (*n_int)++;
+        if (g_visit) visit_mark((size_t)n, 0);
         int32_t c[2] = {s->child[2 * n], s->child[2 * n + 1]};
         float te[2]; int h[2];
         for (int k = 0; k < 2; k++) {
@@ -403,6 +415,7 @@ static Best closest_bvh(const OrcScene *s, const Ray *r, uint64_t *n_int, uint64
             if (fmaxf(te[ci], r->tmin) > b.t) continue;
             uint32_t pos = (uint32_t)~c[ci];
             (*n_tri)++;
+            if (g_visit) visit_mark((size_t)(T - 1) + pos, 1);
             consider_tri(s, r, s->leaf_gid[pos], s->leaf_lo + 3 * pos, s->leaf_hi + 3 * pos, &b);
         }
         for (int k = 0; k < 2; k++) {
@@ -440,6 +453,7 @@ static int any_bvh(const OrcScene *s, const Ray *r, uint64_t *n_int, uint64_t *n
     while (sp) {
         int32_t n = stack[--sp];
         (*n_int)++;
+        if (g_visit) visit_mark((size_t)n, 0);
         int32_t c[2] = {s->child[2 * n], s->child[2 * n + 1]};
         float te[2]; int h[2];
         for (int k = 0; k < 2; k++) {
@@ -453,6 +467,7 @@ static int any_bvh(const OrcScene *s, const Ray *r, uint64_t *n_int, uint64_t *n
             if (!h[ci] || c[ci] >= 0) continue;
             uint32_t pos = (uint32_t)~c[ci];
             (*n_tri)++;
+            if (g_visit) visit_mark((size_t)(T - 1) + pos, 1);
             if (accept_any(s, r, s->leaf_gid[pos], s->leaf_lo + 3 * pos, s->leaf_hi + 3 * pos)) return 1;
         }
         for (int k = 0; k < 2; k++) {
@@ -733,6 +748,7 @@ static void render_pixel(Job *J, OrcStats *st, uint32_t x, uint32_t y) {
     v3 o, d; primary_ray(cam, x, y, J->w, J->h, &o, &d);
     Ray r; ray_init(&r, o, d, 0.001f, 10000.0f);
     st->primary_rays++;
+    if (g_visit) g_visit->kind = 0;
     Best b = closest_bvh(s, &r, &st->n_int_primary, &st->n_tri_primary);
     float out_depth = 10000.0f;
     v3 out_color = V3(0, 0, 0), out_normal = V3(0.5f, 0.5f, 0.5f);
@@ -793,6 +809,7 @@ static void render_pixel(Job *J, OrcStats *st, uint32_t x, uint32_t y) {
                 Ray sr; ray_init(&sr, world_pos, L, 0.01f, len3(nn_L));
                 st->shadow_rays++;
                 if (i < 16) sbits |= 1u << (16 + i);
+                if (g_visit) g_visit->kind = 1 + (int)(i < 16 ? i : 15);
                 if (any_bvh(s, &sr, &st->n_int_shadow, &st->n_tri_shadow)) { att = 0.05f; if (i < 16) sbits |= 1u << i; }
             }
             v3 rad = get_light_radiance(l, world_pos, L);
@@ -810,6 +827,7 @@ static void render_pixel(Job *J, OrcStats *st, uint32_t x, uint32_t y) {
         out_normal = V3(on.x * 0.5f + 0.5f, on.y * 0.5f + 0.5f, on.z * 0.5f + 0.5f);
     }
     if (!(isfinite(out_color.x) && isfinite(out_color.y) && isfinite(out_color.z))) st->nonfinite_pixels++;
+    if (!J->color) return;   /* counting runs (orc_packet_stats) keep no image */
     float *c = J->color + pix * 4; c[0] = out_color.x; c[1] = out_color.y; c[2] = out_color.z; c[3] = 1.0f;
     J->depth[pix] = out_depth;
     float *n = J->normal + pix * 4; n[0] = out_normal.x; n[1] = out_normal.y; n[2] = out_normal.z; n[3] = 1.0f;
@@ -851,6 +869,51 @@ void orc_render(const OrcScene *s, const OrcCamera *cam, const OrcLight *lights,
         for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
     }
     if (stats) *stats = J.stats;
+}
+
+/* ------------------------------------------------------------------ packet-level visit counts (bench.py roofline) */
+typedef struct { Job J; uint32_t bw, bh; uint64_t out[4]; } PacketJob;
+static void *packet_worker(void *arg) {
+    PacketJob *P = (PacketJob *)arg; Job *J = &P->J;
+    const uint32_t T = J->s->T, bx_n = (J->w + P->bw - 1) / P->bw;
+    Visit v; memset(&v, 0, sizeof(v));
+    v.words = (size_t)2 * T;
+    for (uint32_t k = 0; k < 1 + (J->nl < 16 ? J->nl : 16); k++) v.stamp[k] = (uint32_t *)calloc(v.words, 4);
+    g_visit = &v;
+    OrcStats st; memset(&st, 0, sizeof(st));
+    for (;;) {
+        uint32_t by = __sync_fetch_and_add(J->next_row, 1u);          /* a row of blocks */
+        if (by * P->bh >= J->h) break;
+        for (uint32_t bx = 0; bx < bx_n; bx++) {
+            v.id = by * bx_n + bx + 1;                                  /* never 0: the stamps start cleared */
+            for (uint32_t y = by * P->bh; y < (by + 1) * P->bh && y < J->h; y++)
+                for (uint32_t x = bx * P->bw; x < (bx + 1) * P->bw && x < J->w; x++) render_pixel(J, &st, x, y);
+        }
+    }
+    g_visit = NULL;
+    for (int k = 0; k < 17; k++) free(v.stamp[k]);
+    pthread_mutex_lock(J->mu);
+    P->out[0] += v.nodes[0]; P->out[1] += v.tris[0]; P->out[2] += v.nodes[1]; P->out[3] += v.tris[1];
+    uint64_t *a = (uint64_t *)&J->stats, *b = (uint64_t *)&st;
+    for (size_t i = 0; i < sizeof(OrcStats) / 8; i++) a[i] += b[i];
+    pthread_mutex_unlock(J->mu);
+    return NULL;
+}
+void orc_packet_stats(const OrcScene *s, const OrcCamera *cam, const OrcLight *lights, uint32_t n_lights, uint32_t w, uint32_t h,
+                      uint32_t block_w, uint32_t block_h, uint64_t out[4], OrcStats *stats, int n_threads) {
+    PacketJob P; memset(&P, 0, sizeof(P));
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    volatile uint32_t next = 0;
+    P.J.s = s; P.J.cam = cam; P.J.lights = lights; P.J.nl = n_lights; P.J.w = w; P.J.h = h; P.J.y0 = 0; P.J.y1 = h;
+    P.J.mu = &mu; P.J.next_row = &next; P.bw = block_w ? block_w : 8; P.bh = block_h ? block_h : 8;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    if (s->T < 2) n_threads = 1;
+    pthread_t th[256];
+    for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, packet_worker, &P);
+    for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    for (int k = 0; k < 4; k++) out[k] = P.out[k];
+    if (stats) *stats = P.J.stats;
 }
 
 /* ------------------------------------------------------------------ ray-traced AO (BASELINE config 5) */

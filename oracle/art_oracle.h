@@ -88,6 +88,15 @@ void orc_render(const OrcScene *, const OrcCamera *, const OrcLight *, uint32_t 
                 uint32_t y0, uint32_t y1, float *color, float *depth, float *normal, float *hit_tuv, int32_t *hit_id,
                 uint32_t *shadow_bits, OrcStats *stats, int n_threads);
 
+/* Packet-level visit counts of the same frame on the canonical LBVH: the frame is cut into block_w x block_h pixel blocks (8 x 8: what
+ * one GPU wave traces as a packet); the primary rays of a block are one packet, its shadow rays towards light i another.  A node or
+ * triangle a packet's rays touch (the union of their per-ray paths, each ray walked exactly as orc_render walks it) counts ONCE per
+ * packet.  out = { nodes of primary packets, triangles of primary packets, nodes of shadow packets, triangles of shadow packets }.
+ * This is the algorithmic fetch count of a packet tracer (bench.py prices its roofline with it); the per-ray counters of OrcStats
+ * are the contract's figure, which charges every ray for every node.  stats: as orc_render's. */
+void orc_packet_stats(const OrcScene *, const OrcCamera *, const OrcLight *, uint32_t n_lights, uint32_t w, uint32_t h,
+                      uint32_t block_w, uint32_t block_h, uint64_t out[4], OrcStats *stats, int n_threads);
+
 /* ray-traced ambient occlusion with XeGTAO's I/O contract (vk_xe_gtao.rs:17-23, :261-272, :295-333; consumer
  * tonemap.comp.glsl:33-34): inputs = the frame's depth + view-space normal outputs, output = 0..255 per pixel
  * (uint(pow(visibility, 2.2) * 255 + 0.5), 255 where nothing was hit).  spp cosine-weighted rays of length `radius`

@@ -66,6 +66,7 @@ def lib():
         L.orc_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_packet_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_render_ao.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_pack_b10g11r11.argtypes = [C.c_void_p]; L.orc_pack_b10g11r11.restype = C.c_uint32
         L.orc_unpack_b10g11r11.argtypes = [C.c_uint32, C.c_void_p]
@@ -199,6 +200,14 @@ class Scene:
         if debug:
             out.update(hit_tuv=tuv, hit_id=ids, shadow_bits=sb)
         return out
+
+
+def packet_stats(scene: "Scene", cam: OrcCamera, lights, n_lights, w, h, block=(8, 8), threads=1):
+    """visit counts per 8x8-pixel packet on the canonical LBVH (union of the packet's per-ray paths), plus the frame's per-ray stats"""
+    out = (C.c_uint64 * 4)()
+    st = OrcStats()
+    lib().orc_packet_stats(scene.h, C.byref(cam), lights, n_lights, w, h, block[0], block[1], out, C.byref(st), threads)
+    return dict(packet_nodes_primary=int(out[0]), packet_tris_primary=int(out[1]), packet_nodes_shadow=int(out[2]), packet_tris_shadow=int(out[3])), st.as_dict()
 
 
 def render_ao(scene: "Scene", cam: OrcCamera, depth, normal, spp, radius, threads=1):
