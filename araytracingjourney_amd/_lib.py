@@ -12,6 +12,7 @@ ART_FLAG_KEEP_DEBUG = 1
 ART_FLAG_PACKED_TILES = 4  # sharded: the gather payload is the B10G11R11 colour (4 B per pixel)
 ART_FLAG_DEVICE_TREE = 8  # the PREFER_FAST_TRACE tree by PLOC instead of the binned SAH (both built on the device)
 ART_FLAG_FIXED_WAVES = 16  # one wave per 8x8 block always (default: the adaptive wave plan of the fused frame)
+ART_FLAG_TILE_OUTPUT = 32  # compact tile buffer even for an unsharded frame (a one-rank art_mgpu job)
 ART_FLAG_FAST_BUILD = 2  # keep the LBVH topology in the traversal nodes (default: binned-SAH rebuild, PREFER_FAST_TRACE)
 
 
@@ -56,6 +57,23 @@ class ArtGlbCopyInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("mesh_buffer_offset", "mesh_size", "indices_buffer_offset", "indices_size", "image_buffer_offset", "image_size")] + \
                [(n, C.c_uint32) for n in ("single_mesh_element_size", "single_index_size", "image_format", "image_width", "image_height", "image_mip_levels",
                                           "image_layers", "reserved")]
+
+
+class ArtLayout(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "frames_in_flight", "frames_per_launch", "shard_rank", "shard_count", "tiles_owned", "tiles_padded",
+                                          "tile_bytes", "reserved")]
+
+
+# int32_t (*)(void *user, const void *send_dev, size_t bytes, void *recv_dev, void *hip_stream)
+ArtMgpuExchangeFn = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+ART_MGPU_ID_BYTES = 128
+ART_MGPU_SHARED, ART_MGPU_DEDICATED = 0, 1
+ART_MGPU_RCCL, ART_MGPU_HOST_EXCHANGE = 0, 1
+
+
+class ArtMgpuConfig(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("compositor", C.c_uint32), ("launches_per_gather", C.c_uint32), ("tile_buffers", C.c_uint32),
+                ("transport", C.c_uint32), ("exchange", ArtMgpuExchangeFn), ("exchange_user", C.c_void_p)]
 
 
 assert C.sizeof(ArtVertex) == 48 and C.sizeof(ArtLight) == 80 and C.sizeof(ArtCamera) == 268
@@ -116,6 +134,18 @@ SYMBOLS = {
     "art_untile_gathered_strided": (_I32, [_P, _P, _U32, _U32, _P, _P]),
     "art_untile_gathered_frames": (_I32, [_P, _P, _U32, _U32, _U32, _P, _P]),
     "art_get_stats": (_I32, [_P, _P]),
+    "art_get_layout": (_I32, [_P, _P]),
+    "art_timestamp_mark": (_I32, [_P, _U32]),
+    "art_timestamp_elapsed": (_I32, [_P, _P]),
+    "art_mgpu_shard": (_I32, [_U32, _U32, _U32, _P, _P]),
+    "art_mgpu_unique_id": (_I32, [_P]),
+    "art_mgpu_create": (_I32, [_P, _P, _P, _P]),
+    "art_mgpu_trace": (_I32, [_P]),
+    "art_mgpu_flush": (_I32, [_P]),
+    "art_mgpu_device_frame": (_I32, [_P, _P, _P]),
+    "art_mgpu_read_frame": (_I32, [_P, _P, _SZ]),
+    "art_mgpu_counts": (_I32, [_P, _P, _P, _P]),
+    "art_mgpu_destroy": (_I32, [_P]),
     "art_read_hits": (_I32, [_P, _P, _P, _SZ]),
     "art_read_shadow_bits": (_I32, [_P, _P, _SZ]),
     "art_query_closest": (_I32, [_P, _P, _U32, _P, _P]),

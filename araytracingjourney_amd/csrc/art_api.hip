@@ -42,6 +42,8 @@ template <class T> struct DevBuf {
 
 } // namespace
 
+void art::set_last_error(const char *msg) { g_err = msg ? msg : ""; }
+
 // one frame in flight: its own stream and per-frame buffers, like the reference's FrameData ring (renderer.rs:135, :300-318)
 struct FrameSlot {
     hipStream_t own = nullptr;
@@ -54,7 +56,7 @@ struct FrameSlot {
     DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     hipEvent_t done_alias = nullptr;   // the latest frame's completion is this ring event (fused frames: one record less per frame) instead of `done`
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
-    static constexpr uint32_t kTileRing = 8;
+    static constexpr uint32_t kTileRing = kTileRingMax;
     float4 *ext_ring[kTileRing] = {}; uint32_t ext_ring_n = 0; // caller-owned buffers the slot's frames write in turn, one per trip round the frame ring (art_bind_color_tiles_ring)
     float4 *tiles_of_last = nullptr;   // where the slot's most recent frame wrote its tiles
     float4 *tiles_for(uint64_t frame_no, uint32_t F) { float4 *t = ext_tiles ? (ext_ring_n > 1 ? ext_ring[(frame_no / F) % ext_ring_n] : ext_tiles) : d_color_tiles.p; tiles_of_last = t; return t; }
@@ -67,7 +69,7 @@ struct FrameSlot {
         d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_entry.release(); d_wave_cost.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
     }
 };
-constexpr uint32_t kMaxFrames = 24;
+constexpr uint32_t kMaxFrames = kMaxFrameSlots;
 
 // Which wave of the fused frame's launch traces what.  A launch lasts as long as its slowest wave, and an 8x8 packet that crosses dense
 // distant geometry walks the union of 64 unrelated paths: up to 0.5 ms where the rest of the launch is done after 0.1 ms.  Every wave
@@ -135,11 +137,13 @@ struct ArtContext {
     hipEvent_t ev[kRing][5] = {};
     bool ev_fused[kRing] = {};                 // the frame was one launch: only ev[0] and ev[4] were recorded
     uint64_t frame_no = 0, collected_upto = 0;
+    hipEvent_t mark[2] = {nullptr, nullptr};   // art_timestamp_mark
     bool traced = false;
     bool graph_mode = false; // replay a captured hipGraph per slot instead of 5 launches + 6 event records (host-bound multi-GPU runs)
     uint32_t ao_spp = 0;
     ArtStats stats{};
     bool tiles_packed() const { return (cfg.flags & ART_FLAG_PACKED_TILES) != 0; }
+    bool tiled() const { return cfg.shard_count > 1 || (cfg.flags & ART_FLAG_TILE_OUTPUT) != 0; } // writes the compact tile buffer beside the frame
     size_t tile_px_bytes() const { return tiles_packed() ? 4 : 16; } // B10G11R11 words or float4 in the compact tile buffer
     hipStream_t stream_of(uint32_t k) const { return (ext_stream && F == 1) ? ext_stream : slot[k].own; }
     hipStream_t main_stream() const { return stream_of(0); }
@@ -392,7 +396,7 @@ int32_t setup_frame(ArtContext *c) {
         if (staged) { HIPC(S.d_contrib.ensure(nl * c->n_local)); HIPC(S.d_shadow_rays.ensure(2 * nl * c->n_local)); }
         HIPC(S.d_color.ensure(npix * B)); HIPC(S.d_normal.ensure(npix * B)); HIPC(S.d_depth.ensure(npix * B));
         HIPC(hipMemset(S.d_color.p, 0, npix * B * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * B * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * B * 4));
-        if (count > 1) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels * B)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * B * c->tile_px_bytes())); }
+        if (c->tiled()) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels * B)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * B * c->tile_px_bytes())); }
         if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local * B)); // fused frames always write their per-pixel shadow bits (stats)
         if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() * B) { S.ext_tiles = nullptr; S.ext_ring_n = 0; S.tiles_of_last = nullptr; S.ext_tiles_bytes = 0; }
     }
@@ -439,6 +443,15 @@ bool mat4_inverse(const float *m, float *o) {
 }
 
 } // namespace
+
+int32_t art::ring_rewind(ArtContext *c) {
+    if (!c) return fail(ART_E_INVALID, "ring_rewind: null context");
+    int32_t r = use_device(c); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    c->frame_no = 0; c->collected_upto = 0; c->last = 0;
+    c->plan.next_sample = 0; c->plan.pending = false;   // (a sample in flight has landed: everything is synchronised)
+    return ART_OK;
+}
 
 extern "C" {
 
@@ -514,6 +527,7 @@ int32_t art_destroy(ArtContext *c) {
     }
     for (int f = 0; f < ArtContext::kRing; f++)
         for (int i = 0; i < 5; i++) if (c->ev[f][i]) (void)hipEventDestroy(c->ev[f][i]);
+    for (int i = 0; i < 2; i++) if (c->mark[i]) (void)hipEventDestroy(c->mark[i]);
     delete c;
     return ART_OK;
 }
@@ -771,7 +785,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
-    a.color_tiles = c->cfg.shard_count > 1 ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)
+    a.color_tiles = c->tiled() ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
     a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0; a.frame_waves = c->frame_waves;
     a.batch = c->B; a.tiles_stride = c->padded_tiles * kTilePixels;
@@ -794,7 +808,7 @@ int32_t art_trace(ArtContext *c) {
     if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
     if (c->plan.enabled) { r = plan_poll(c); if (r) return r; }
     FrameArgs a = make_frame_args(c, S);
-    if (c->cfg.shard_count > 1) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
+    if (c->tiled()) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
     if (c->B > 1 && (!fused || c->packet_wide || c->frame_waves < 8)) return fail(ART_E_STATE, "art_trace: several frames per launch need the default fused frame");
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
@@ -997,7 +1011,7 @@ int32_t art_shard_tile_count(ArtContext *c, uint32_t *owned, uint32_t *padded) {
 }
 int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
     int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_color_tiles"); if (r) return r;
-    if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
+    if (!c->tiled()) return fail(ART_E_STATE, "art_device_color_tiles: context is not sharded");
     FrameSlot &S = c->slot[c->last];
     const size_t one = (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes();
     *p = (char *)S.last_tiles() + c->read_b * one; if (b) *b = one;
@@ -1005,7 +1019,7 @@ int32_t art_device_color_tiles(ArtContext *c, void **p, size_t *b) {
 }
 int32_t art_bind_color_tiles(ArtContext *c, uint32_t slot, void *dev, size_t bytes) {
     if (!c) return fail(ART_E_INVALID, "art_bind_color_tiles: null context");
-    if (c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_bind_color_tiles: context is not sharded");
+    if (!c->tiled()) return fail(ART_E_STATE, "art_bind_color_tiles: context is not sharded");
     if (slot >= c->F) return fail(ART_E_INVALID, "art_bind_color_tiles: slot >= frames in flight");
     void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_bind_color_tiles"); if (r) return r;
     if (dev && bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() * c->B) return fail(ART_E_INVALID, "art_bind_color_tiles: size mismatch (padded tiles x tile bytes x frames per launch)");
@@ -1094,7 +1108,7 @@ int32_t art_collect_timings(ArtContext *c, float sums_ms[5], uint32_t *n_frames)
     return ART_OK;
 }
 int32_t art_read_color_tiles(ArtContext *c, void *dst, size_t bytes) {
-    if (c && c->cfg.shard_count <= 1) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
+    if (c && !c->tiled()) return fail(ART_E_STATE, "art_read_color_tiles: context is not sharded");
     FrameSlot *S = c ? &c->slot[c->last] : nullptr;
     const size_t one = c ? (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() : 0;
     return read_back(c, S ? (const char *)S->last_tiles() + c->read_b * one : nullptr, one, dst, bytes, "art_read_color_tiles");
@@ -1123,6 +1137,32 @@ int32_t art_untile_gathered_strided(ArtContext *c, const void *gathered_dev, uin
 int32_t art_untile_gathered(ArtContext *c, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream) {
     if (!c) return fail(ART_E_INVALID, "art_untile_gathered: null argument");
     return art_untile_gathered_strided(c, gathered_dev, shard_count, c->padded_tiles, frame_dev, hip_stream);
+}
+
+int32_t art_get_layout(ArtContext *c, ArtLayout *out) {
+    if (!c || !out) return fail(ART_E_INVALID, "art_get_layout: null argument");
+    void *p; int32_t r = dev_ptr(c, nullptr, 0, &p, nullptr, "art_get_layout"); if (r) return r;   // lays the frame out if that has not happened yet
+    std::memset(out, 0, sizeof(*out));
+    out->width = c->W; out->height = c->H; out->frames_in_flight = c->F; out->frames_per_launch = c->B;
+    out->shard_rank = c->cfg.shard_count > 1 ? c->cfg.shard_rank : 0; out->shard_count = c->cfg.shard_count > 1 ? c->cfg.shard_count : 1;
+    out->tiles_owned = (uint32_t)c->tile_list.size(); out->tiles_padded = c->padded_tiles; out->tile_bytes = c->tiled() ? (uint32_t)(kTilePixels * c->tile_px_bytes()) : 0u; // 0: no compact tile buffer
+    return ART_OK;
+}
+int32_t art_timestamp_mark(ArtContext *c, uint32_t which) {
+    if (!c || which > 1) return fail(ART_E_INVALID, "art_timestamp_mark: mark 0 or 1");
+    if (!c->traced) return fail(ART_E_STATE, "art_timestamp_mark: nothing traced yet");
+    int32_t r = use_device(c); if (r) return r;
+    if (!c->mark[which]) HIPC(hipEventCreate(&c->mark[which]));
+    HIPC(hipEventRecord(c->mark[which], c->stream_of(c->last)));
+    return ART_OK;
+}
+int32_t art_timestamp_elapsed(ArtContext *c, float *ms) {
+    if (!c || !ms) return fail(ART_E_INVALID, "art_timestamp_elapsed: null argument");
+    if (!c->mark[0] || !c->mark[1]) return fail(ART_E_STATE, "art_timestamp_elapsed: both marks must have been recorded");
+    int32_t r = use_device(c); if (r) return r;
+    HIPC(hipEventSynchronize(c->mark[1]));
+    HIPC(hipEventElapsedTime(ms, c->mark[0], c->mark[1]));
+    return ART_OK;
 }
 
 int32_t art_get_stats(ArtContext *c, ArtStats *out) {

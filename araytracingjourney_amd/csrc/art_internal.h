@@ -60,6 +60,10 @@ constexpr int kTile = 32;            // shard tile edge (pixels)
 constexpr int kTilePixels = kTile * kTile;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kMaxLights = 16;
+constexpr uint32_t kMaxFrameSlots = 24; // ring slots of a context (more than ~22 streams in use stall the command processor)
+constexpr uint32_t kTileRingMax = 8;    // caller-owned compact tile buffers per ring slot (art_bind_color_tiles_ring)
+int32_t ring_rewind(ArtContext *ctx);   // art_api.hip: waits for every frame in flight, then the next art_trace is launch 0 again (ring slot 0, first tile buffer)
+void set_last_error(const char *msg);   // art_api.hip: the thread's art_last_error() string, for entry points that live in other files
 
 // ---- launch wrappers (art_build.hip / art_trace.hip) ---------------------------------------------------------
 struct BuildInputs {

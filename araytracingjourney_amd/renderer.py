@@ -212,11 +212,11 @@ class Model:
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
-    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, device_tree=False, fixed_waves=False):
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, device_tree=False, fixed_waves=False, tile_output=False):
         self._L = _lib.load()
         w, h = extent
         cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
-                        flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0) | (_lib.ART_FLAG_PACKED_TILES if packed_tiles else 0) | (_lib.ART_FLAG_DEVICE_TREE if device_tree else 0) | (_lib.ART_FLAG_FIXED_WAVES if fixed_waves else 0),
+                        flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0) | (_lib.ART_FLAG_PACKED_TILES if packed_tiles else 0) | (_lib.ART_FLAG_DEVICE_TREE if device_tree else 0) | (_lib.ART_FLAG_FIXED_WAVES if fixed_waves else 0) | (_lib.ART_FLAG_TILE_OUTPUT if tile_output else 0),
                         frames_in_flight=frames_in_flight)
         self._ctx = C.c_void_p()
         check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))
@@ -443,6 +443,20 @@ class Renderer:
     def wait_external_event(self, hip_event_ptr):
         check(self._L.art_wait_external_event(self._ctx, C.c_void_p(hip_event_ptr)))
 
+    def layout(self) -> dict:
+        lay = _lib.ArtLayout()
+        check(self._L.art_get_layout(self._ctx, C.byref(lay)))
+        return {n: getattr(lay, n) for n, _ in lay._fields_ if n != "reserved"}
+
+    def timestamp_mark(self, which):
+        """device timestamp behind the most recently traced frame (mark 0 or 1)"""
+        check(self._L.art_timestamp_mark(self._ctx, which))
+
+    def timestamp_elapsed_ms(self):
+        ms = C.c_float()
+        check(self._L.art_timestamp_elapsed(self._ctx, C.byref(ms)))
+        return ms.value
+
     def collect_timings(self):
         sums = (C.c_float * 5)()
         n = C.c_uint32()
@@ -522,6 +536,76 @@ class Renderer:
         out = dict(child=np.zeros((NI, 2), np.int32), node_lo=np.zeros((NI, 3), np.float32), node_hi=np.zeros((NI, 3), np.float32))
         check(self._L.art_get_traversal_tree(self._ctx, _ptr(out["child"]), _ptr(out["node_lo"]), _ptr(out["node_hi"])))
         return out
+
+
+def mgpu_shard(rank, world, dedicated=False):
+    """(shard_rank, shard_count) the context of `rank` is created with (art_mgpu_shard)"""
+    sr, sc = C.c_uint32(), C.c_uint32()
+    check(_lib.load().art_mgpu_shard(rank, world, _lib.ART_MGPU_DEDICATED if dedicated else _lib.ART_MGPU_SHARED, C.byref(sr), C.byref(sc)))
+    return sr.value, sc.value
+
+
+def mgpu_unique_id() -> bytes:
+    """rank 0: the job's 128-byte RCCL id, to be handed to the other ranks"""
+    buf = (C.c_uint8 * _lib.ART_MGPU_ID_BYTES)()
+    check(_lib.load().art_mgpu_unique_id(buf))
+    return bytes(buf)
+
+
+class MultiGpu:
+    """The sharded frame behind the C ABI (art_mgpu_*): this rank's share traced, the tiles of a group of launches gathered to rank 0 by one
+    RCCL gather, un-tiled by one launch.  `exchange` (a Python function (send_ptr, nbytes, recv_ptr, stream_ptr) -> None) replaces RCCL for
+    rehearsals on one GPU."""
+
+    def __init__(self, renderer: "Renderer", rank, world, unique_id: bytes = None, dedicated=False, launches_per_gather=0, tile_buffers=0, exchange=None):
+        self._L = _lib.load()
+        self.renderer, self.rank, self.world = renderer, rank, world
+        cfg = _lib.ArtMgpuConfig(rank=rank, world=world, compositor=_lib.ART_MGPU_DEDICATED if dedicated else _lib.ART_MGPU_SHARED,
+                                 launches_per_gather=launches_per_gather, tile_buffers=tile_buffers, transport=_lib.ART_MGPU_HOST_EXCHANGE if exchange else _lib.ART_MGPU_RCCL)
+        self._cb = None
+        if exchange:
+            def _cb(user, send, nbytes, recv, stream):
+                try:
+                    exchange(send, nbytes, recv, stream)
+                    return 0
+                except Exception:   # nothing may unwind into the C caller
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            self._cb = _lib.ArtMgpuExchangeFn(_cb)   # kept alive as long as the object
+            cfg.exchange = self._cb
+        idbuf = (C.c_uint8 * _lib.ART_MGPU_ID_BYTES)(*unique_id) if unique_id is not None else None
+        self._h = C.c_void_p()
+        check(self._L.art_mgpu_create(renderer._ctx, C.byref(cfg), idbuf, C.byref(self._h)))
+
+    def trace(self):
+        check(self._L.art_mgpu_trace(self._h))
+
+    def flush(self):
+        check(self._L.art_mgpu_flush(self._h))
+
+    def counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        check(self._L.art_mgpu_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(launches_traced=a.value, gathers=b.value, launches_per_gather=c.value)
+
+    def read_frame(self):
+        """rank 0, after flush(): the most recent frame -- [h, w, 4] float32, or [h, w] uint32 B10G11R11 words with packed tiles"""
+        w, h = self.renderer.extent
+        a = np.empty((h, w), np.uint32) if self.renderer.packed_tiles else np.empty((h, w, 4), np.float32)
+        check(self._L.art_mgpu_read_frame(self._h, _ptr(a), a.nbytes))
+        return a
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.art_mgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def set_root_relief(per_256):

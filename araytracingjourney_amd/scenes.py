@@ -17,6 +17,7 @@ on every machine and numpy version.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -536,6 +537,39 @@ def bistro_like(detail: float = 1.0) -> Scene:
     cam = dict(pos=(-1.85, 0.085, 0.0), dir=_unit((1.0, 0.02, 0.03)), fovy=math.pi / 2, znear=0.1, zfar=1000.0)
     lights = [dict(kind="directional", dir=(-0.25, -1.0, -0.35), color=(3.0, 3.0, 3.0), casts_shadows=True)]
     return Scene("bistro_like", prims, cam, lights)
+
+
+def camera_path(scene: Scene, n: int):
+    """n camera poses around the scene's own (bench.py --camera-path): a closed loop of small displacements with the view direction swinging
+    along, so that consecutive frames walk different parts of the tree.  Pose 0 is the scene's camera."""
+    p0, d0 = np.asarray(scene.camera["pos"], np.float64), np.asarray(scene.camera["dir"], np.float64)
+    out = []
+    for i in range(n):
+        a = 2.0 * math.pi * i / n
+        pos = p0 + np.array([0.22 * math.sin(a), 0.06 * (1.0 - math.cos(a)), 0.18 * (1.0 - math.cos(a))])
+        d = d0 + np.array([0.0, 0.10 * math.sin(a), 0.35 * math.sin(a) - 0.15 * (1.0 - math.cos(a))])
+        out.append(dict(scene.camera, pos=tuple(float(x) for x in pos), dir=_unit(d)))
+    return out
+
+
+def from_glb(path, lights=None, camera=None) -> Scene:
+    """A .glb through the C++ reader (art_glb_*: GltfModelReader of gltf_model_reader.rs) as a Scene, set up like the reference's main.rs:23-66:
+    model matrix = uniform scale 2 (:30-36), the renderer's default camera (renderer.rs:222-231), one directional light unless given.
+    Like VkModel (vk_model.rs:498-508) it needs positions, uvs, normals, tangents, indices and the albedo / ORM / normal textures."""
+    from . import model_reader as mr
+    r = mr.GltfModelReader(str(path), True, mr.COERCE_R8G8B8A8)
+    data, infos = r.copy_model_data_to_ptr(mr.VERTICES | mr.TEX_COORDS | mr.NORMALS | mr.TANGENTS | mr.INDICES, mr.ALBEDO | mr.ORM | mr.NORMAL)
+    prims = []
+    for ci in infos:
+        if ci.single_mesh_element_size != 48 or ci.image_layers != 3:
+            raise ValueError("the GLB does not carry the 48-byte vertex + three texture layers the ray tracer reads")
+        verts = data[ci.mesh_buffer_offset:ci.mesh_buffer_offset + ci.mesh_size].view(F32).reshape(-1, 12).copy()
+        idx = data[ci.indices_buffer_offset:ci.indices_buffer_offset + ci.indices_size].view(np.uint16 if ci.single_index_size == 2 else np.uint32).copy()
+        tex = data[ci.image_buffer_offset:ci.image_buffer_offset + ci.image_size].reshape(3, ci.image_height, ci.image_width, 4).copy()
+        prims.append(Primitive(verts, idx, tex, scale_matrix(2.0)))
+    r.close()
+    cam = camera or dict(pos=(0.0, 0.0, 0.0), dir=(0.0, 0.0, 1.0), fovy=math.pi / 2, znear=0.1, zfar=1000.0)
+    return Scene("glb:" + os.path.basename(str(path)), prims, cam, lights if lights is not None else sponza_lights(1))
 
 
 def get_scene(name: str, detail: float = 1.0) -> Scene:

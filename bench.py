@@ -7,7 +7,8 @@ light, one shadow ray per lit pixel.
 
 A step = one frame of the hot path (primary rays + closest hit, hit reconstruction + PBR direct light, shadow rays,
 accumulation; for N > 1 also the RCCL gather of the HDR tiles to rank 0 and the un-tile).  The scene, BVH, camera and
-lights are resident in HBM before the timed region.  N > 1 shards the frame by 32x32 screen tile (strong scaling).
+lights are resident in HBM before the timed region.  N > 1 shards the frame by 32x32 screen tile (strong scaling) through
+libart's art_mgpu_* entry points: the whole sharded frame -- trace, ncclGather, un-tile -- is C ABI, this file is its caller.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -18,25 +19,15 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 # Several frames are kept in flight (the reference keeps 3: renderer.rs:135); each ring slot's stream needs a hardware queue of
 # its own to overlap with the others, and the runtime's default is 4.  Must be set before the HIP runtime starts.
 # N > 1: 12 launches of 4 frames each in flight on 16 hardware queues -- the exchange stream and RCCL's streams get queues of their own, and
-# the command processor's cliff at 24 queues in use (3x slower: profiles/README.md r1k) stays far away.  (Before the wave plan and the
-# 4-frame launches a share needed 20 slots on 22 queues to hide its slowest block; now 12 / 16 measure the same as 20 / 22: r1o.)
+# the command processor's cliff at 24 queues in use (3x slower: profiles/README.md r1k) stays far away.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming)
 
-
-def algorithmic_bytes(st, n_lights):
-    """bytes(ray) = 32 + 64*N_int + 48*N_tri + B_out on the canonical binary LBVH (oracle counters)."""
-    prim = 32 * st["primary_rays"] + 64 * st["n_int_primary"] + 48 * st["n_tri_primary"] + 16 * st["primary_rays"]
-    shad = 32 * st["shadow_rays"] + 64 * st["n_int_shadow"] + 48 * st["n_tri_shadow"] + 4 * st["shadow_rays"]
-    shade = (24 + 12 + 144 + 48 + 80 * n_lights) * st["hit_pixels"] + 24 * st["primary_rays"]
-    return dict(primary=prim, shadow=shad, shade=shade, frame=prim + shad + shade)
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -46,25 +37,48 @@ def main():
     ap.add_argument("--lights", type=int, default=1, choices=[1, 4])
     ap.add_argument("--scene", default="sponza", choices=["sponza", "bistro"], help="sponza = BASELINE configs 2/3/5 (the default is config 2); bistro = config 4 (2.8 M triangles, one directional light)")
     ap.add_argument("--detail", type=float, default=1.0, help="scene detail (1.0 = the 262k-triangle config)")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="ring of per-frame streams/buffers; default 3 like the reference's FrameData ring (renderer.rs:135) on one GPU, 12 when the frame is sharded")
+    ap.add_argument("--glb", default=None, help="a .glb that satisfies the reference's reader (gltf_model_reader.rs:62-63, :643-681: one mesh, one buffer, tangents, albedo + ORM + normal "
+                                                "textures) instead of the synthetic scene: loaded through art_scene_add_glb, set up like main.rs:23-66; the line then says data: \"real glb\". "
+                                                "Default: assets/*.glb if one is there (SURVEY.md 8d), else the synthetic scene")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="ring of per-frame streams / buffers like the reference's FrameData ring (renderer.rs:135, which keeps 3); "
+                                                                      "default 16 on one GPU (one hardware queue each), 12 launches when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
-    ap.add_argument("--graph", type=int, default=-1, help="replay one captured hipGraph per frame slot (default: on for N>1, where the host is the limiter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-frames", type=int, default=12, help="N>1: frames per RCCL gather call (the ring's slots are contiguous, so GB frames travel as one message per peer; amortises the collective's launch cost)")
-    ap.add_argument("--compositor", default="auto", choices=["auto", "dedicated", "shared"],
-                    help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace "
-                         "1/(N-1) each; auto = shared: with the exchange submitted by the host (no device-side waits) a root that also traces a 1/8 share "
-                         "spends 35.5 us per frame, exchange and un-tile included, where the tracers of a 7 + 1 layout need 39.1 (profiles/README.md r1n)")
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="N>1: frames one launch traces (1..4; default: the largest of 4, 2, 1 that divides --steps; a launch costs ~7 us of machine time whatever it traces, which a 1/8 share feels)")
+    ap.add_argument("--plain", action="store_true", help="only the contract's timed region (profiling passes: no single-frame spans, no steady-state / camera-path legs, no CPU baseline)")
+    ap.add_argument("--camera-path", type=int, default=8, help="N = 1 extra leg: the camera moves every frame along a closed path of this many poses (0 = skip); ray counts of every pose "
+                                                               "are checked against the oracle's committed ones")
+    ap.add_argument("--gather-launches", type=int, default=0, help="N>1: ring slots (launches) per RCCL gather; 0 = the whole ring (the slots are contiguous, so a group travels as one message per peer)")
+    ap.add_argument("--compositor", default="shared", choices=["dedicated", "shared"],
+                    help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace 1/(N-1) each "
+                         "(rehearsed on one GPU: a root that also traces a 1/8 share spends 35.5 us per frame where the tracers of a 7 + 1 layout need 39.1, profiles/README.md r1n)")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="N>1: frames one launch traces (1..4; default: the largest of 4, 2, 1 that divides --steps and --warmup's launches; "
+                                                                       "a launch costs ~7 us of machine time whatever it traces, which a 1/8 share feels)")
     ap.add_argument("--root-relief", type=int, default=-1, help="N>1, shared compositor: 1/256ths of rank 0's share handed to the other ranks (default 8 per GPU)")
-    ap.add_argument("--gather", default="packed", choices=["packed", "fp32"], help="N>1 exchange payload: the colour tiles as B10G11R11_UFLOAT_PACK32 words -- the reference's colour image format (renderer.rs:268), 4 B per pixel -- or as RGBA32F (16 B per pixel)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo = rehearsal of the N>1 plumbing (tiles staged through the host)")
-    args = ap.parse_args()
+    ap.add_argument("--gather", default="fp32", choices=["fp32", "packed"], help="N>1 exchange payload: RGBA32F tiles -- the HDR buffer, 16 B per pixel (default, the contract) -- or "
+                                                                                  "B10G11R11_UFLOAT_PACK32 words, the reference's colour image format (renderer.rs:268), 4 B per pixel")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL inside libart (ncclGather on the tile buffers); gloo = rehearsal of the same loop with the "
+                                                                                  "collective replaced by a host function (tiles staged through host memory, ranks may share one GPU)")
+    return ap.parse_args()
 
+
+def host_cores():
+    n = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    try:  # a cgroup CPU quota (e.g. 16 CPUs of a 256-thread host) is the real core budget
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def main():
+    args = parse()
     import numpy as np
     import torch
     import torch.distributed as dist
     from araytracingjourney_amd import renderer, scenes
+    import roofline as RL
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,13 +91,20 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()   # rehearsal: ranks may share one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        # control plane (the job's id, barriers, the max over ranks of the wall clock) on gloo; the DATA path -- the gather of the tiles --
+        # is RCCL inside libart (art_mgpu_*), which needs nothing from torch
+        dist.init_process_group("gloo")
 
+    # ---- the scene -------------------------------------------------------------------------------------------------------------------
     W, H = args.width, args.height
-    if args.scene == "bistro":
+    glb = args.glb
+    if glb is None and os.path.isdir(os.path.join(ROOT, "assets")):
+        found = sorted(f for f in os.listdir(os.path.join(ROOT, "assets")) if f.lower().endswith(".glb"))
+        glb = os.path.join(ROOT, "assets", found[0]) if found else None
+    if glb:
+        sc = scenes.from_glb(glb, lights=scenes.sponza_lights(args.lights))   # the oracle's copy of what the C++ reader yields
+        lights = sc.lights
+    elif args.scene == "bistro":
         sc = scenes.bistro_like(args.detail)
         lights = sc.lights
     else:
@@ -99,8 +120,22 @@ def main():
     # is what levels its loop with the others' on the rehearsal (profiles/README.md r1n: 35.7 -> 31 us per frame at N = 8)
     relief = 0 if (world == 1 or dedicated) else min(255, (8 * world if args.root_relief < 0 else args.root_relief))
     renderer.set_root_relief(relief)
-    shard = ((rank - 1) if dedicated else rank, G) if renders else (0, G)   # the compositor keeps a context for the layout tables and the un-tile
-    r = renderer.renderer_for_scene(sc, (W, H), device=local_rank, shard=shard if world > 1 else (0, 1), frames_in_flight=F, packed_tiles=packed)
+    shard = renderer.mgpu_shard(rank, world, dedicated) if world > 1 else (0, 1)
+
+    def make_renderer(**kw):
+        if glb:   # through the real ingest: art_glb_open + art_scene_add_glb (renderer.rs:346)
+            from araytracingjourney_amd import model_reader as mr
+            r_ = renderer.Renderer((W, H), **kw)
+            r_.add_model_glb(mr.GltfModelReader(glb, True, mr.COERCE_B8G8R8A8), scenes.scale_matrix(2.0))
+            cam = r_.camera_mut()
+            cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
+            for d in lights:
+                r_.lights_mut().push_dict(d)
+            r_.prepare_first_frame()
+            return r_
+        return renderer.renderer_for_scene(sc, (W, H), **kw)
+
+    r = make_renderer(device=local_rank, shard=shard, frames_in_flight=F, packed_tiles=packed)
     B = 1                             # frames per launch
     if world > 1 and not args.ao:
         B = args.frames_per_launch if args.frames_per_launch > 0 else next(b for b in (4, 2, 1) if args.steps % b == 0)
@@ -108,119 +143,53 @@ def main():
             raise SystemExit(f"--steps {args.steps} is not a multiple of --frames-per-launch {B}")
         r.set_frames_per_launch(B)
     r.upload_state()
-    stream = torch.cuda.Stream()      # torch side of the exchange: RCCL waits, un-tile on the root
-    torch.cuda.set_stream(stream)
 
-    tiles = gathered = frame = None
-    GB = 1
-    NBUF = 4                          # tile buffers per ring slot, written in turn: a frame waits for the exchange of NBUF trips ago
-    QUEUED = "queued"                 # ... or for that exchange to be submitted at all, if its frames are still running
-    consumed = [[None] * F for _ in range(NBUF)]   # per tile buffer: event "the exchange that read these tiles has finished"
+    # ---- N > 1: the sharded frame behind the C ABI -------------------------------------------------------------------------------------
+    mg, transport = None, None
     if world > 1:
-        owned, padded = r.shard_tile_count()
-        GB = max(1, min(args.gather_frames, F))
-        while F % GB:                 # whole gather groups per trip round the ring
-            GB -= 1
-        tshape, tdtype = ((padded, 32, 32), torch.int32) if packed else ((padded, 32, 32, 4), torch.float32)
-        # slot k renders into tiles[trip % NBUF][k]: GB slots are one contiguous message, and a slot's next frames never wait for the
-        # exchanges that still read its previous tiles
-        tiles = torch.zeros((NBUF, F, B) + tshape, dtype=tdtype, device="cuda")   # [buffer][slot = launch][frame of the launch]
-        for k in range(F):
-            r.bind_color_tiles_ring(k, [tiles[b, k].data_ptr() for b in range(NBUF)], tiles[0, k].numel() * 4)
-        if rank == 0:
-            gathered = torch.empty((world, F, B) + tshape, dtype=tdtype, device="cuda")   # [peer][slot][frame]: a frame's shards are F * B * padded tiles apart
-            frame = torch.zeros((GB * B,) + ((H, W) if packed else (H, W, 4)), dtype=tdtype, device="cuda")   # the frames of one exchange, un-tiled by one launch
-        torch.cuda.synchronize()
-
-    traced = [0]                      # frames submitted so far (tile buffer = (traced // F) % NBUF)
-    fifo = []                         # gather groups whose frames are still running: (first slot, frames, tile buffer, first frame index)
-
-    def step():
-        if world == 1:
-            r.trace()                 # the whole frame (one fused launch) on the next ring slot's stream
-            if args.ao:
-                r.trace_ao(args.ao)
-            return
-        k, par = traced[0] % F, (traced[0] // F) % NBUF      # the ring slot and the tile buffer this frame takes
-        while consumed[par][k] is QUEUED:                   # its previous contents have not even been sent: NBUF trips behind, rare
-            poll()
-        ev = consumed[par][k]
-        if ev is not None and not ev.query():
-            # Gate on the HOST: a cross-stream wait queued in front of every frame costs the frame kernels their L2 contents (an acquire
-            # per launch; measured 115 instead of 55 us per frame on a 1/8 share).  The event is NBUF trips old: it has almost always fired.
-            ev.synchronize()
-        if renders:                                         # (a dedicated compositor only takes part in the exchange)
-            r.trace()
-            if args.ao:
-                r.trace_ao(args.ao)                         # per tile from the local G-buffer: no extra exchange
-        traced[0] += 1
-        pending[1] += 1
-        if pending[1] == GB or k + 1 == F:                  # one exchange per GB frames (never across the ring's wrap: one contiguous slice)
-            exchange()
-        elif fifo and traced[0] % 4 == 0:
-            poll()
-
-    pending = [0, 0]                  # first slot and number of frames traced but not yet gathered
-    newest = [0]                      # where in `frame` the most recent frame sits
-
-    def exchange(force=False):
-        # The group is queued and SUBMITTED by poll() once the host sees its frames done (art_frames_done), so the exchange stream carries no
-        # device-side wait: on a GPU that keeps tracing, each hipStreamWaitEvent packet took ~40 us to retire, which held a 1/7 share at
-        # 47 us per frame where 39 are possible (profiles/README.md r1n).  Every rank submits its groups in the same order.
-        k0, n = pending
-        if n:
-            pending[0], pending[1] = (k0 + n) % F, 0
-            par = ((traced[0] - 1) // F) % NBUF              # the buffers these frames wrote
-            fifo.append((k0, n, par, r.frames_traced() - n if renders else 0))
-            for j in range(k0, k0 + n):
-                consumed[par][j] = QUEUED
-        poll(force)
-
-    def poll(force=False):
-        while fifo:
-            k0, n, par, first = fifo[0]
-            if renders and not r.frames_done(first, n):
-                if not force:
-                    return
-                r.sync()
-            fifo.pop(0)
-            run_exchange(k0, n, par)
-
-    def run_exchange(k0, n, par):
-        src = tiles[par, k0:k0 + n]
         if args.backend == "nccl":
-            dist.gather(src, [gathered[w, k0:k0 + n] for w in range(world)] if rank == 0 else None, dst=0)
-        else:   # rehearsal: same call sequence, payload through host memory
-            host = src.cpu()
-            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-            dist.gather(host, parts, dst=0)
-            if rank == 0:
-                for w in range(world):
-                    gathered[w, k0:k0 + n].copy_(parts[w])
-        if rank == 0:                                       # every frame of the exchange is un-tiled, by one launch
-            first = 1 if dedicated else 0                   # shard s of the frame came from rank first + s
-            r.untile_gathered(gathered[first, k0].data_ptr(), G, frame.data_ptr(), stream.cuda_stream, shard_stride_tiles=F * B * padded, n_frames=n * B)
-            newest[0] = n * B - 1
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        for j in range(k0, k0 + n):
-            consumed[par][j] = ev
+            ids = [renderer.mgpu_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            mg = renderer.MultiGpu(r, rank, world, unique_id=ids[0], dedicated=dedicated, launches_per_gather=args.gather_launches)
+            transport = "RCCL ncclGather inside libart (art_mgpu_*)"
+        else:
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+            def gloo_gather(send, nbytes, recv, stream):   # the collective of the rehearsal: same call sequence, payload through host memory
+                host = torch.empty(nbytes, dtype=torch.uint8)
+                assert hip.hipMemcpy(host.data_ptr(), send, nbytes, 2) == 0
+                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    for w_, part in enumerate(parts):
+                        assert hip.hipMemcpy(recv + w_ * nbytes, part.data_ptr(), nbytes, 1) == 0
+            mg = renderer.MultiGpu(r, rank, world, dedicated=dedicated, launches_per_gather=args.gather_launches, exchange=gloo_gather)
+            transport = "host function over gloo (rehearsal)"
+
+    def step():                       # one launch: B frames of this rank's share (+ its part of the exchange)
+        if mg:
+            mg.trace()
+        else:
+            r.trace()
+        if args.ao and renders:
+            r.trace_ao(args.ao)       # per tile from the local G-buffer: no extra exchange
 
     def fence():
-        if world > 1:
-            exchange(force=True)      # frames still waiting for their group: the timed region ends with every frame on the root
+        if mg:
+            mg.flush()                # every frame traced so far is on the root, un-tiled
         r.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = (world > 1) if args.graph < 0 else bool(args.graph)
-    r.set_graph_mode(use_graph)
-    if world > 1:                     # two trips round the ring before anything is counted: the wave plan has seen a frame and settled
-        for _ in range(2 * F):
-            step()
-        fence()
+    # ---- settle (untimed set-up, like the scene build): the wave plan has sampled frames and re-planned, every stream has run -----------------
+    for _ in range(3 * F):
+        step()
+    fence()
+    # ---- the contract: W untimed warm-up steps, then EXACTLY K steps between two fences ------------------------------------------------------
     for _ in range((args.warmup + B - 1) // B):   # a step() is one launch = B frames
         step()
     fence()
@@ -231,16 +200,26 @@ def main():
     fence()
     wall = time.perf_counter() - t0
     stage, n_timed = r.collect_timings()  # HIP events on the frames' own streams, over the timed frames (last <= 128)
-    # the same kernels with ONE frame on the GPU at a time (not part of the timed region; for the isolated roofline figure)
-    iso = {}
-    r.set_graph_mode(False)   # per-stage events need the individual launches
-    for _ in range(8):
-        step()
+
+    extras = world == 1 and not args.plain
+    # ---- steady state: the same K frames with the ring kept full on both sides (device timestamps behind the last priming frame and behind frame K) ----
+    steady = None
+    if extras and not args.ao:
+        for _ in range(2 * F):
+            r.trace()
+        r.timestamp_mark(0)
+        for _ in range(args.steps):
+            r.trace()
+        r.timestamp_mark(1)
+        for _ in range(F):            # frames behind the mark: the ones in front of it never run on an emptying GPU
+            r.trace()
+        ms = r.timestamp_elapsed_ms()
         fence()
-    iso, _ = r.collect_timings()
-    # SURVEY.md 8d protocol: 100 frames, one on the GPU at a time, each timed by its own HIP events: median / p10 / p90 of the frame span
+        steady = dict(ms_per_step=ms / args.steps, frames=args.steps, protocol=f"{2 * F} priming frames, device timestamp behind the last of them, {args.steps} frames, timestamp, {F} more frames; no host "
+                                                                               "synchronisation in between: what a render loop sees, where `value` (fenced on both sides) also pays the fill and the drain of the ring")
+    # ---- one frame on the GPU at a time, each timed by its own HIP events (median / p10 / p90 over 100 frames) -----------------
     alone = None
-    if world == 1:
+    if extras:
         spans = []
         for _ in range(100):
             step()
@@ -251,7 +230,7 @@ def main():
         if not args.ao and F > 1:
             # the same frame in a context that keeps ONE frame in flight: there the wave plan splits the blocks whose packets crawl (with 16 in
             # flight nothing needs splitting), which is what a caller that wants a frame's latency rather than frames per second would use
-            one = renderer.renderer_for_scene(sc, (W, H), device=local_rank, frames_in_flight=1)
+            one = make_renderer(device=local_rank, frames_in_flight=1)
             one.upload_state()
             for _ in range(24):               # the plan settles within a few frames
                 one.trace(); one.sync()
@@ -268,57 +247,83 @@ def main():
     if not renders:                   # the compositor traced nothing
         st = dict(st, primary_rays=0, shadow_rays=0, ao_rays=0, hit_pixels=0)
     rays_local = st["primary_rays"] + st["shadow_rays"] + st["ao_rays"]
-    # outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit
+
+    # ---- a moving camera: every frame a different pose (no frame in flight shares its BVH path with its neighbours) --------------------------
+    campath = None
+    tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights)) if (args.scene == "sponza" and args.detail == 1.0 and not glb) else None
+    if args.scene == "bistro" and args.detail == 1.0 and (W, H) == (1920, 1080) and not glb:
+        tag = "c4_bistro_like_1080p_1light"
+    if extras and not args.ao and args.camera_path > 0:
+        poses = scenes.camera_path(sc, args.camera_path)
+        cams = [renderer.Camera(p["pos"], p["dir"], W / H, p["fovy"], p["znear"], p["zfar"]) for p in poses]
+        gold_path = os.path.join(ROOT, "tests", "golden", f"{tag}.camera_path_{args.camera_path}.json") if tag else None
+        gold = json.load(open(gold_path)) if gold_path and os.path.exists(gold_path) else None
+        rays_pose = []
+        for i, cam in enumerate(cams):            # every pose once alone: its ray counts, against the oracle's committed ones
+            r._camera = cam
+            r.upload_state(); r.trace(); r.sync()
+            ps = r.stats()
+            if gold:
+                assert (ps["shadow_rays"], ps["hit_pixels"]) == (gold["poses"][i]["shadow_rays"], gold["poses"][i]["hit_pixels"]), f"camera path pose {i}: GPU ray counts differ from the oracle's"
+            rays_pose.append(ps["primary_rays"] + ps["shadow_rays"])
+
+        def moving(n):
+            for i in range(n):
+                r._camera = cams[i % len(cams)]
+                r.upload_state()
+                r.trace()
+        moving(2 * F)
+        fence()
+        c0 = time.perf_counter()
+        moving(args.steps)
+        fence()
+        cwall = time.perf_counter() - c0
+        rays_moved = sum(rays_pose[i % len(cams)] for i in range(args.steps))
+        campath = dict(poses=len(cams), value=rays_moved / cwall / 1e6, unit="Mray/s", ms_per_step=cwall * 1e3 / args.steps, rays_per_frame_min=min(rays_pose), rays_per_frame_max=max(rays_pose),
+                       ray_counts_checked_against_oracle=bool(gold), protocol="art_set_camera before every frame, fenced on both sides like `value`")
+        r._camera = renderer.Camera(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
+        r.upload_state()
+
+    # ---- outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit ---------------------------
     frame_ok = None
     if world > 1 and rank == 0:
-        whole = renderer.renderer_for_scene(sc, (W, H), device=local_rank)
+        got = mg.read_frame()
+        whole = make_renderer(device=local_rank)
         whole.render_frame()
         if packed:   # the assembled frame is the packed colour image: against the single GPU's (art_present packs it, vk_rt_lightning_shadows.rs:152)
             whole.present()
-            frame_ok = bool(np.array_equal(frame[newest[0]].cpu().numpy().view(np.uint32), whole.read_packed()[0]))
+            frame_ok = bool(np.array_equal(got, whole.read_packed()[0]))
         else:
-            frame_ok = bool(np.array_equal(frame[newest[0]].cpu().numpy().view(np.uint32), whole.read_color().view(np.uint32)))
+            frame_ok = bool(np.array_equal(got.view(np.uint32), whole.read_color().view(np.uint32)))
         whole.close()
-    t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["primary_ms"], stage["shadow_ms"], stage["shade_ms"], stage["frame_ms"], iso["primary_ms"], iso["shadow_ms"]],
-                     dtype=torch.float64, device="cuda")
+    counts = mg.counts() if mg else None
     if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["frame_ms"]], dtype=torch.float64)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         wall = float(tmax[0])
         rays_total, shadow_total = float(tsum[1]), float(tsum[2])
-        stage_max = dict(primary_ms=float(tmax[3]), shadow_ms=float(tmax[4]), shade_ms=float(tmax[5]), frame_ms=float(tmax[6]))
-        iso = dict(iso, primary_ms=float(tmax[7]), shadow_ms=float(tmax[8]))
+        stage = dict(stage, frame_ms=float(tmax[3]))
     else:
         rays_total, shadow_total = float(rays_local), float(st["shadow_rays"])
-        stage_max = stage
-    if use_graph:   # no per-stage events inside a replayed graph: price the roofline with the one-frame-alone launches
-        stage_max = dict(iso, frame_ms=stage_max["frame_ms"])
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        if mg:
+            mg.close()
+        dist.destroy_process_group()
         return
 
     ms_per_step = wall * 1e3 / args.steps
     value = rays_total / (wall / args.steps) / 1e6
 
-    # ---- algorithmic bytes: the oracle's canonical-LBVH visit counters for this exact frame
-    tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights))
-    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and args.detail == 1.0 and not args.ao and args.scene == "sponza" else None
+    # ---- the oracle's counters for this exact frame (canonical LBVH: per ray = SURVEY.md 8d's contract figure, per 8x8 packet) ------------------
+    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and not args.ao else None
     ost = json.load(open(fx)) if fx and os.path.exists(fx) else None
 
-    # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame
+    # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame ---------------------------------------
     cpu = None
-    if not args.no_cpu_baseline and not args.ao and world == 1:   # rank 0 at N = 1 only (the contract)
+    if not args.no_cpu_baseline and not args.plain and not args.ao and world == 1:   # rank 0 at N = 1 only (the contract)
         from oracle import orc
-        ncores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
-        try:  # a cgroup CPU quota (e.g. 16 CPUs of a 256-thread host) is the real core budget
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            if q != "max":
-                ncores = max(1, min(ncores, int(int(q) / int(per))))
-        except Exception:
-            pass
+        ncores = host_cores()
         S = orc.Scene(sc.primitives, morton_bits=30)
         cam = orc.camera_from_params(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
         L = orc.make_lights(lights)
@@ -338,51 +343,75 @@ def main():
                    sample=f"the same {W}x{H} frame x {reps} repetitions ({rays1} rays each, {cdt:.1f} s wall) on {ncores} threads; 1-thread figure "
                           f"on rows [{H // 2 - 128},{H // 2 + 128}) ({dt1:.1f} s); scalar C oracle (stands in for the scalar Rust tracer: no Rust "
                           "toolchain in this image), pthreads over 1-row bands")
-        if ost is None:
-            ost = cst
+        if ost is None:     # no committed counters for this workload (other extents, a .glb): the oracle's, counted now
+            pk, _ = orc.packet_stats(S, cam, L, len(lights), W, H, threads=ncores)
+            ost = dict(cst, **pk)
     if ost is not None and world == 1:
         assert ost["shadow_rays"] == st["shadow_rays"] and ost["hit_pixels"] == st["hit_pixels"], \
             f"GPU ray counts differ from the oracle's: {st['shadow_rays']}/{st['hit_pixels']} vs {ost['shadow_rays']}/{ost['hit_pixels']}"
 
+    # ---- roofline (tools/roofline.py re-derives every number below from profiles/) -------------------------------------------------------------
     roof = None
-    if ost is not None:
-        ab = algorithmic_bytes(ost, args.lights)
-        fused = st.get("frame_launches") == 1   # one launch per frame (k_frame): its span is booked on the first stage
-        dom = "frame" if fused else ("primary" if stage_max["primary_ms"] >= stage_max["shadow_ms"] else "shadow")
-        kname = {"frame": "k_frame", "primary": "k_primary", "shadow": "k_shadow"}[dom]
-        dur_ms = stage_max["primary_ms" if fused else f"{dom}_ms"]
-        per_launch = ab[dom] / world * B  # each rank's launch handles 1/world of the rays of B frames
-        achieved = per_launch / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-        iso_ms = iso["primary_ms" if fused else f"{dom}_ms"]
-        traffic, traffic_src = None, None   # PMC counters cannot be read from inside this process: the committed separate-pass measurement of this exact workload
-        tf = os.path.join(ROOT, "profiles", "r1p_pmc_traffic.json")
-        if fused and world == 1 and tag == "c2_sponza_like_1080p_1light" and os.path.exists(tf):
-            tj = json.load(open(tf))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r1p_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH_SIZE + WRITE_SIZE)"
-        roof = dict(bound="hbm", kernel=kname, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=per_launch, kernel_ms=dur_ms, frames_timed=n_timed, frames_in_flight=F,
-                    kernel_ms_alone=iso_ms, frac_alone=(per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms > 0 else None,
-                    frame_algorithmic_bytes=ab["frame"], frame_frac=ab["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    frac_of_measured_stream_peak=achieved / 6300.0,   # 6.3 TB/s: the achievable streaming rate the micro-architecture guide measures
-                   
-                    note="working set (BVH + triangles, ~30 MB) is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes")
+    if ost is not None and st.get("frame_launches") == 1:
+        ab = RL.algorithmic_bytes(ost, len(lights))
+        us = ms_per_step * 1e3 * world                     # machine time one GPU spends per frame: each rank's launch handles 1/world of the frame's rays
+        share = 1.0 / world
+        ab_launch = {k: v * share * B for k, v in ab.items()}   # what ONE launch (B frames of a 1/world share) accounts for
+        cur_path = os.path.join(ROOT, "profiles", "current_pmc.json")
+        cur = json.load(open(cur_path)) if os.path.exists(cur_path) else None
+        usable = bool(cur) and world == 1 and cur.get("workload") == workload_name(sc, glb, W, H, lights, shadow_total, args)
+        pmc = cur["pmc"] if usable else {}
+        fr = RL.fractions(pmc, us * B, ab_launch)
+        kernel_ms = stage["primary_ms"]                    # HIP events on the launch's own stream: one launch's span, overlapped by the others in flight
+        binding = max((k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac") if k in fr), key=lambda k: fr[k], default=None)
+        if binding == "hbm_frac" or binding is None:
+            # no instruction counts for this workload (they come from a committed rocprofv3 --pmc pass): the packet-level algorithmic bytes against HBM
+            roof = dict(bound="hbm", kernel="k_frame", achieved=ab_launch.get("packet", ab_launch["contract"]) / (us * B * 1e-6) / 1e9, peak=RL.HBM_PEAK / 1e9, unit="GB/s")
+            roof["frac"] = roof["achieved"] / roof["peak"]
+        else:
+            per_s = {"valu_issue_frac": RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES, "salu_issue_frac": RL.CUS * RL.CLOCK_HZ}[binding]
+            n_inst = pmc["SQ_INSTS_VALU" if binding == "valu_issue_frac" else "SQ_INSTS_SALU"]
+            roof = dict(bound=binding.replace("_frac", ""), kernel="k_frame", achieved=n_inst / (us * B * 1e-6) / 1e9, peak=per_s / 1e9, unit="G wave-instructions/s", frac=fr[binding])
+        roof.update(
+            traffic=fr.get("hbm_bytes_per_launch"), hbm_frac=fr.get("hbm_frac"), valu_issue_frac=fr.get("valu_issue_frac"), salu_issue_frac=fr.get("salu_issue_frac"),
+            packet_frac=fr.get("packet_frac"), contract_frac=fr.get("contract_frac"), l2_hit_rate=fr.get("l2_hit_rate"), valu_lane_utilisation=fr.get("valu_lane_utilisation"),
+            machine_us_per_launch=us * B, kernel_ms=kernel_ms, launches_overlapping=kernel_ms * 1e3 / (us * B) if us else None, frames_timed=n_timed, frames_in_flight=F * B,
+            algorithmic_bytes_per_launch=dict(packet=ab_launch.get("packet"), contract=ab_launch["contract"], packet_traversal=ab_launch.get("packet_traversal_bytes"),
+                                              shading=ab_launch.get("shading_bytes"), outputs=ab_launch.get("output_bytes")),
+            pmc_source=cur["source"] if usable else None, pmc_kernel_source_sha16=cur.get("kernel_source_sha16") if usable else None,
+            pmc_stale=(cur.get("kernel_source_sha16") != RL.kernel_source_hash()) if usable else None,
+            note="frac = the binding roof: wave-instructions issued per launch (committed rocprofv3 --pmc pass of this workload) over what the chip can issue in the launch's share of "
+                 "machine time (ms_per_step: ~13 launches overlap, so kernel_ms, one launch's own span, is not that share).  hbm_frac = measured HBM traffic (2 x FETCH_SIZE + "
+                 "WRITE_SIZE, Infinity-Cache hits included) / 8 TB/s.  packet_frac = the oracle's packet-level algorithmic bytes (a node / triangle once per 8x8-pixel packet, "
+                 "canonical LBVH) / 8 TB/s.  contract_frac = SURVEY.md 8(d)'s per-ray algorithmic bytes / 8 TB/s: above 1 because the tree (~30 MB) is cache-resident and a packet "
+                 "fetches a node once for 64 rays -- NOT an achieved bandwidth")
 
     line = {
-        "metric": ("Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}") if args.scene == "sponza"
-                  else f"Mray/s (primary+shadow), Bistro-class {W}x{H}",
+        "metric": (("Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}") if args.scene == "sponza"
+                   else f"Mray/s (primary+shadow), Bistro-class {W}x{H}") if not glb else f"Mray/s (primary+shadow), {os.path.basename(glb)} {W}x{H}",
         "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{'bistro_like(seed=0xB157' if args.scene == 'bistro' else 'sponza_like(seed=0x5A0A'}, {sc.n_tris} triangles, {len(sc.primitives)} primitives) {W}x{H}, {len(lights)} light(s), "
-                               f"{int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else ""), "width": W, "height": H, "lights": args.lights,
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else f" (rank 0 composites too and traces {256 - relief}/256 of a share)") + f", RCCL gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F (16 B/px)'} colour tiles to rank 0, {B} frames per launch, {GB * B} frames per gather") + f", {F * B} frames in flight"},
-        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B, "hip_graph_replay": use_graph,
-        "stage_ms": stage_max, "stage_ms_one_frame_alone": iso, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"],
-        "gathered_frame_equals_single_gpu_frame": frame_ok,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real glb" if glb else "synthetic",
+        "config": {"workload": workload_name(sc, glb, W, H, lights, shadow_total, args), "width": W, "height": H, "lights": len(lights),
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else f" (rank 0 composites too and traces {256 - relief}/256 of a share)")
+                                   + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F HDR (16 B/px)'} colour tiles to rank 0, {B} frames per launch, "
+                                     f"{counts['launches_per_gather'] * B} frames per gather") + f", {F * B} frames in flight"},
+        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
+        "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
+        "camera_path": campath,
+        "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": 3 * F * B,
+        "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
         "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(line))
+    if mg:
+        mg.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def workload_name(sc, glb, W, H, lights, shadow_total, args):
+    scene = (f"{os.path.basename(glb)} through art_scene_add_glb (" if glb else ("bistro_like(seed=0xB157, " if args.scene == "bistro" else "sponza_like(seed=0x5A0A, "))
+    return f"{scene}{sc.n_tris} triangles, {len(sc.primitives)} primitives) {W}x{H}, {len(lights)} light(s), {int(shadow_total)} shadow rays/frame" + (f", {args.ao} AO rays per hit pixel" if args.ao else "")
 
 
 if __name__ == "__main__":

@@ -83,6 +83,8 @@ typedef struct ArtConfig {
 #define ART_FLAG_FIXED_WAVES 16u /* every 8x8 pixel block of a frame is traced by one wave, always.  Default: adaptive -- now and then a frame counts the packet
                                   * steps of each of its waves, and blocks whose wave outlasts the launch's fair share of the GPU (a packet crossing dense distant
                                   * geometry) are dealt to 4 or 16 waves in the following frames.  The image does not depend on it. */
+#define ART_FLAG_TILE_OUTPUT 32u /* write the compact tile buffer even when the frame is not sharded (shard_count <= 1: one shard owning every tile): a job of ONE rank
+                                  * then runs the whole art_mgpu_* path -- gather from itself, un-tile -- which is how the RCCL transport is exercised on a one-GPU machine */
 #define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits) */
 
 typedef struct ArtStats {
@@ -240,6 +242,70 @@ int32_t art_untile_gathered_strided(ArtContext *ctx, const void *gathered_dev, u
 /* n_frames frames in ONE launch (the exchange of several ring slots by one collective): frame z's tiles start z * padded tiles into
  * every shard's buffer, its image is written at frames_dev + z * width * height elements */
 int32_t art_untile_gathered_frames(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, uint32_t n_frames, void *frames_dev, void *hip_stream);
+
+/* what a caller that sizes buffers around a context needs to know (the multi-GPU frame below does) */
+typedef struct ArtLayout {
+    uint32_t width, height;
+    uint32_t frames_in_flight;   /* ring slots */
+    uint32_t frames_per_launch;  /* frames one art_trace traces = frames per ring slot */
+    uint32_t shard_rank, shard_count;
+    uint32_t tiles_owned, tiles_padded; /* 32x32 tiles this shard renders; the largest count over all shards (the per-rank gather size) */
+    uint32_t tile_bytes;         /* bytes of one tile in the compact tile buffer: 16384 (RGBA32F) or 4096 (ART_FLAG_PACKED_TILES); 0: the context writes none */
+    uint32_t reserved;
+} ArtLayout;
+int32_t art_get_layout(ArtContext *ctx, ArtLayout *out);
+/* two device timestamps on the frame streams (a measurement aid, e.g. "how long did frames i..j take while the ring stayed full"):
+ * art_timestamp_mark(ctx, 0|1) records mark 0 / 1 behind the most recently traced frame on its stream; art_timestamp_elapsed waits for mark 1
+ * and returns the time between the two. */
+int32_t art_timestamp_mark(ArtContext *ctx, uint32_t which);
+int32_t art_timestamp_elapsed(ArtContext *ctx, float *ms);
+
+/* ---- the sharded frame as one surface (new functionality, BASELINE.json north_star: "frames shard by screen tile across the 8 GPUs of one node
+ * with an RCCL gather of the HDR buffer over xGMI"; the reference renders on one queue of one device, renderer.rs:188) ----------------------------
+ * One process per GPU.  Every process creates its context with the shard art_mgpu_shard gives it, loads the same scene, and creates an ArtMgpu
+ * from the SAME 128-byte id (rank 0 makes it with art_mgpu_unique_id and passes it on by whatever channel the host has: a file, a socket,
+ * MPI, torch.distributed).  Then every rank calls, frame after frame and in the same order,
+ *     art_set_camera(ctx, ..)   (all ranks the same camera)        art_mgpu_trace(mg)
+ * and rank 0 finds the assembled frames behind art_mgpu_flush / art_mgpu_read_frame.  Inside: the rank's share is traced into a ring of
+ * compact tile buffers (4 per ring slot, written in turn); the tiles of `frames_per_gather` launches travel as ONE ncclGather (RCCL, rccl.h:745)
+ * to rank 0 on a stream of their own, submitted by the host once it has SEEN the group's frames finish (art_frames_done: no device-side wait
+ * in front of the collective or of the next frames -- such waits cost the frames in flight their L2 contents, profiles/README.md r1n), and one
+ * launch un-tiles the group on rank 0 (art_untile_gathered_frames).  The payload is the context's tile format: RGBA32F -- the HDR buffer --
+ * by default, B10G11R11 words with ART_FLAG_PACKED_TILES.
+ * RCCL is loaded at art_mgpu_create (dlopen of librccl.so.1: libart itself does not link it); ART_E_NO_DEVICE if it cannot be. */
+typedef struct ArtMgpu ArtMgpu;
+#define ART_MGPU_ID_BYTES 128
+#define ART_MGPU_SHARED 0u     /* rank 0 traces a share AND receives / un-tiles every frame */
+#define ART_MGPU_DEDICATED 1u  /* rank 0 only receives and un-tiles; ranks 1..world-1 trace 1/(world-1) each */
+#define ART_MGPU_RCCL 0u
+#define ART_MGPU_HOST_EXCHANGE 1u /* the collective is the caller's function (rehearsals on one GPU, where RCCL refuses two ranks per device; other fabrics) */
+/* must leave, ordered before anything enqueued on hip_stream afterwards, every rank's `bytes` bytes (rank order) in recv_dev on rank 0
+ * (recv_dev is NULL elsewhere); send_dev is complete when it is called.  Returns 0 or an error the library passes on as ART_E_HIP. */
+typedef int32_t (*ArtMgpuExchangeFn)(void *user, const void *send_dev, size_t bytes, void *recv_dev, void *hip_stream);
+typedef struct ArtMgpuConfig {
+    uint32_t rank, world;        /* this process; processes (= GPUs) of the job */
+    uint32_t compositor;         /* ART_MGPU_SHARED | ART_MGPU_DEDICATED */
+    uint32_t launches_per_gather;/* ring slots per collective; 0 = all of the ring (one collective per trip); rounded down to a divisor of the ring */
+    uint32_t tile_buffers;       /* compact tile buffers per ring slot, 1..8; 0 = 4 */
+    uint32_t transport;          /* ART_MGPU_RCCL | ART_MGPU_HOST_EXCHANGE */
+    ArtMgpuExchangeFn exchange;  /* ART_MGPU_HOST_EXCHANGE only */
+    void *exchange_user;
+} ArtMgpuConfig;
+/* host only: the shard (ArtConfig.shard_rank / shard_count) rank `rank` of `world` creates its context with */
+int32_t art_mgpu_shard(uint32_t rank, uint32_t world, uint32_t compositor, uint32_t *shard_rank, uint32_t *shard_count);
+int32_t art_mgpu_unique_id(uint8_t id[ART_MGPU_ID_BYTES]);
+/* ctx: built scene, final extent, frames in flight and frames per launch (change none of them while the ArtMgpu lives).  Collective: every rank calls it. */
+int32_t art_mgpu_create(ArtContext *ctx, const ArtMgpuConfig *cfg, const uint8_t id[ART_MGPU_ID_BYTES], ArtMgpu **out);
+/* one launch of this rank's share (art_trace: frames_per_launch frames with the context's current camera[s]) + its part of the exchange. */
+int32_t art_mgpu_trace(ArtMgpu *mg);
+/* every frame traced so far has been gathered and (rank 0) un-tiled when it returns.  Collective. */
+int32_t art_mgpu_flush(ArtMgpu *mg);
+/* rank 0, after art_mgpu_flush: the most recently traced frame, assembled (width x height RGBA32F, or B10G11R11 words with packed tiles) */
+int32_t art_mgpu_device_frame(ArtMgpu *mg, void **dev_ptr, size_t *bytes);
+int32_t art_mgpu_read_frame(ArtMgpu *mg, void *dst, size_t bytes);
+/* frames traced / gathers submitted so far, and how many launches travel per gather */
+int32_t art_mgpu_counts(ArtMgpu *mg, uint64_t *launches_traced, uint64_t *gathers, uint32_t *launches_per_gather);
+int32_t art_mgpu_destroy(ArtMgpu *mg);
 
 int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
 /* device time per stage (HIP events on the context's stream) summed over the frames traced since the previous call

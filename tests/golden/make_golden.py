@@ -17,10 +17,15 @@ from oracle import orc  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def render(sc, w, h, lights, threads=8, bits=30):
+def render(sc, w, h, lights, threads=8, bits=30, packets=False):
     S = orc.Scene(sc.primitives, morton_bits=bits)
     cam = orc.camera_from_params(sc.camera["pos"], sc.camera["dir"], w / h, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
-    return S.render(cam, orc.make_lights(lights), len(lights), w, h, threads=threads)
+    out = S.render(cam, orc.make_lights(lights), len(lights), w, h, threads=threads)
+    if packets:   # the same frame counted per 8x8-pixel packet (what bench.py's packet-level roofline figure is priced with)
+        pk, st = orc.packet_stats(S, cam, orc.make_lights(lights), len(lights), w, h, threads=threads)
+        assert st == out["stats"]
+        out["stats"] = dict(out["stats"], **pk)
+    return out
 
 
 def _dump(tag, st):
@@ -35,16 +40,26 @@ def _dump(tag, st):
 def main():
     c = scenes.cornell()
     for n in (64, 256):
-        out = render(c, n, n, c.lights)
+        out = render(c, n, n, c.lights, packets=True)
         np.savez_compressed(os.path.join(HERE, f"cornell_{n}.npz"), color=out["color"], depth=out["depth"], normal=out["normal"])
         json.dump(out["stats"], open(os.path.join(HERE, f"cornell_{n}.stats.json"), "w"), indent=1)
     if "--full" in sys.argv:
         s = scenes.sponza_like()
         for tag, (w, h), lights in (("c2_sponza_like_1080p_1light", (1920, 1080), scenes.sponza_lights(1)),
                                     ("c3_sponza_like_2160p_4lights", (3840, 2160), scenes.sponza_lights(4))):
-            out = render(s, w, h, lights)
+            out = render(s, w, h, lights, packets=True)
             st = dict(out["stats"], width=w, height=h, n_lights=len(lights), n_tris=s.n_tris, morton_bits=30)
             _dump(tag, st)
+        # bench.py --camera-path 8 on config 2: the ray counts of every pose (the GPU's must equal them)
+        S2 = orc.Scene(s.primitives, morton_bits=30)
+        L2 = scenes.sponza_lights(1)
+        poses = []
+        for cp in scenes.camera_path(s, 8):
+            cam = orc.camera_from_params(cp["pos"], cp["dir"], 1920 / 1080, cp["fovy"], cp["znear"], cp["zfar"])
+            st = S2.render(cam, orc.make_lights(L2), 1, 1920, 1080, threads=8)["stats"]
+            poses.append(dict(pos=cp["pos"], dir=cp["dir"], **{k: st[k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "nonfinite_pixels")}))
+        json.dump(dict(config="c2_sponza_like_1080p_1light", poses=poses), open(os.path.join(HERE, "c2_sponza_like_1080p_1light.camera_path_8.json"), "w"), indent=1)
+        print("camera path", [(p["shadow_rays"], p["hit_pixels"]) for p in poses])
         # config 5: 16-spp AO on config 3's extent with config 2's light (the AO pass only reads depth + normal)
         import zlib
         w, h, spp, radius = 3840, 2160, 16, 0.2 * 1.457
@@ -55,7 +70,7 @@ def main():
         _dump("c5_sponza_like_2160p_16spp_ao", dict(st, hit_pixels=out["stats"]["hit_pixels"], ao_crc32=zlib.crc32(ao.tobytes()), ao_mean=float(ao.mean()), width=w, height=h,
                                                     spp=spp, radius=radius, n_tris=s.n_tris, morton_bits=30))
         b = scenes.bistro_like()
-        out = render(b, 1920, 1080, b.lights)
+        out = render(b, 1920, 1080, b.lights, packets=True)
         _dump("c4_bistro_like_1080p_1light", dict(out["stats"], width=1920, height=1080, n_lights=len(b.lights), n_tris=b.n_tris, morton_bits=30))
 
 

@@ -1,0 +1,102 @@
+"""The sharded frame behind the C ABI (include/art.h, art_mgpu_*): host-only pieces on the CPU, the frame itself on the GPU --
+one rank over RCCL (ART_FLAG_TILE_OUTPUT), and 2 / 3 rank jobs of fresh child processes with the collective replaced by a host function
+over gloo (RCCL refuses two ranks on one device; the 8-GPU run is the driver's)."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_mgpu_shard_rule_and_argument_errors():
+    from araytracingjourney_amd import _lib, renderer
+    assert [renderer.mgpu_shard(r, 4) for r in range(4)] == [(0, 4), (1, 4), (2, 4), (3, 4)]
+    assert [renderer.mgpu_shard(r, 4, dedicated=True) for r in range(4)] == [(0, 3), (0, 3), (1, 3), (2, 3)]   # rank 0 composites, ranks 1.. are shards 0..
+    assert renderer.mgpu_shard(0, 1) == (0, 1)
+    L = _lib.load()
+    sr, sc = C.c_uint32(), C.c_uint32()
+    assert L.art_mgpu_shard(4, 4, 0, C.byref(sr), C.byref(sc)) == _lib.ART_E_INVALID          # rank >= world
+    assert L.art_mgpu_shard(0, 1, 1, C.byref(sr), C.byref(sc)) == _lib.ART_E_INVALID          # a dedicated compositor alone
+    assert L.art_mgpu_shard(0, 0, 0, C.byref(sr), C.byref(sc)) == _lib.ART_E_INVALID
+    h = C.c_void_p()
+    assert L.art_mgpu_create(None, None, None, C.byref(h)) == _lib.ART_E_INVALID and b"null" in L.art_last_error()
+    for fn in (L.art_mgpu_trace, L.art_mgpu_flush):
+        assert fn(None) == _lib.ART_E_INVALID
+    assert L.art_mgpu_destroy(None) == _lib.ART_OK
+    assert C.sizeof(_lib.ArtMgpuConfig) == 40 and C.sizeof(_lib.ArtLayout) == 40
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed", [False, True])
+def test_one_rank_job_over_rccl_assembles_the_frame(get_scene, packed):
+    """RCCL inside libart on the one GPU there is: ncclGetUniqueId, ncclCommInitRank (1 rank), ncclGather of every group, un-tile --
+    frames with a moving camera through a ring of 4 slots x 2 frames per launch, 2 launches per gather; every flushed frame equals the
+    unsharded render bit for bit (RGBA32F: the HDR buffer; packed: the B10G11R11 colour image)"""
+    from araytracingjourney_amd import renderer as R, _lib
+    sc = get_scene("sponza_like", 0.12)
+    w, h, F, B = 480, 270, 4, 2
+    whole = R.renderer_for_scene(sc, (w, h))
+    r = R.renderer_for_scene(sc, (w, h), frames_in_flight=F, tile_output=True, packed_tiles=packed)
+    lay = r.layout()
+    assert (lay["shard_count"], lay["tiles_owned"], lay["tiles_padded"], lay["tile_bytes"]) == (1, 15 * 9, 15 * 9, 4096 if packed else 16384)
+    r.set_frames_per_launch(B)
+    r.upload_state()
+    for _ in range(3):
+        r.trace()                                       # frames traced before the job starts: the ring is rewound at create
+    mg = R.MultiGpu(r, 0, 1, unique_id=R.mgpu_unique_id(), launches_per_gather=2)
+    p0 = sc.camera["pos"]
+    for i in range(11):                                 # 11 launches: groups of 2, a trip's wrap, a partial group at the flush
+        cams = [R.Camera((p0[0] + 0.01 * (2 * i + b), p0[1], p0[2] + 0.004 * i), r.camera_mut().dir(), w / h, r.camera_mut().fovy(), 0.1, 1000.0) for b in range(B)]
+        r.set_camera_batch(cams)
+        mg.trace()
+        if i in (0, 4, 10):
+            mg.flush()
+            got = mg.read_frame()
+            whole._camera = cams[-1]
+            whole.render_frame()
+            if packed:
+                whole.present()
+                assert np.array_equal(got, whole.read_packed()[0]), i
+            else:
+                assert np.array_equal(got.view(np.uint32), whole.read_color().view(np.uint32)), i
+    c = mg.counts()
+    assert c["launches_traced"] == 11 and c["launches_per_gather"] == 2 and c["gathers"] >= 6
+    with pytest.raises(_lib.ArtError):                  # a context that writes no tiles cannot take part
+        R.MultiGpu(whole, 0, 1, unique_id=R.mgpu_unique_id())
+    with pytest.raises(_lib.ArtError):                  # nor one whose shard is not the rank's
+        R.MultiGpu(r, 1, 2, unique_id=R.mgpu_unique_id())
+    mg.close(); r.close(); whole.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,extra", [(2, []), (2, ["--gather", "packed"]), (3, ["--compositor", "dedicated"]), (2, ["--ao", "4"]), (3, ["--gather-launches", "3", "--frames-per-launch", "2"])],
+                         ids=["shared", "shared-packed", "dedicated", "ao", "groups-of-3x2"])
+def test_sharded_bench_job_of_child_processes_gathers_the_single_gpu_frame(ranks, extra):
+    """bench.py as the driver launches it (torch.distributed.run, one process per rank), the ranks sharing the one GPU and the collective
+    going through gloo: the C++ loop of art_mgpu_* -- tile-buffer rings, host-gated groups, un-tile -- with real concurrency; rank 0 checks the
+    assembled frame against an unsharded render, bit for bit"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--detail", "0.12",
+           "--width", "640", "--height", "360", "--frames-in-flight", "6"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads(lines[0])
+    assert line["gathered_frame_equals_single_gpu_frame"] is True
+    assert line["n_gpus"] == ranks and line["gathers"] >= 4 and line["value"] > 0
+    assert ("B10G11R11" in line["config"]["parallelism"]) == ("packed" in extra) and ("RGBA32F HDR" in line["config"]["parallelism"]) == ("packed" not in extra)

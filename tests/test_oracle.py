@@ -293,7 +293,8 @@ def test_cornell_golden_fixture(orc, get_scene, n):
     assert_radiance_close(out["color"], gold["color"], rel=1e-5)
     assert_radiance_close(out["depth"], gold["depth"], rel=1e-6, what="depth")
     assert_radiance_close(out["normal"], gold["normal"], rel=1e-5, what="normal")
-    assert out["stats"] == json.load(open(os.path.join(GOLD, f"cornell_{n}.stats.json")))
+    gold_st = json.load(open(os.path.join(GOLD, f"cornell_{n}.stats.json")))
+    assert out["stats"] == {k: v for k, v in gold_st.items() if not k.startswith("packet_")}   # (the packet counts: test_packet_visit_counts)
     assert out["stats"]["nonfinite_pixels"] == 0 and sc.n_tris == 34
 
 
@@ -303,3 +304,26 @@ def test_threads_do_not_change_the_frame(orc, get_scene):
     a = S.render(oracle_camera(orc, sc, 96, 64), L, nl, 96, 64, threads=1)
     b = S.render(oracle_camera(orc, sc, 96, 64), L, nl, 96, 64, threads=5)
     assert np.array_equal(a["color"], b["color"]) and a["stats"] == b["stats"]
+
+
+def test_packet_visit_counts(orc, get_scene):
+    """orc_packet_stats (bench.py's packet-level roofline figure): with 1x1 blocks a packet is one ray, so the counts ARE the per-ray
+    counters; with 8x8 blocks every node / triangle counts once per block, so they lie between per-ray / 64 and per-ray; the frame's
+    per-ray stats do not depend on how it is cut; committed for the Cornell fixture"""
+    sc = get_scene("cornell")
+    S, L, nl = oracle_for(orc, sc)
+    cam = oracle_camera(orc, sc, 64, 64)
+    ref = S.render(cam, L, nl, 64, 64, threads=3)["stats"]
+    one, st1 = orc.packet_stats(S, cam, L, nl, 64, 64, block=(1, 1), threads=3)
+    assert st1 == ref
+    assert (one["packet_nodes_primary"], one["packet_tris_primary"], one["packet_nodes_shadow"], one["packet_tris_shadow"]) == \
+           (ref["n_int_primary"], ref["n_tri_primary"], ref["n_int_shadow"], ref["n_tri_shadow"])
+    pk, st8 = orc.packet_stats(S, cam, L, nl, 64, 64, threads=3)
+    assert st8 == ref and orc.packet_stats(S, cam, L, nl, 64, 64, threads=1)[0] == pk
+    for a, b in (("packet_nodes_primary", "n_int_primary"), ("packet_tris_primary", "n_tri_primary"), ("packet_nodes_shadow", "n_int_shadow"), ("packet_tris_shadow", "n_tri_shadow")):
+        assert ref[b] / 64 <= pk[a] < ref[b], (a, pk[a], ref[b])
+    assert pk["packet_nodes_primary"] >= 64                                   # 64 blocks, each visits at least the root
+    gold = json.load(open(os.path.join(GOLD, "cornell_64.stats.json")))
+    assert dict(ref, **pk) == gold
+    whole, _ = orc.packet_stats(S, cam, L, nl, 64, 64, block=(64, 64))         # the whole frame as one packet: no node twice
+    assert whole["packet_nodes_primary"] <= sc.n_tris - 1 and whole["packet_tris_primary"] <= sc.n_tris
