@@ -15,11 +15,30 @@
  * Because the floating-point slab test is monotone under box inclusion, every BVH whose node boxes
  * contain their triangles' AABBs exactly returns this same answer, whatever its shape or visit order.
  */
-#include "art_oracle.h"
 #include <math.h>
 #include <pthread.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef ORC_F64
+/* liborc_f64.so (tests only): THIS source with every float a double -- arrays, records and arithmetic alike (constants keep their
+ * float-rounded values).  It exists so that the restatement can be compared with the independent numpy one (tests/np_shading.py, fp64)
+ * far below float rounding, which separates transcription errors (the same in both builds) from float32 conditioning (tests/test_oracle.py).
+ * The defines come after the system headers and before art_oracle.h, whose API then takes doubles.  Packing / presentation (bit-level
+ * float formats) are not part of this build. */
+#define float double
+#define fmaf fma
+#define sqrtf sqrt
+#define powf pow
+#define acosf acos
+#define tanf tan
+#define fabsf fabs
+#define fminf fmin
+#define fmaxf fmax
+#define floorf floor
+#define copysignf copysign
+#endif
+#include "art_oracle.h"
 
 /* ------------------------------------------------------------------ small vector maths */
 typedef struct { float x, y, z; } v3;
@@ -122,7 +141,7 @@ int orc_scene_add_primitive(OrcScene *s, const float *verts, uint32_t nv, const 
     Prim *p = &s->prims[s->n_prims];
     memset(p, 0, sizeof(*p));
     p->nv = nv; p->n_idx = n_idx; p->idx_bytes = idx_bytes; p->tw = tw; p->th = th;
-    p->verts = (float *)malloc((size_t)nv * 48); memcpy(p->verts, verts, (size_t)nv * 48);
+    p->verts = (float *)malloc((size_t)nv * 12 * sizeof(float)); memcpy(p->verts, verts, (size_t)nv * 12 * sizeof(float));
     p->idx = (uint32_t *)malloc((size_t)n_idx * 4);
     for (uint32_t i = 0; i < n_idx; i++) {
         uint32_t v = idx_bytes == 2 ? ((const uint16_t *)idx)[i] : ((const uint32_t *)idx)[i];
@@ -131,7 +150,7 @@ int orc_scene_add_primitive(OrcScene *s, const float *verts, uint32_t nv, const 
     }
     size_t tb = (size_t)3 * tw * th * 4;
     p->tex = (uint8_t *)malloc(tb); memcpy(p->tex, tex, tb);
-    memcpy(p->o2w, model3x4, 48);
+    memcpy(p->o2w, model3x4, 12 * sizeof(float));
     affine_inverse(p->o2w, p->w2o);
     p->n_tri = n_idx / 3;
     s->n_prims++;
@@ -182,9 +201,9 @@ int orc_scene_build(OrcScene *s, int morton_bits) {
     for (uint32_t p = 0; p < s->n_prims; p++) { s->prims[p].first_tri = T; T += s->prims[p].n_tri; }
     s->T = T;
     if (T == 0) return -2;
-    s->tv = (float *)malloc((size_t)T * 36);
+    s->tv = (float *)malloc((size_t)T * 9 * sizeof(float));
     s->tri_prim = (uint32_t *)malloc((size_t)T * 4);
-    float *tlo = (float *)malloc((size_t)T * 12), *thi = (float *)malloc((size_t)T * 12);
+    float *tlo = (float *)malloc((size_t)T * 3 * sizeof(float)), *thi = (float *)malloc((size_t)T * 3 * sizeof(float));
     v3 cmin = V3(INFINITY, INFINITY, INFINITY), cmax = V3(-INFINITY, -INFINITY, -INFINITY);
     for (uint32_t p = 0; p < s->n_prims; p++) {
         const Prim *pr = &s->prims[p];
@@ -225,18 +244,18 @@ int orc_scene_build(OrcScene *s, int morton_bits) {
     qsort(ki, T, sizeof(KeyId), cmp_keyid);
     s->leaf_gid = (uint32_t *)malloc((size_t)T * 4);
     s->keys = (uint64_t *)malloc((size_t)T * 8);
-    s->leaf_lo = (float *)malloc((size_t)T * 12);
-    s->leaf_hi = (float *)malloc((size_t)T * 12);
+    s->leaf_lo = (float *)malloc((size_t)T * 3 * sizeof(float));
+    s->leaf_hi = (float *)malloc((size_t)T * 3 * sizeof(float));
     for (uint32_t i = 0; i < T; i++) {
         s->leaf_gid[i] = ki[i].gid; s->keys[i] = ki[i].key;
-        memcpy(s->leaf_lo + 3 * i, tlo + 3 * ki[i].gid, 12);
-        memcpy(s->leaf_hi + 3 * i, thi + 3 * ki[i].gid, 12);
+        memcpy(s->leaf_lo + 3 * i, tlo + 3 * ki[i].gid, 3 * sizeof(float));
+        memcpy(s->leaf_hi + 3 * i, thi + 3 * ki[i].gid, 3 * sizeof(float));
     }
     free(ki); free(tlo); free(thi);
     uint32_t NI = T > 1 ? T - 1 : 0;
     s->child = (int32_t *)malloc((size_t)(NI ? NI : 1) * 8);
-    s->node_lo = (float *)malloc((size_t)(NI ? NI : 1) * 12);
-    s->node_hi = (float *)malloc((size_t)(NI ? NI : 1) * 12);
+    s->node_lo = (float *)malloc((size_t)(NI ? NI : 1) * 3 * sizeof(float));
+    s->node_hi = (float *)malloc((size_t)(NI ? NI : 1) * 3 * sizeof(float));
     int32_t *parent_int = (int32_t *)malloc((size_t)(NI ? NI : 1) * 4);
     int32_t *parent_leaf = (int32_t *)malloc((size_t)T * 4);
     if (NI) parent_int[0] = -1;
@@ -279,7 +298,7 @@ int orc_scene_build(OrcScene *s, int morton_bits) {
                         hi[k] = c == 0 ? chh[k] : fmaxf(hi[k], chh[k]);
                     }
                 }
-                memcpy(s->node_lo + 3 * n, lo, 12); memcpy(s->node_hi + 3 * n, hi, 12);
+                memcpy(s->node_lo + 3 * n, lo, 3 * sizeof(float)); memcpy(s->node_hi + 3 * n, hi, 3 * sizeof(float));
                 n = parent_int[n];
             }
         }
@@ -296,11 +315,11 @@ void orc_scene_get_lbvh(const OrcScene *s, uint32_t *leaf_gid, uint64_t *keys, i
     if (leaf_gid) memcpy(leaf_gid, s->leaf_gid, (size_t)T * 4);
     if (keys) memcpy(keys, s->keys, (size_t)T * 8);
     if (child) memcpy(child, s->child, (size_t)NI * 8);
-    if (node_lo) memcpy(node_lo, s->node_lo, (size_t)NI * 12);
-    if (node_hi) memcpy(node_hi, s->node_hi, (size_t)NI * 12);
-    if (leaf_lo) memcpy(leaf_lo, s->leaf_lo, (size_t)T * 12);
-    if (leaf_hi) memcpy(leaf_hi, s->leaf_hi, (size_t)T * 12);
-    if (tri_verts) memcpy(tri_verts, s->tv, (size_t)T * 36);
+    if (node_lo) memcpy(node_lo, s->node_lo, (size_t)NI * 3 * sizeof(float));
+    if (node_hi) memcpy(node_hi, s->node_hi, (size_t)NI * 3 * sizeof(float));
+    if (leaf_lo) memcpy(leaf_lo, s->leaf_lo, (size_t)T * 3 * sizeof(float));
+    if (leaf_hi) memcpy(leaf_hi, s->leaf_hi, (size_t)T * 3 * sizeof(float));
+    if (tri_verts) memcpy(tri_verts, s->tv, (size_t)T * 9 * sizeof(float));
 }
 
 /* ------------------------------------------------------------------ ray queries */
@@ -1020,6 +1039,7 @@ void orc_render_ao(const OrcScene *s, const OrcCamera *cam, uint32_t w, uint32_t
     if (n_tri) *n_tri = J.n_tri;
 }
 
+#ifndef ORC_F64 /* bit-level float formats: float build only */
 /* ------------------------------------------------------------------ output packing + LPM tonemap */
 /* float32 -> unsigned small float with 5 exponent bits and `mb` mantissa bits, round to nearest even; negatives -> 0, overflow -> +Inf */
 static uint32_t pack_ufloat(float f, int mb) {
@@ -1142,3 +1162,4 @@ void orc_present(const float *color, const uint32_t *ao, uint32_t n, uint32_t *p
         o[2] = (uint8_t)(clampf(c[0], 0.0f, 1.0f) * 255.0f + 0.5f); o[3] = 255;
     }
 }
+#endif /* !ORC_F64 */

@@ -12,18 +12,24 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+# oracle/orc64.py executes this file again with _F64 = True: the same wrapper over liborc_f64.so, the build of art_oracle.c in which every
+# float is a double (arrays, records, arithmetic); packing / presentation are not part of that build
+_F64 = bool(globals().get("_F64", False))
+REAL = np.float64 if _F64 else np.float32
+CREAL = C.c_double if _F64 else C.c_float
+_SO = "liborc_f64.so" if _F64 else os.environ.get("ORC_SO", "liborc.so")   # ORC_SO=liborc_asan.so: the sanitizer build (tests/test_oracle.py)
 
 
 class OrcLight(C.Structure):
-    _fields_ = [("pos", C.c_float * 3), ("type", C.c_uint32), ("dir", C.c_float * 3), ("casts_shadows", C.c_uint32),
-                ("color", C.c_float * 3), ("falloff_distance", C.c_float), ("area_pos2", C.c_float * 3), ("penumbra_angle", C.c_float),
-                ("area_pos3", C.c_float * 3), ("umbra_angle", C.c_float)]
+    _fields_ = [("pos", CREAL * 3), ("type", C.c_uint32), ("dir", CREAL * 3), ("casts_shadows", C.c_uint32),
+                ("color", CREAL * 3), ("falloff_distance", CREAL), ("area_pos2", CREAL * 3), ("penumbra_angle", CREAL),
+                ("area_pos3", CREAL * 3), ("umbra_angle", CREAL)]
 
 
 class OrcCamera(C.Structure):
     _pack_ = 1
-    _fields_ = [("view", C.c_float * 16), ("view_inv", C.c_float * 16), ("proj", C.c_float * 16), ("proj_inv", C.c_float * 16),
-                ("camera_pos", C.c_float * 3)]
+    _fields_ = [("view", CREAL * 16), ("view_inv", CREAL * 16), ("proj", CREAL * 16), ("proj_inv", CREAL * 16),
+                ("camera_pos", CREAL * 3)]
 
 
 class OrcStats(C.Structure):
@@ -34,17 +40,17 @@ class OrcStats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
-assert C.sizeof(OrcLight) == 80 and C.sizeof(OrcCamera) == 268
+assert (C.sizeof(OrcLight), C.sizeof(OrcCamera)) == ((160, 536) if _F64 else (80, 268))
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+    subprocess.check_call(["make", "-s", "-C", _HERE, "asan" if _SO == "liborc_asan.so" else _SO])
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liborc.so")
+        path = os.path.join(_HERE, _SO)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
@@ -56,31 +62,32 @@ def lib():
         L.orc_scene_num_tris.argtypes = [C.c_void_p]
         L.orc_scene_num_tris.restype = C.c_uint32
         L.orc_scene_get_lbvh.argtypes = [C.c_void_p] + [C.c_void_p] * 8
-        L.orc_camera_from_params.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
-        L.orc_light_point.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
-        L.orc_light_spot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.orc_camera_from_params.argtypes = [C.c_void_p, C.c_void_p, CREAL, CREAL, CREAL, CREAL, C.c_void_p]
+        L.orc_light_point.argtypes = [C.c_void_p, C.c_void_p, CREAL, C.c_int, C.c_void_p]
+        L.orc_light_spot.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, CREAL, CREAL, CREAL, C.c_int, C.c_void_p]
         L.orc_light_directional.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-        L.orc_light_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]
+        L.orc_light_area.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, CREAL, CREAL, CREAL, C.c_int, C.c_void_p]
         L.orc_gen_primary.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_trace_closest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_trace_any.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_packet_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
-        L.orc_render_ao.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.orc_pack_b10g11r11.argtypes = [C.c_void_p]; L.orc_pack_b10g11r11.restype = C.c_uint32
-        L.orc_unpack_b10g11r11.argtypes = [C.c_uint32, C.c_void_p]
-        L.orc_pack_f16.argtypes = [C.c_float]; L.orc_pack_f16.restype = C.c_uint16
-        L.orc_lpm_control_block.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_present.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.orc_brdf_terms.argtypes = [C.c_float] * 7 + [C.c_void_p]
+        L.orc_render_ao.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, CREAL, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        if not _F64:
+            L.orc_pack_b10g11r11.argtypes = [C.c_void_p]; L.orc_pack_b10g11r11.restype = C.c_uint32
+            L.orc_unpack_b10g11r11.argtypes = [C.c_uint32, C.c_void_p]
+            L.orc_pack_f16.argtypes = [CREAL]; L.orc_pack_f16.restype = C.c_uint16
+            L.orc_lpm_control_block.argtypes = [C.c_int, CREAL, CREAL, CREAL, CREAL, CREAL, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.orc_present.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_brdf_terms.argtypes = [CREAL] * 7 + [C.c_void_p]
         L.orc_light_eval.argtypes = [C.c_void_p] * 4
         _LIB = L
     return _LIB
 
 
 def _f3(v):
-    return (C.c_float * 3)(*[float(x) for x in v])
+    return (CREAL * 3)(*[float(x) for x in v])
 
 
 def _ptr(a):
@@ -134,11 +141,11 @@ class Scene:
             self.h = None
 
     def add_primitive(self, verts, indices, tex, model):
-        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        verts = np.ascontiguousarray(verts, dtype=REAL)
         indices = np.ascontiguousarray(indices)
         assert indices.dtype in (np.uint16, np.uint32)
         tex = np.ascontiguousarray(tex, dtype=np.uint8)
-        model = np.ascontiguousarray(model, dtype=np.float32)
+        model = np.ascontiguousarray(model, dtype=REAL)
         r = self._L.orc_scene_add_primitive(self.h, _ptr(verts), verts.shape[0], _ptr(indices), indices.size, indices.dtype.itemsize,
                                             _ptr(tex), tex.shape[2], tex.shape[1], _ptr(model))
         if r < 0:
@@ -158,22 +165,22 @@ class Scene:
         T = self.n_tris
         NI = max(T - 1, 0)
         out = dict(leaf_gid=np.zeros(T, np.uint32), keys=np.zeros(T, np.uint64), child=np.zeros((NI, 2), np.int32),
-                   node_lo=np.zeros((NI, 3), np.float32), node_hi=np.zeros((NI, 3), np.float32), leaf_lo=np.zeros((T, 3), np.float32),
-                   leaf_hi=np.zeros((T, 3), np.float32), tri_verts=np.zeros((T, 9), np.float32))
+                   node_lo=np.zeros((NI, 3), REAL), node_hi=np.zeros((NI, 3), REAL), leaf_lo=np.zeros((T, 3), REAL),
+                   leaf_hi=np.zeros((T, 3), REAL), tri_verts=np.zeros((T, 9), REAL))
         self._L.orc_scene_get_lbvh(self.h, *[_ptr(out[k]) for k in ("leaf_gid", "keys", "child", "node_lo", "node_hi", "leaf_lo", "leaf_hi", "tri_verts")])
         return out
 
     def trace_closest(self, rays, mode=0):
-        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        rays = np.ascontiguousarray(rays, dtype=REAL).reshape(-1, 8)
         n = rays.shape[0]
-        tuv = np.zeros((n, 4), np.float32)
+        tuv = np.zeros((n, 4), REAL)
         ids = np.zeros((n, 2), np.int32)
         ni, nt = C.c_uint64(), C.c_uint64()
         self._L.orc_trace_closest(self.h, _ptr(rays), n, mode, _ptr(tuv), _ptr(ids), C.byref(ni), C.byref(nt))
         return tuv, ids, int(ni.value), int(nt.value)
 
     def trace_any(self, rays, mode=0):
-        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        rays = np.ascontiguousarray(rays, dtype=REAL).reshape(-1, 8)
         n = rays.shape[0]
         hit = np.zeros(n, np.uint8)
         ni, nt = C.c_uint64(), C.c_uint64()
@@ -185,12 +192,12 @@ class Scene:
         if reuse and getattr(self, "_bufs", None) is not None and self._bufs[0].shape == (h, w, 4):
             color, depth, normal = self._bufs          # timing loops: do not page-fault 75 MB of fresh output per frame
         else:
-            color = np.zeros((h, w, 4), np.float32)
-            depth = np.zeros((h, w), np.float32)
-            normal = np.zeros((h, w, 4), np.float32)
+            color = np.zeros((h, w, 4), REAL)
+            depth = np.zeros((h, w), REAL)
+            normal = np.zeros((h, w, 4), REAL)
             if reuse:
                 self._bufs = (color, depth, normal)
-        tuv = np.zeros((h, w, 4), np.float32) if debug else None
+        tuv = np.zeros((h, w, 4), REAL) if debug else None
         ids = np.zeros((h, w, 2), np.int32) if debug else None
         sb = np.zeros((h, w), np.uint32) if debug else None
         st = OrcStats()
@@ -212,8 +219,8 @@ def packet_stats(scene: "Scene", cam: OrcCamera, lights, n_lights, w, h, block=(
 
 def render_ao(scene: "Scene", cam: OrcCamera, depth, normal, spp, radius, threads=1):
     h, w = depth.shape
-    depth = np.ascontiguousarray(depth, np.float32)
-    normal = np.ascontiguousarray(normal, np.float32)
+    depth = np.ascontiguousarray(depth, REAL)
+    normal = np.ascontiguousarray(normal, REAL)
     out = np.zeros((h, w), np.uint32)
     nr, ni, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
     lib().orc_render_ao(scene.h, C.byref(cam), w, h, _ptr(depth), _ptr(normal), spp, radius, _ptr(out), C.byref(nr), C.byref(ni), C.byref(nt), threads)
@@ -222,7 +229,7 @@ def render_ao(scene: "Scene", cam: OrcCamera, depth, normal, spp, radius, thread
 
 def present(color, ao=None):
     """-> (packed B10G11R11 colour [h,w] u32, BGRA8 [h,w,4])"""
-    color = np.ascontiguousarray(color, np.float32)
+    color = np.ascontiguousarray(color, REAL)
     h, w = color.shape[:2]
     packed = np.zeros((h, w), np.uint32)
     bgra = np.zeros((h, w, 4), np.uint8)
@@ -232,12 +239,12 @@ def present(color, ao=None):
 
 
 def pack_b10g11r11(rgb):
-    a = np.ascontiguousarray(rgb, np.float32)
+    a = np.ascontiguousarray(rgb, REAL)
     return int(lib().orc_pack_b10g11r11(_ptr(a)))
 
 
 def unpack_b10g11r11(v):
-    out = np.zeros(3, np.float32)
+    out = np.zeros(3, REAL)
     lib().orc_unpack_b10g11r11(int(v), _ptr(out))
     return out
 
@@ -253,20 +260,20 @@ def lpm_control_block(shoulder, soft_gap, hdr_max, exposure, contrast, shoulder_
 
 
 def gen_primary(cam: OrcCamera, w, h):
-    rays = np.zeros((h * w, 8), np.float32)
+    rays = np.zeros((h * w, 8), REAL)
     lib().orc_gen_primary(C.byref(cam), w, h, _ptr(rays))
     return rays
 
 
 def brdf_terms(NdotL, NdotV, NdotH, LdotH, nc_NdotV, nc_NdotL, alpha):
-    out = np.zeros(4, np.float32)
+    out = np.zeros(4, REAL)
     lib().orc_brdf_terms(NdotL, NdotV, NdotH, LdotH, nc_NdotV, nc_NdotL, alpha, _ptr(out))
     return out
 
 
 def light_eval(light: OrcLight, p):
-    nn = np.zeros(3, np.float32)
-    rad = np.zeros(3, np.float32)
-    pp = np.asarray(p, np.float32)
+    nn = np.zeros(3, REAL)
+    rad = np.zeros(3, REAL)
+    pp = np.asarray(p, REAL)
     lib().orc_light_eval(C.byref(light), _ptr(pp), _ptr(nn), _ptr(rad))
     return nn, rad

@@ -177,3 +177,59 @@ def shade_pixel(prim, tri, u, v, cam_view, cam_view_inv, camera_pos, lights, sha
     on[1:] = -on[1:]
     on = normalize(on) * 0.5 + 0.5
     return rho, depth, on, mask
+
+
+# ---- geometry, from the same sources: camera block (vk_camera.rs:104-126, :182-193 with nalgebra's look_at_rh / Perspective3 as
+# SURVEY.md 8a spells them out), ray generation (raytrace.rgen.glsl:78-88), and what traceRayEXT returns for opaque two-sided
+# triangles -- the closest Moeller-Trumbore hit in (tmin, tmax) -- by brute force over every triangle, in float64 ------------------
+def camera_matrices(pos, dir, aspect, fovy, znear, zfar):
+    """-> view, view_inv, proj, proj_inv as 4x4 (row, col) float64"""
+    eye = np.asarray(pos, np.float64)
+    f = normalize(np.asarray(dir, np.float64))
+    up = np.array([0.0, -1.0, 0.0])
+    s = normalize(np.cross(f, up))
+    u = np.cross(s, f)
+    view = np.array([[s[0], s[1], s[2], -s @ eye], [u[0], u[1], u[2], -u @ eye], [-f[0], -f[1], -f[2], f @ eye], [0, 0, 0, 1.0]])
+    c = 1.0 / math.tan(fovy / 2.0)
+    proj = np.array([[c / aspect, 0, 0, 0], [0, c, 0, 0], [0, 0, (zfar + znear) / (znear - zfar), 2.0 * zfar * znear / (znear - zfar)], [0, 0, -1.0, 0]])
+    return view, np.linalg.inv(view), proj, np.linalg.inv(proj)
+
+
+def primary_ray(x, y, w, h, view_inv, proj_inv):
+    pc = np.array([x + 0.5, y + 0.5])
+    d = pc / np.array([w, h], np.float64) * 2.0 - 1.0
+    origin = (view_inv @ np.array([0.0, 0.0, 0.0, 1.0]))[:3]
+    target = proj_inv @ np.array([d[0], d[1], 1.0, 1.0])
+    direction = (view_inv @ np.append(normalize(target[:3]), 0.0))[:3]
+    return origin, direction
+
+
+def world_triangles(primitives):
+    """-> [T, 3, 3] world-space vertices, [T] primitive index, [T] triangle index inside its primitive"""
+    tris, pid, tid = [], [], []
+    for pi, p in enumerate(primitives):
+        M = p.model.astype(np.float64).reshape(3, 4)
+        P = p.verts[:, :3].astype(np.float64) @ M[:, :3].T + M[:, 3]
+        idx = p.indices.astype(np.int64).reshape(-1, 3)
+        tris.append(P[idx]); pid += [pi] * len(idx); tid += list(range(len(idx)))
+    return np.concatenate(tris), np.array(pid), np.array(tid)
+
+
+def closest_hit(o, d, tris, tmin=0.001, tmax=10000.0, eps=0.0):
+    """two-sided Moeller-Trumbore against all triangles at once -> (index into tris or -1, t, u, v, margin): margin = how far inside its
+    triangle the hit lies in barycentric units (a hit within ~1e-6 of an edge may legitimately go to the neighbour in another implementation)"""
+    v0, e1, e2 = tris[:, 0], tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]
+    p = np.cross(d, e2)
+    det = np.einsum("ij,ij->i", e1, p)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / det
+        tv = o - v0
+        u = np.einsum("ij,ij->i", tv, p) * inv
+        q = np.cross(tv, e1)
+        v = (q @ d) * inv
+        t = np.einsum("ij,ij->i", e2, q) * inv
+    ok = (det != 0) & (u >= -eps) & (v >= -eps) & (u + v <= 1 + eps) & (t > tmin) & (t < tmax)   # eps: edges fattened (what makes shared edges watertight)
+    if not ok.any():
+        return -1, tmax, 0.0, 0.0, 0.0
+    i = int(np.argmin(np.where(ok, t, np.inf)))
+    return i, float(t[i]), float(u[i]), float(v[i]), float(min(u[i], v[i], 1.0 - u[i] - v[i]))
