@@ -59,6 +59,12 @@ class ArtGlbCopyInfo(C.Structure):
                                           "image_layers", "reserved")]
 
 
+class ArtTuning(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("frame_form", "tree_builder", "frame_waves", "packet_wide", "primary_walk", "shadow_walk", "ao_walk", "block_order", "fixed_waves",
+                                          "split_fixed_steps", "split_min_steps")] + [("split_alpha", C.c_float)] + \
+               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log")]
+
+
 class ArtLayout(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("width", "height", "frames_in_flight", "frames_per_launch", "shard_rank", "shard_count", "tiles_owned", "tiles_padded",
                                           "tile_bytes", "reserved")]
@@ -135,6 +141,7 @@ SYMBOLS = {
     "art_untile_gathered_frames": (_I32, [_P, _P, _U32, _U32, _U32, _P, _P]),
     "art_get_stats": (_I32, [_P, _P]),
     "art_get_layout": (_I32, [_P, _P]),
+    "art_set_tuning": (_I32, [_P, _P]),
     "art_timestamp_mark": (_I32, [_P, _U32]),
     "art_timestamp_elapsed": (_I32, [_P, _P]),
     "art_mgpu_shard": (_I32, [_U32, _U32, _U32, _P, _P]),

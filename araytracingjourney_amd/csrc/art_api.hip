@@ -42,6 +42,7 @@ template <class T> struct DevBuf {
 
 } // namespace
 
+uint32_t art::g_build_log = 0;
 void art::set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 
 // one frame in flight: its own stream and per-frame buffers, like the reference's FrameData ring (renderer.rs:135, :300-318)
@@ -76,14 +77,14 @@ constexpr uint32_t kMaxFrames = kMaxFrameSlots;
 // reports its packet steps; blocks that took many are dealt to four waves (4x4 pixels each) or sixteen (2x2) from the next plan on, heaviest first.
 // The image does not depend on the plan (closest / any hit are structure- and packet-independent), only the launch's tail does.
 struct WavePlan {
-    bool enabled = true;               // ART_SPLIT=0: every 8x8 block is one wave, always
+    bool enabled = true;               // false (ART_FLAG_FIXED_WAVES, ArtTuning.fixed_waves): every 8x8 block is one wave, always
     // A block is split when its wave makes more packet steps (nodes + triangles visited, all its walks) than the launch's fair share of the
     // machine would take anyway: alpha * (steps of the whole launch) * (launches in flight) / (wave slots of the GPU), at least min_steps.
     // With 16 full frames in flight nothing is split (a straggler hides behind the other launches, and split waves cost more steps in
     // total); one frame at a time, or a 1/8 share of a frame, is where the tail is the launch.
-    float alpha = 0.7f;                // ART_SPLIT_ALPHA (0.5 .. 1 measured alike on 1/8 shares)
-    uint32_t min_steps = 150;          // ART_SPLIT_STEPS
-    uint32_t fixed_steps = 0;          // ART_SPLIT_FIXED: a fixed target instead (experiments)
+    float alpha = 0.7f;                // ArtTuning.split_alpha (0.5 .. 1 measured alike on 1/8 shares)
+    uint32_t min_steps = 150;          // ArtTuning.split_min_steps
+    uint32_t fixed_steps = 0;          // ArtTuning.split_fixed_steps: a fixed target instead (tests, experiments)
     uint32_t in_flight = 1;            // min(frames in flight, hardware queues)
     std::vector<uint32_t> order;       // launch order of the 256-pixel blocks (setup_frame)
     std::vector<uint8_t> level;        // per 8x8 block: 0 = one wave, 1 = four quadrant waves, 2 = sixteen cell waves
@@ -112,12 +113,16 @@ struct ArtContext {
     uint32_t W = 0, H = 0;
     std::vector<HostPrim> prims;
     bool built = false, have_camera = false, frame_ready = false;
-    int frame_waves = 8;      // ART_FRAME_WAVES: occupancy target of the fused frame kernel's instance (6 | 7 | 8)
-    bool fused = true;        // packet frames run as ONE launch (k_frame); ART_FUSED=0: the four staged launches
-    int tree_builder = 3;     // with fast_trace: 3 = binned SAH on the device (art_sahdev.hip), 1 = the same on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip); ART_SAH=<n>
-    bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD / ART_SAH=0: keep the Karras tree)
-    bool packet_wide = false; // ART_PACKET_WIDE=1: packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
-    int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised, 1 quantised binary (measured: profiles/README.md); ART_BVH=<p><s> overrides for A/B runs
+    // which of the equivalent forms this context runs: the defaults are the product, the others are reachable through art_set_tuning only (nothing reads the environment)
+    ArtTuning tuning{};
+    int frame_waves = 8;      // occupancy target of the fused frame kernel's instance (6 | 7 | 8)
+    bool fused = true;        // packet frames run as ONE launch (k_frame); frame_form 1: the four staged launches
+    int tree_builder = 3;     // with fast_trace: 3 = binned SAH on the device (art_sahdev.hip), 1 = the same on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip)
+    bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD: keep the Karras tree)
+    bool packet_wide = false; // packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
+    int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised (measured: profiles/README.md)
+    uint32_t macro = 2;       // XCD-aware launch order: macro-blocks of macro x macro tiles (0: identity)
+    bool ao_entry = true;     // AO rays start at the per-pixel entry node (k_ao_entry)
     // device scene
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
     Lbvh bvh{};
@@ -233,13 +238,12 @@ static void plan_build_items(const WavePlan &P, const std::vector<uint32_t> &cos
 }
 static int32_t plan_reset(ArtContext *c) {
     WavePlan &P = c->plan;
-    static const bool off = std::getenv("ART_SPLIT") && std::atoi(std::getenv("ART_SPLIT")) == 0;
-    P.enabled = !off && !(c->cfg.flags & ART_FLAG_FIXED_WAVES);
-    if (const char *e = std::getenv("ART_SPLIT_STEPS")) { int v = std::atoi(e); if (v > 0) P.min_steps = (uint32_t)v; }
-    if (const char *e = std::getenv("ART_SPLIT_FIXED")) { int v = std::atoi(e); if (v > 0) P.fixed_steps = (uint32_t)v; }
-    if (const char *e = std::getenv("ART_SPLIT_ALPHA")) { float v = (float)std::atof(e); if (v > 0.f) P.alpha = v; }
-    uint32_t hwq = 4; // HIP's default number of hardware queues per process
-    if (const char *e = std::getenv("GPU_MAX_HW_QUEUES")) { int v = std::atoi(e); if (v > 0) hwq = (uint32_t)v; }
+    const ArtTuning &t = c->tuning;
+    P.enabled = !t.fixed_waves && !(c->cfg.flags & ART_FLAG_FIXED_WAVES);
+    P.min_steps = t.split_min_steps ? t.split_min_steps : 150;
+    P.fixed_steps = t.split_fixed_steps;
+    P.alpha = t.split_alpha > 0.f ? t.split_alpha : 0.7f;
+    const uint32_t hwq = t.hw_queues ? t.hw_queues : 4;   // HIP's default number of hardware queues per process; a host that raises GPU_MAX_HW_QUEUES says so in ArtTuning
     P.in_flight = std::max(1u, std::min(c->F, hwq));
     const uint32_t n64 = c->n_local / 64;
     P.level.assign(n64, 0);
@@ -286,7 +290,7 @@ static int32_t plan_poll(ArtContext *c) {
         next = P.level; // does not fit: a more tolerant target
     }
     const bool changed = next != P.level;
-    static const int verbose = std::getenv("ART_SPLIT_LOG") ? std::atoi(std::getenv("ART_SPLIT_LOG")) : 0;
+    const int verbose = (g_build_log & 4u) ? 2 : ((g_build_log & 2u) ? 1 : 0);
     if (verbose > 1) {
         size_t d = 0; uint32_t mx = 0;
         for (size_t b = 0; b < next.size(); b++) { d += next[b] != P.level[b]; mx = std::max(mx, worst[b]); }
@@ -309,8 +313,7 @@ static int32_t plan_poll(ArtContext *c) {
         }
         P.retire_set[P.cur] = true;
         P.cur = other; P.replans++;
-        static const bool log = std::getenv("ART_SPLIT_LOG") != nullptr;
-        if (log) {
+        if (verbose) {
             size_t n1 = 0, n2 = 0;
             for (size_t b = 0; b < P.level.size(); b++) { n1 += P.level[b] == 1; n2 += P.level[b] == 2; }
             std::vector<uint32_t> w(worst); std::sort(w.begin(), w.end());
@@ -357,9 +360,8 @@ int32_t setup_frame(ArtContext *c) {
         // kMacro x kMacro tiles, deal the macro-blocks round-robin to the XCDs (balance: every XCD gets pieces from all over the
         // frame) and order the launch so that XCD x works through ITS macro-blocks: its L2 then holds the BVH of a few screen
         // regions instead of the whole view, in every kernel of the frame and in every frame in flight.  A permutation of the
-        // blocks whatever the hardware's dispatch order is; only the locality depends on it.  ART_MACRO=0: identity.
-        uint32_t macro = 2;
-        if (const char *e = std::getenv("ART_MACRO")) macro = (uint32_t)std::atoi(e);
+        // blocks whatever the hardware's dispatch order is; only the locality depends on it.  (ArtTuning.block_order 1: identity.)
+        const uint32_t macro = c->macro;
         const uint32_t nb = c->n_local / 256;
         std::vector<uint32_t> order(nb);
         for (uint32_t b = 0; b < nb; b++) order[b] = b;
@@ -497,16 +499,9 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     if (e != hipSuccess) { (void)art_destroy(c); return hipfail(e, "art_create"); } // releases the streams and events created so far
     c->W = cfg->width; c->H = cfg->height;
     // the fused packet frame is the default at every ring depth (one frame at a time: 0.575 ms against 0.669 ms for the staged per-ray
-    // kernels, profiles/README.md r1h); ART_BVH=24 selects the per-ray walks (binary for primary rays, 4-wide for shadow rays)
-    if (const char *pw = std::getenv("ART_PACKET_WIDE")) c->packet_wide = std::atoi(pw) != 0;
+    // kernels, profiles/README.md r1h); art_set_tuning selects the other forms
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
     if (cfg->flags & ART_FLAG_DEVICE_TREE) c->tree_builder = 2;
-    if (const char *sh = std::getenv("ART_SAH")) { c->fast_trace = std::atoi(sh) != 0; if (std::atoi(sh) == 2) c->tree_builder = 2; else if (std::atoi(sh) == 3) c->tree_builder = 3; else if (std::atoi(sh) == 1) c->tree_builder = 1; }
-    if (const char *fu = std::getenv("ART_FUSED")) c->fused = std::atoi(fu) != 0;
-    if (const char *fw = std::getenv("ART_FRAME_WAVES")) c->frame_waves = std::atoi(fw);
-    if (const char *w = std::getenv("ART_BVH")) { auto ok = [](char ch) { return ch == '1' || ch == '2' || ch == '4'; };
-        if (ok(w[0]) || w[0] == '8') { c->kind_primary = w[0] - '0'; c->kind_shadow = (ok(w[1]) || w[1] == '8') ? w[1] - '0' : (w[0] == '8' ? 4 : c->kind_primary);
-            c->kind_ao = (w[1] && (ok(w[2]) || w[2] == '8')) ? w[2] - '0' : (c->kind_shadow == 8 ? 4 : c->kind_shadow); } }
     *out = c;
     return ART_OK;
 }
@@ -529,6 +524,32 @@ int32_t art_destroy(ArtContext *c) {
         for (int i = 0; i < 5; i++) if (c->ev[f][i]) (void)hipEventDestroy(c->ev[f][i]);
     for (int i = 0; i < 2; i++) if (c->mark[i]) (void)hipEventDestroy(c->mark[i]);
     delete c;
+    return ART_OK;
+}
+
+int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
+    if (!c || !t) return fail(ART_E_INVALID, "art_set_tuning: null argument");
+    auto walk_ok = [](uint32_t k) { return k == 0 || k == 2 || k == 4 || k == 8; };
+    if (t->frame_form > 2 || t->tree_builder > 1 || (t->frame_waves != 0 && (t->frame_waves < 6 || t->frame_waves > 8)) || !walk_ok(t->primary_walk) || !walk_ok(t->shadow_walk) || !walk_ok(t->ao_walk))
+        return fail(ART_E_INVALID, "art_set_tuning: frame_form 0..2, tree_builder 0..1, frame_waves 0|6|7|8, walks 0|2|4|8");
+    int32_t r = use_device(c); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    drop_graphs(c);
+    c->tuning = *t;
+    c->fused = t->frame_form == 0;
+    c->kind_primary = t->frame_form == 2 ? 2 : 8; c->kind_shadow = t->frame_form == 2 ? 4 : 8; c->kind_ao = 4;   // per-ray frames: binary nodes for primary rays, 4-wide for shadow rays
+    if (t->primary_walk) c->kind_primary = (int)t->primary_walk;
+    if (t->shadow_walk) c->kind_shadow = (int)t->shadow_walk;
+    if (t->ao_walk) c->kind_ao = (int)t->ao_walk;
+    c->fast_trace = !(c->cfg.flags & ART_FLAG_FAST_BUILD);
+    c->tree_builder = (c->cfg.flags & ART_FLAG_DEVICE_TREE) ? 2 : (t->tree_builder == 1 ? 1 : 3);
+    c->frame_waves = t->frame_waves ? (int)t->frame_waves : 8;
+    c->packet_wide = t->packet_wide != 0;
+    c->macro = t->block_order == 0 ? 2u : (t->block_order == 1 ? 0u : t->block_order);
+    c->ao_entry = t->ao_entry_off == 0;
+    set_trace_tune(t->trace_chunk, t->trace_refill, t->trace_blocks);
+    g_build_log = t->log;
+    c->built = false; c->frame_ready = false; c->traced = false;   // the tree and the frame layout are made again with the new choices
     return ART_OK;
 }
 
@@ -780,7 +801,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p; a.fold_counters = c->kind_primary == 8 && c->kind_shadow == 8 && c->n_local != 0;
-    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.qnodes = c->bvh.qnodes; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
+    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
     a.n_lights = (uint32_t)c->lights.size();
     if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
@@ -825,10 +846,9 @@ int32_t art_trace(ArtContext *c) {
             (void)hipGraphDestroy(g);
             if (e != hipSuccess) { S.graph = nullptr; return hipfail(e, "hipGraphInstantiate"); }
         }
-        static const bool lean = std::getenv("ART_LEAN_EVENTS") != nullptr; // experiment: fewer packets per frame
-        if (!lean) for (int i = 0; i < 4; i++) HIPC(hipEventRecord(ev[i], s));
+        for (int i = 0; i < 4; i++) HIPC(hipEventRecord(ev[i], s));
         HIPC(hipGraphLaunch(S.graph, s));
-        if (!lean) HIPC(hipEventRecord(ev[4], s));
+        HIPC(hipEventRecord(ev[4], s));
         HIPC(hipEventRecord(S.done, s)); S.done_alias = nullptr;
         S.ao_valid = false; S.presented = false;
         c->last = k; c->frame_no++; c->traced = true;
@@ -897,8 +917,7 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     FrameArgs a = make_frame_args(c, S);
     HIPC(hipMemsetAsync(S.d_counters.p + 64 + 16 * 32, 0, 8 * 32 * 4, s)); // the AO launch's work cursors
     HIPC(hipEventRecord(S.ao_ev[0], s));
-    static const bool ao_entry = !std::getenv("ART_AO_ENTRY") || std::atoi(std::getenv("ART_AO_ENTRY")) != 0;
-    if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, ao_entry ? S.d_ao_entry.p : nullptr, S.d_ao.p, lut, s);
+    if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, c->ao_entry ? S.d_ao_entry.p : nullptr, S.d_ao.p, lut, s);
     HIPC(hipEventRecord(S.ao_ev[1], s));
     HIPC(hipEventRecord(S.done, s)); S.done_alias = nullptr;
     HIPC(hipGetLastError());
@@ -976,7 +995,6 @@ int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_p
 int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p + (size_t)c->read_b * c->W * c->H; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
 int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->slot[c->last].d_normal.p + (size_t)c->read_b * c->W * c->H; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 
-static const int g_relief_env_applied = [] { if (const char *e = std::getenv("ART_ROOT_RELIEF")) { int v = std::atoi(e); if (v >= 0 && v <= 255) shard_root_relief() = (uint32_t)v; } return 0; }();
 int32_t art_set_root_relief(uint32_t per_256) {
     if (per_256 > 255) return fail(ART_E_INVALID, "art_set_root_relief: 0..255");
     shard_root_relief() = per_256;
@@ -1273,7 +1291,7 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     if (e == hipSuccess && (sync_all(c) != ART_OK || ensure_wide(c, true) != ART_OK)) e = hipErrorUnknown;
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
-    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_primary == 8 ? 2 : c->kind_primary}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.tris, c->kind_primary == 8 ? 2 : c->kind_primary}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);
@@ -1302,7 +1320,7 @@ int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit
     if (e == hipSuccess && (sync_all(c) != ART_OK || ensure_wide(c, true) != ART_OK)) e = hipErrorUnknown;
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
-    if (e == hipSuccess) { launch_query_any(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.qnodes, c->bvh.tris, c->kind_shadow == 8 ? 4 : c->kind_shadow}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) { launch_query_any(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.tris, c->kind_shadow == 8 ? 4 : c->kind_shadow}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_r); (void)hipFree(d_h);

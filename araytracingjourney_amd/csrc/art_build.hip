@@ -308,49 +308,8 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
     return hipSuccess;
 }
 
-// quantised binary nodes, one thread per internal node (device; double arithmetic only for the exact floor/ceil)
-__global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t T, const int32_t *__restrict__ child, const float *__restrict__ node_lo, const float *__restrict__ node_hi,
-                                                     const float *__restrict__ leaf_lo, const float *__restrict__ leaf_hi, DevNodeQ *__restrict__ out) {
-    uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    int c0, c1; bool absent1 = false;
-    if (T == 1) { if (n != 0) return; c0 = ~0; c1 = ~0; absent1 = true; }
-    else { if (n >= T - 1) return; c0 = child[2 * n]; c1 = child[2 * n + 1]; }
-    const float *l0 = c0 < 0 ? leaf_lo + 3 * (size_t)(~c0) : node_lo + 3 * (size_t)c0, *h0 = c0 < 0 ? leaf_hi + 3 * (size_t)(~c0) : node_hi + 3 * (size_t)c0;
-    const float *l1 = c1 < 0 ? leaf_lo + 3 * (size_t)(~c1) : node_lo + 3 * (size_t)c1, *h1 = c1 < 0 ? leaf_hi + 3 * (size_t)(~c1) : node_hi + 3 * (size_t)c1;
-    uint32_t qb[12]; // lo0 xyz, hi0 xyz, lo1 xyz, hi1 xyz
-    uint32_t eb[3]; float org[3];
-    for (int k = 0; k < 3; k++) {
-        float o = fminf(l0[k], l1[k]), top = fmaxf(h0[k], h1[k]);
-        double ext = (double)top - (double)o;
-        int e = ext > 0.0 ? ilogb(ext) - 8 : -100; // 2^(e+8) <= ext: start below and walk up
-        if (e < -100) e = -100;
-        float sc;
-        for (;;) { sc = ldexpf(1.0f, e); if (fmaf(255.0f, sc, o) >= top) break; e++; }
-        org[k] = o; eb[k] = (uint32_t)(e + 127);
-        const float v[4] = {l0[k], h0[k], l1[k], h1[k]};
-        for (int j = 0; j < 4; j++) {
-            double rel = ((double)v[j] - (double)o) / (double)sc;
-            int q = (j & 1) ? (int)ceil(rel) : (int)floor(rel);
-            q = q < 0 ? 0 : (q > 255 ? 255 : q);
-            if (j & 1) { while (q < 255 && fmaf((float)q, sc, o) < v[j]) q++; }
-            else { while (q > 0 && fmaf((float)q, sc, o) > v[j]) q--; }
-            qb[(j >> 1) * 6 + (j & 1) * 3 + k] = (uint32_t)q;
-        }
-    }
-    uint32_t gamma = (uint32_t)(c0 < 0 ? ~c0 : c0);
-    uint32_t flags = (c0 < 0 ? 1u : 0u) | (c1 < 0 ? 2u : 0u) | (absent1 ? 4u : 0u);
-    DevNodeQ d;
-    d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
-    d.exps = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (flags << 24);
-    d.q[0] = qb[0] | (qb[1] << 8) | (qb[2] << 16) | (qb[3] << 24);
-    d.q[1] = qb[4] | (qb[5] << 8) | (qb[6] << 16) | (qb[7] << 24);
-    d.q[2] = qb[8] | (qb[9] << 8) | (qb[10] << 16) | (qb[11] << 24);
-    d.gamma = gamma;
-    out[n] = d;
-}
-
 void lbvh_free(Lbvh &l) {
-    hipFree(l.wide); hipFree(l.widef); hipFree(l.qnodes); hipFree(l.shade_tris);
+    hipFree(l.wide); hipFree(l.widef); hipFree(l.shade_tris);
     hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
     hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim); hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi);
     l = Lbvh{};
@@ -376,7 +335,6 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
         HIPQ(hipMalloc(&out.leaf_lo, (size_t)T * 12)); HIPQ(hipMalloc(&out.leaf_hi, (size_t)T * 12));
         HIPQ(hipMalloc(&out.tris, (size_t)T * sizeof(DevTri))); HIPQ(hipMalloc(&out.nodes, (size_t)NI * sizeof(DevNode)));
         HIPQ(hipMalloc(&out.tri_prim, (size_t)T * 4));
-        HIPQ(hipMalloc(&out.qnodes, (size_t)NI * sizeof(DevNodeQ)));
         HIPQ(hipMalloc(&out.shade_tris, (size_t)T * sizeof(DevShadeTri)));
         const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
         HIPQ(hipMemcpyAsync(cb, init, 24, hipMemcpyHostToDevice, s));
@@ -393,7 +351,6 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
             k_refit<<<GT, B, 0, s>>>(T, out.child, parent_int, parent_leaf, out.leaf_lo, out.leaf_hi, out.node_lo, out.node_hi, arrive);
         }
         k_emit_nodes<<<(NI + B - 1) / B, B, 0, s>>>(T, out.child, out.node_lo, out.node_hi, out.leaf_lo, out.leaf_hi, out.nodes);
-        k_emit_qnodes<<<(NI + B - 1) / B, B, 0, s>>>(T, out.child, out.node_lo, out.node_hi, out.leaf_lo, out.leaf_hi, out.qnodes);
         HIPQ(hipGetLastError());
         HIPQ(hipStreamSynchronize(s));
         return hipSuccess;
@@ -511,7 +468,7 @@ hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out) {
     *depth_out = 0;
     if (T < 3) return hipSuccess;
     const uint32_t NI = T - 1, B = 256;
-    static const uint32_t radius = [] { const char *e = getenv("ART_PLOC_RADIUS"); int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : kPlocRadius); }();
+    const uint32_t radius = kPlocRadius; // radius 2 .. 128 all measured within 15.4-15.9 Gray/s (profiles/README.md)
     float *lo[2] = {nullptr, nullptr}, *hi[2] = {nullptr, nullptr};
     int32_t *ref[2] = {nullptr, nullptr};
     uint32_t *cnt[2] = {nullptr, nullptr}, *left_leaves = nullptr, *place = nullptr; int32_t *child_t = nullptr; float *lo_t = nullptr, *hi_t = nullptr;

@@ -36,12 +36,6 @@ struct alignas(16) DevNode { float4 q[4]; };
 //   child[c] >= 0: wide node index; < 0: ~position of a triangle in leaf order
 struct alignas(16) DevNode4 { float ox, oy, oz; uint32_t exps; uint32_t q[6]; uint32_t spare[2]; int32_t child[4]; };
 static_assert(sizeof(DevNode4) == 64, "DevNode4 layout");
-// 32-byte binary node with 8-bit quantised child boxes: half the bytes of DevNode through the vector-memory path.
-//   w0 = origin.xyz | ex | ey<<8 | ez<<16 | flags<<24   (flags: 1 child0 is a leaf, 2 child1 is a leaf, 4 child1 absent)
-//   w1 = lo0x lo0y lo0z hi0x | hi0y hi0z lo1x lo1y | lo1z hi1x hi1y hi1z | gamma
-//   Karras' children are gamma and gamma+1 (as node indices or leaf positions), so one word addresses both.
-struct alignas(16) DevNodeQ { float ox, oy, oz; uint32_t exps; uint32_t q[3]; uint32_t gamma; };
-static_assert(sizeof(DevNodeQ) == 32, "DevNodeQ layout");
 // 128-byte 4-wide node with full-precision child boxes, for the packet walk: a wave's iteration is bound by the latency of one
 // dependent (scalar) node fetch, so halving the number of iterations matters more than the bytes.
 //   box[c] = lo.xyz hi.xyz of child c (an absent child has lo = +3e38, hi = -3e38 and is masked by `valid`)
@@ -82,7 +76,6 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevNode4 *wide;         // [n_wide] collapsed + quantised traversal structure
     DevNodeW *widef;        // [n_wide] the same topology with float boxes (packet walk)
     uint32_t n_wide;
-    DevNodeQ *qnodes;       // [max(T-1,1)] quantised binary nodes
     DevShadeTri *shade_tris; // [T] leaf order
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
@@ -99,6 +92,8 @@ hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out);
 // the binned SAH of sah_build, level by level on the device (art_sahdev.hip)
 hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s);
 void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s);
+void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks); // art_trace.hip: persistent tracer presets (0 = default)
+extern uint32_t g_build_log;   // art_api.hip: art_set_tuning log bits (1 build phases, 2 wave plan) -- stderr, off by default
 void lbvh_free(Lbvh &l);
 
 // float32 -> unsigned small float (5 exponent bits, MB mantissa bits), round to nearest even; negatives -> 0, overflow -> +Inf
@@ -137,10 +132,10 @@ struct FrameArgs {
     const uint32_t *tile_list; uint32_t n_tiles_owned; uint32_t tiles_x; // owned 32x32 tiles
     uint32_t n_local;          // n_tiles_owned * 1024
     const uint32_t *block_order; // [n_local / 256] launch block -> 256-pixel block (XCD-aware order, art_api.hip setup_frame)
-    const DevNode *nodes; const DevNode4 *wide; const DevNodeW *widef; const DevNodeQ *qnodes; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
+    const DevNode *nodes; const DevNode4 *wide; const DevNodeW *widef; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
     bool packet_wide;          // packet walks use the 128-byte 4-wide nodes (else the binary nodes)
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
-    int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised, 1 binary quantised
+    int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised
     // the light records travel BY VALUE with every launch, like the camera block: a frame in flight can never see a later art_set_lights
     // (a device-side table, however it is double-buffered, is overwritten while launches queued 16 frames ago still hold its address)
     ArtLight lights[kMaxLights]; uint32_t n_lights;
@@ -176,7 +171,7 @@ bool launch_frame(const FrameArgs &a, hipStream_t s);      // the fused frame: p
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s); // out[0] += shadow rays, out[1] += hit pixels
 // ambient occlusion on the frame's depth/normal outputs; occl: n_local*spp bytes; lut: spp+1 output values; cursors at counters[64+512..] are reused (queries never overlap a frame)
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, int *entry, uint32_t *ao, const uint32_t *lut, hipStream_t s); // entry: n_local ints of scratch (per-pixel start node) or null
-struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris; int kind; }; // kind: 2 | 4 | 1
+struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevTri *tris; int kind; }; // kind: 2 | 4
 void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);
 // per-frame counter block (zeroed every frame): [64..] primary cursors, [64+256..] shadow cursors, [64+512..] query cursors,

@@ -11,7 +11,6 @@
 //   accept(tri, ray) := slab(AABB(tri), ray) passes AND Moller-Trumbore hits with tmin < t < tmax
 //   t_eff := max(t_MT, t_entry(AABB(tri)));  closest := argmin (t_eff, gid);  any := exists accept
 #include "art_internal.h"
-#include <cstdlib>
 #include <type_traits>
 
 namespace art {
@@ -107,21 +106,19 @@ constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (6
 constexpr int kBlock = 256;
 // tunables of the persistent tracer: {chunk, refill, blocks}.  Measured on config 2 (profiles/README.md):
 // one frame at a time is bound by the slowest wave's critical path -> small chunks, more waves; several frames in flight
-// are throughput-bound -> fewer cursor atomics, fewer resident waves.  ART_CHUNK / ART_REFILL / ART_BLOCKS
-// in the environment override both presets (sweeps).
+// are throughput-bound -> fewer cursor atomics, fewer resident waves.  art_set_tuning (trace_chunk / trace_refill / trace_blocks)
+// overrides both presets for sweeps.
 struct Tune { uint32_t chunk, refill, blocks; };
 static Tune g_tune[2] = {{64, 12, 1536}, {128, 24, 1024}};
-static bool g_tune_init = false;
-static const Tune &tune(bool pipelined) {
-    if (!g_tune_init) {
-        for (int k = 0; k < 2; k++) {
-            if (const char *e = getenv("ART_CHUNK")) { int v = atoi(e); if (v >= 64 && v <= 65536) g_tune[k].chunk = (uint32_t)v; }
-            if (const char *e = getenv("ART_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) g_tune[k].refill = (uint32_t)v; }
-            if (const char *e = getenv("ART_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 16384) g_tune[k].blocks = (uint32_t)v; }
-        }
-        g_tune_init = true;
+static const Tune &tune(bool pipelined) { return g_tune[pipelined ? 1 : 0]; }
+void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks) {
+    static const Tune preset[2] = {{64, 12, 1536}, {128, 24, 1024}};
+    for (int k = 0; k < 2; k++) {
+        g_tune[k] = preset[k];
+        if (chunk >= 64 && chunk <= 65536) g_tune[k].chunk = chunk;
+        if (refill >= 1 && refill <= 64) g_tune[k].refill = refill;
+        if (blocks >= 1 && blocks <= 16384) g_tune[k].blocks = blocks;
     }
-    return g_tune[pipelined ? 1 : 0];
 }
 constexpr int kCursorStride = 32; // one 128-byte line per XCD cursor
 
@@ -204,26 +201,6 @@ template <bool ANY> struct Trav : TravBase<ANY, kOvfStack> {
         bool h0 = slab(this->r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, this->tbest, te0);
         bool h1 = slab(this->r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, this->tbest, te1);
         return this->descend2(h0, h1, te0, te1, __float_as_int(q3.x), __float_as_int(q3.y), lds, ovf);
-    }
-};
-
-// 32-byte quantised binary nodes (DevNodeQ): a child box is dequantised (origin + q*scale, one exact fma) and goes through
-// the same slab(), which keeps the monotonicity argument of DESIGN.md 1.1 intact
-template <bool ANY> struct TravQ : TravBase<ANY, kOvfStack> {
-    using Nodes = const DevNodeQ *;
-    __device__ __forceinline__ bool step_internal(Nodes qn, int *lds, int *ovf) {
-        const uint4 *nq = reinterpret_cast<const uint4 *>(qn + this->cur);
-        uint4 a = nq[0], b = nq[1];
-        float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
-        float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
-        uint32_t flags = a.w >> 24;
-        int c0 = (flags & 1u) ? (int)~b.w : (int)b.w, c1 = (flags & 2u) ? (int)~(b.w + 1u) : (int)(b.w + 1u);
-        float te0, te1;
-        bool h0 = slab(this->r, fmaf((float)(b.x & 255u), sx, ox), fmaf((float)((b.x >> 8) & 255u), sy, oy), fmaf((float)((b.x >> 16) & 255u), sz, oz),
-                       fmaf((float)(b.x >> 24), sx, ox), fmaf((float)(b.y & 255u), sy, oy), fmaf((float)((b.y >> 8) & 255u), sz, oz), this->tbest, te0);
-        bool h1 = slab(this->r, fmaf((float)((b.y >> 16) & 255u), sx, ox), fmaf((float)(b.y >> 24), sy, oy), fmaf((float)(b.z & 255u), sz, oz),
-                       fmaf((float)((b.z >> 8) & 255u), sx, ox), fmaf((float)((b.z >> 16) & 255u), sy, oy), fmaf((float)(b.z >> 24), sz, oz), this->tbest, te1) && !(flags & 4u);
-        return this->descend2(h0, h1, te0, te1, c0, c1, lds, ovf);
     }
 };
 
@@ -547,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_ao_entry(FrameArgs a, const DevNode4
 // what a persistent tracing wave reads its rays from and writes its results to
 enum { MODE_PRIMARY = 0, MODE_SHADOW = 1, MODE_QUERY_CLOSEST = 2, MODE_QUERY_ANY = 3, MODE_AO = 4 };
 struct TraceArgs {
-    const DevNode *nodes; const DevNode4 *wide; const DevNodeQ *qnodes; const DevTri *tris;
+    const DevNode *nodes; const DevNode4 *wide; const DevTri *tris;
     uint32_t total;          // candidate slots
     uint32_t leaf_batch;     // lanes that must wait on a triangle before the wave runs the triangle test
     uint32_t chunk, refill;  // slots a wave takes from a cursor at a time; idle lanes that trigger a refill (Aila & Laine 2009, dynamic fetch)
@@ -583,7 +560,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
     uint32_t shards_left = 8;
     uint32_t cur = 0, end = 0; // wave-uniform: the unread part of this wave's chunk
     bool exhausted = false, active = false;
-    typename std::conditional<WIDTH == 4, Trav4<ANY>, typename std::conditional<WIDTH == 1, TravQ<ANY>, Trav<ANY>>::type>::type tr;
+    typename std::conditional<WIDTH == 4, Trav4<ANY>, Trav<ANY>>::type tr;
     uint32_t slot = 0, traced = 0;
     for (;;) {
         uint64_t idle = __ballot(!active);
@@ -660,7 +637,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
         bool done = false;
         if (active && tr.cur >= 0) {
             if constexpr (WIDTH == 4) done = tr.step_internal(a.wide, lds, ovf);
-            else if constexpr (WIDTH == 1) done = tr.step_internal(a.qnodes, lds, ovf);
             else done = tr.step_internal(a.nodes, lds, ovf);
         }
         // ... and the triangle tests only once enough lanes wait on one (or nobody can move without it)
@@ -1094,13 +1070,12 @@ template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipeli
     const Tune &t = tune(pipelined);
     a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = 1; // batching was measured slower at every threshold (profiles/README.md)
     if (kind == 4) k_trace<MODE, 4><<<nb, kBlock, 0, s>>>(a);
-    else if (kind == 1) k_trace<MODE, 1><<<nb, kBlock, 0, s>>>(a);
     else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);
 }
 void launch_primary(const FrameArgs &f, hipStream_t s) {
     if (f.trace_kind[0] == 8) { if (f.packet_wide) k_packet<PK_PRIMARY, true><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); else k_packet<PK_PRIMARY, false><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); return; } // packet walk over the binary nodes
     TraceArgs a{};
-    a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
+    a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
     launch_trace<MODE_PRIMARY>(a, f.trace_kind[0], f.pipelined, s);
 }
@@ -1109,7 +1084,7 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     if (f.n_lights == 0) return;
     if (f.trace_kind[1] == 8) { if (f.packet_wide) k_packet<PK_SHADOW, true><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); else k_packet<PK_SHADOW, false><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); return; }
     TraceArgs a{};
-    a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
+    a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
@@ -1142,13 +1117,13 @@ void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<block
 void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s) {
     if (!n) return;
     TraceArgs a{};
-    a.nodes = b.nodes; a.wide = b.wide; a.qnodes = b.qnodes; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.hits = hits;
+    a.nodes = b.nodes; a.wide = b.wide; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.hits = hits;
     launch_trace<MODE_QUERY_CLOSEST>(a, b.kind, false, s);
 }
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s) {
     if (!n) return;
     TraceArgs a{};
-    a.nodes = b.nodes; a.wide = b.wide; a.qnodes = b.qnodes; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
+    a.nodes = b.nodes; a.wide = b.wide; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
     launch_trace<MODE_QUERY_ANY>(a, b.kind, false, s);
 }
 // AO resolve: occluded count -> uint(pow(visibility, 2.2) * 255 + 0.5) through a host-built table; 255 where nothing was hit
@@ -1172,7 +1147,7 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, in
         return;
     }
     TraceArgs a{};
-    a.nodes = f.nodes; a.wide = f.wide; a.qnodes = f.qnodes; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
+    a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
     if (f.trace_kind[2] == 4 && entry) { // one entry node per pixel for its spp rays
         k_ao_entry<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, f.wide, radius, entry);

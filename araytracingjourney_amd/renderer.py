@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -212,7 +213,7 @@ class Model:
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
-    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, device_tree=False, fixed_waves=False, tile_output=False):
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, device_tree=False, fixed_waves=False, tile_output=False, tuning=None):
         self._L = _lib.load()
         w, h = extent
         cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
@@ -220,6 +221,12 @@ class Renderer:
                         frames_in_flight=frames_in_flight)
         self._ctx = C.c_void_p()
         check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))
+        # The host tells the library how many hardware queues it asked HIP for (libart itself reads no environment variable); `tuning` picks one of the
+        # equivalent forms of the path (ArtTuning: staged / per-ray frames, host-built tree, wave-plan targets ...) -- tests and sweeps only.
+        t = _lib.ArtTuning(**dict(tuning or {}))
+        if not t.hw_queues:
+            t.hw_queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
+        check(self._L.art_set_tuning(self._ctx, C.byref(t)))
         self.extent = (w, h)
         self.shard = shard
         self.packed_tiles = packed_tiles

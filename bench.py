@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plain", action="store_true", help="only the contract's timed region (profiling passes: no single-frame spans, no steady-state / camera-path legs, no CPU baseline)")
+    ap.add_argument("--tuning", default="", help="A/B sweeps: ArtTuning fields for the benchmarked context, key=value[,key=value...] (include/art.h: frame_form, tree_builder, frame_waves, "
+                                                 "block_order, split_alpha ...); the default -- none -- is the product")
     ap.add_argument("--camera-path", type=int, default=8, help="N = 1 extra leg: the camera moves every frame along a closed path of this many poses (0 = skip); ray counts of every pose "
                                                                "are checked against the oracle's committed ones")
     ap.add_argument("--gather-launches", type=int, default=0, help="N>1: ring slots (launches) per RCCL gather; 0 = the whole ring (the slots are contiguous, so a group travels as one message per peer)")
@@ -135,7 +137,8 @@ def main():
             return r_
         return renderer.renderer_for_scene(sc, (W, H), **kw)
 
-    r = make_renderer(device=local_rank, shard=shard, frames_in_flight=F, packed_tiles=packed)
+    tuning = {k: (float(v) if k == "split_alpha" else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)} or None
+    r = make_renderer(device=local_rank, shard=shard, frames_in_flight=F, packed_tiles=packed, tuning=tuning)
     B = 1                             # frames per launch
     if world > 1 and not args.ao:
         B = args.frames_per_launch if args.frames_per_launch > 0 else next(b for b in (4, 2, 1) if args.steps % b == 0)
@@ -399,7 +402,7 @@ def main():
         "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
         "camera_path": campath,
         "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": 3 * F * B,
-        "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
+        "tuning": tuning, "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
         "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(line))

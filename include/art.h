@@ -313,6 +313,27 @@ int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
 int32_t art_collect_timings(ArtContext *ctx, float sums_ms[5], uint32_t *n_frames);
 
 /* ---- parity / debug surface (not part of the reference's API; used by tests through this C ABI) ---- */
+/* Which of the EQUIVALENT forms of the path a context runs.  All-zero = what the product runs; the other values exist so that tests can
+ * show that every form gives the same frame bit for bit (tests/test_gpu_parity.py) and so that sweeps need no rebuild.  libart reads
+ * nothing from the environment: a host application's environment cannot change which kernels or trees it gets.
+ * Synchronises; the scene has to be built again afterwards (art_scene_build). */
+typedef struct ArtTuning {
+    uint32_t frame_form;        /* 0 one fused launch per frame (k_frame) | 1 four staged launches, packet walks | 2 four staged launches, per-ray walks */
+    uint32_t tree_builder;      /* 0 the context's default (binned SAH on the device; ART_FLAG_FAST_BUILD: LBVH topology; ART_FLAG_DEVICE_TREE: PLOC) | 1 binned SAH on the host threads */
+    uint32_t frame_waves;       /* fused frame: occupancy target per SIMD: 0 = 8 | 6 | 7 | 8 */
+    uint32_t packet_wide;       /* 1: packets walk the 128-byte 4-wide float nodes */
+    uint32_t primary_walk, shadow_walk, ao_walk; /* override one ray type's walk: 0 default | 8 packet | 2 per-ray binary | 4 per-ray 4-wide quantised */
+    uint32_t block_order;       /* launch order of the 256-pixel blocks: 0 XCD-aware macro-blocks of 2x2 tiles | 1 identity | n: macro-blocks of n x n tiles */
+    uint32_t fixed_waves;       /* 1: no adaptive wave plan (like ART_FLAG_FIXED_WAVES) */
+    uint32_t split_fixed_steps; /* wave plan: a fixed packet-step target instead of the adaptive one (0: adaptive) */
+    uint32_t split_min_steps;   /* wave plan: lowest target (0 = 150) */
+    float split_alpha;          /* wave plan: fraction of the launch's fair share a wave may take before its block is split (0 = 0.7) */
+    uint32_t ao_entry_off;      /* 1: AO rays start at the root instead of their pixel's entry node */
+    uint32_t trace_chunk, trace_refill, trace_blocks; /* persistent per-ray tracer (process-wide): slots per cursor pop, idle lanes that trigger a refill, resident blocks; 0 = presets */
+    uint32_t hw_queues;         /* hardware queues the HOST gave the process (GPU_MAX_HW_QUEUES; 0 = HIP's default of 4): the wave plan counts min(frames in flight, this) launches in flight */
+    uint32_t log;               /* to stderr: 1 build phase times, 2 wave-plan decisions, 4 every wave-plan poll */
+} ArtTuning;
+int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
 /* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */
 int32_t art_read_hits(ArtContext *ctx, float *tuv, int32_t *ids, size_t n_pixels);
 /* per pixel: bit i = light i shadowed, bit 16+i = shadow ray for light i traced (i < 16) */

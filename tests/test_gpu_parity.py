@@ -50,21 +50,14 @@ def test_ray_queries_match_oracle_bitwise(R, orc, get_scene, name, detail):
     r.close()
 
 
-FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"ART_FUSED": "0"}), "per-ray": (1, {"ART_BVH": "24"})}
+FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"frame_form": 1}), "per-ray": (1, {"frame_form": 2})}   # ArtTuning (art_set_tuning)
 
 
 def _frame_parity(R, orc, sc, w, h, n_lights, form="fused"):
     # the three forms of the frame: one fused launch (packet walks), four staged launches (packet walks), four staged launches with
     # the per-ray walks (binary for primary rays, 4-wide for shadow rays)
-    import os
-    fif, env = FORMS[form]
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True, frames_in_flight=fif)
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    fif, tuning = FORMS[form]
+    r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True, frames_in_flight=fif, tuning=tuning)
     r.render_frame()
     S, L, nl = oracle_for(orc, sc, n_lights)
     ref = S.render(oracle_camera(orc, sc, w, h), L, nl, w, h, threads=8, debug=True)
@@ -427,18 +420,14 @@ def test_frame_ring_gives_the_same_frames(R, get_scene):
     ring.close()
 
 
-def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
+def test_frame_forms_and_trees_give_the_same_frame(R, get_scene):
     """the fused frame kernel, the four staged packet kernels, the per-ray kernels -- on the SAH tree and on the LBVH topology
     (ART_FLAG_FAST_BUILD): one frame, bit for bit (colour, depth, normal, ray counts); 4 lights so the light loop is covered"""
     from araytracingjourney_amd import scenes
     sc = get_scene("sponza_like", 0.12)
     w, h = 320, 200
-    def frame(frames_in_flight, fast_build=False, env=None, device_tree=False):
-        for k, v in (env or {}).items():
-            monkeypatch.setenv(k, v)
-        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=frames_in_flight, fast_build=fast_build, device_tree=device_tree)
-        for k in (env or {}):
-            monkeypatch.delenv(k)
+    def frame(frames_in_flight, fast_build=False, tuning=None, device_tree=False):
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=frames_in_flight, fast_build=fast_build, device_tree=device_tree, tuning=tuning)
         for d in scenes.sponza_lights(4):
             r.lights_mut().push_dict(d)
         r.render_frame()
@@ -447,26 +436,27 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene, monkeypatch):
         return out
     ref = frame(4)                                               # fused, SAH (the default with several frames in flight)
     assert ref[3]["frame_launches"] == 1 and ref[3]["shadow_rays"] > 10000
-    for name, got in (("staged packets", frame(4, env={"ART_FUSED": "0"})), ("per-ray", frame(1, env={"ART_BVH": "24"})), ("fused, one frame in flight", frame(1)),
+    for name, got in (("staged packets", frame(4, tuning={"frame_form": 1})), ("per-ray", frame(1, tuning={"frame_form": 2})), ("fused, one frame in flight", frame(1)),
                       ("fused on the LBVH topology", frame(4, fast_build=True)), ("fused on the device-built (PLOC) tree", frame(4, device_tree=True)),
-                      ("per-ray on the PLOC tree", frame(1, device_tree=True, env={"ART_BVH": "24"})), ("per-ray on the LBVH topology", frame(1, fast_build=True, env={"ART_BVH": "24"})),
-                      ("fused on the host-built SAH tree", frame(4, env={"ART_SAH": "1"})), ("fused, 7 waves/SIMD", frame(4, env={"ART_FRAME_WAVES": "7"})), ("fused, no block reordering", frame(4, env={"ART_MACRO": "0"}))):
+                      ("per-ray on the PLOC tree", frame(1, device_tree=True, tuning={"frame_form": 2})), ("per-ray on the LBVH topology", frame(1, fast_build=True, tuning={"frame_form": 2})),
+                      ("fused on the host-built SAH tree", frame(4, tuning={"tree_builder": 1})), ("fused, 7 waves/SIMD", frame(4, tuning={"frame_waves": 7})), ("fused, no block reordering", frame(4, tuning={"block_order": 1})),
+                      ("staged, per-ray primary + packet shadow", frame(2, tuning={"frame_form": 1, "primary_walk": 2})), ("fused, 4-wide float packet nodes", frame(4, tuning={"packet_wide": 1}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
         assert got[3]["shadow_rays"] == ref[3]["shadow_rays"] and got[3]["hit_pixels"] == ref[3]["hit_pixels"], name
-    assert frame(4, env={"ART_FUSED": "0"})[3]["frame_launches"] == 4
+    assert frame(4, tuning={"frame_form": 1})[3]["frame_launches"] == 4
 
 
-def test_wave_plan_changes_the_waves_never_the_image(R, get_scene, monkeypatch):
+def test_wave_plan_changes_the_waves_never_the_image(R, get_scene):
     """the fused frame's adaptive wave plan (ART_FLAG_FIXED_WAVES off): after a sampled frame heavy 8x8 blocks are dealt to 4 / 16 waves --
     the same frame bit for bit before and after, unsharded, sharded, with one light and four, and equal to the fixed-wave frame"""
     from araytracingjourney_amd import scenes
     sc = get_scene("sponza_like", 0.12)
     w, h = 640, 360
-    monkeypatch.setenv("ART_SPLIT_FIXED", "40")          # a low step target, so that plenty of blocks split in this small scene
+    low = {"split_fixed_steps": 40}                      # a low step target, so that plenty of blocks split in this small scene
     for n_lights, shard in ((1, (0, 1)), (4, (0, 1)), (4, (1, 3))):
         fixed = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=1, fixed_waves=True, shard=shard)
-        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=2, shard=shard)
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=2, shard=shard, tuning=low)
         for x in (fixed, r):
             for d in scenes.sponza_lights(n_lights):
                 x.lights_mut().push_dict(d)
@@ -582,13 +572,10 @@ def test_residency_only_device_models_are_traced(R, get_scene):
 
 @pytest.mark.parametrize("builder", ["sah-device", "sah-host", "ploc-device"])
 @pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12), ("sponza_like", 1.0)])
-def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, monkeypatch, name, detail, builder):
+def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail, builder):
     """what makes the SAH rebuild invisible: every leaf of the canonical LBVH hangs in the traversal tree exactly once,
     every node box is the exact min/max union of its children's boxes, the root is node 0, the depth stays inside the walks' stacks"""
-    if builder == "sah-host":
-        monkeypatch.setenv("ART_SAH", "1")
-    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=builder == "ploc-device")   # binned SAH on the device (default) / on the host threads / PLOC
-    monkeypatch.delenv("ART_SAH", raising=False)
+    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=builder == "ploc-device", tuning={"tree_builder": 1} if builder == "sah-host" else None)   # binned SAH on the device (default) / on the host threads / PLOC
     lb, tr = r.get_lbvh(), r.get_traversal_tree()
     T = lb["leaf_gid"].size
     child = tr["child"]

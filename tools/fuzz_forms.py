@@ -19,12 +19,11 @@ for case in range(n_cases):
     B = random.choice((1, 1, 2, 3, 4))
     relief = random.choice((0, 0, 40, 200)) if G > 1 else 0
     R.set_root_relief(relief)
-    os.environ['ART_SPLIT_FIXED'] = str(random.choice((8, 30, 100000)))   # wave-plan target in packet steps: nearly everything / some / nothing splits
+    split = random.choice((8, 30, 100000))   # wave-plan target in packet steps (ArtTuning.split_fixed_steps): nearly everything / some / nothing splits
     outs = []
     for form in ("fused", "per-ray"):
-        if form == "per-ray": os.environ["ART_BVH"] = "24"
-        r = R.renderer_for_scene(sc, (w, h), n_lights=0, shard=(k, G), frames_in_flight=fif, packed_tiles=packed, device_tree=random.random() < 0.3)
-        os.environ.pop("ART_BVH", None)
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, shard=(k, G), frames_in_flight=fif, packed_tiles=packed, device_tree=random.random() < 0.3,
+                                 tuning={"frame_form": 2} if form == "per-ray" else {"split_fixed_steps": split})
         if form == "fused" and B > 1: r.set_frames_per_launch(B)
         for d in (lights16[:nl] if sc is spo else [dict(sc.lights[0], pos=(0.1 * i - 0.3, 0.5, 0.05 * i)) for i in range(nl)]):
             r.lights_mut().push_dict(d)
@@ -37,7 +36,7 @@ for case in range(n_cases):
         r.close()
     a, b = outs
     ok = all(np.array_equal(a[i].view(np.uint32), b[i].view(np.uint32)) for i in range(3)) and a[4:7] == b[4:7] and (G == 1 or np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)))
-    print(f"case {case}: {sc.name} {w}x{h} lights {nl} F {fif} shard {k}/{G} relief {relief} packed {packed} B {B} split {os.environ['ART_SPLIT_FIXED']} (blocks split: {a[7]}): {'ok' if ok else 'MISMATCH'} rays {a[6]}+{a[4]}", flush=True)
+    print(f"case {case}: {sc.name} {w}x{h} lights {nl} F {fif} shard {k}/{G} relief {relief} packed {packed} B {B} split {split} (blocks split: {a[7]}): {'ok' if ok else 'MISMATCH'} rays {a[6]}+{a[4]}", flush=True)
     if not ok: sys.exit(1)
 R.set_root_relief(0)
 print("FUZZ_OK")
