@@ -235,3 +235,19 @@ def test_model_residency_state_machine():
     s = R.Sphere((1.0, 0.0, 0.0), 2.0).transform([[2, 0, 0, 5], [0, 3, 0, 0], [0, 0, 1, 0]])   # model_reader.rs:128-141
     assert np.allclose(s.center, (7.0, 0.0, 0.0)) and s.radius == 6.0
     assert abs(R.Sphere((0, 0, 0), 1.0).get_distance_from_point((0, 3, 4)) - 4.0) < 1e-6
+
+
+def test_rust_binding_is_generated_from_the_header_and_complete():
+    """bindings/art_sys.rs (the extern "C" block a maintainer of the reference would add) is what tools/gen_rust_bindings.py makes of
+    include/art.h today, and names every function the header declares and the ctypes table binds; no Rust toolchain here, so: generated, not compiled"""
+    import re, subprocess, sys
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_bindings.py"), "--check"], capture_output=True, text=True).returncode == 0
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "art.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(art_\w+)\s*\(", hdr))
+    rs = open(os.path.join(ROOT, "bindings", "art_sys.rs")).read()
+    bound = set(re.findall(r"pub fn (art_\w+)\(", rs))
+    from araytracingjourney_amd import _lib
+    assert declared == bound == set(_lib.SYMBOLS), (declared ^ bound, declared ^ set(_lib.SYMBOLS))
+    for name, size in (("ArtVertex", 48), ("ArtLight", 80), ("ArtCamera", 268), ("ArtConfig", 32)):
+        assert f"size_of::<{name}>() == {size})" in rs
+    assert "#[repr(C, packed)] #[derive(Clone, Copy)]\npub struct ArtCamera" in rs
