@@ -262,6 +262,19 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
                 cand[nc++] = child[2 * (size_t)n + 1];
             }
         }
+        // the packet walk takes the children front to back along ONE axis (0,1,2,3 or 3,2,1,0 by the rays' direction sign on it): sort them by box
+        // centre along the axis the centres spread most on
+        uint32_t sort_axis = 0;
+        {
+            float best_spread = -1.0f;
+            for (uint32_t k = 0; k < 3; k++) {
+                float lo = INFINITY, hi = -INFINITY;
+                for (int i = 0; i < nc; i++) { BoxRef b = box(cand[i]); float c = 0.5f * b.lo[k] + 0.5f * b.hi[k]; lo = std::fmin(lo, c); hi = std::fmax(hi, c); }
+                if (hi - lo > best_spread) { best_spread = hi - lo; sort_axis = k; }
+            }
+            auto centre = [&](int32_t ref) { BoxRef b = box(ref); return 0.5f * b.lo[sort_axis] + 0.5f * b.hi[sort_axis]; };
+            std::stable_sort(cand, cand + nc, [&](int32_t x, int32_t y) { return centre(x) < centre(y); });
+        }
         DevNode4 d; std::memset(&d, 0, sizeof(d));
         DevNodeW dw; std::memset(&dw, 0, sizeof(dw));
         float org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -278,7 +291,8 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
         }
         uint32_t mask = 0;
         for (int i = 0; i < 4; i++) {
-            if (i >= nc) { d.child[i] = 0x7FFFFFFF; dw.child[i] = 0x7FFFFFFF; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = -3.0e38f; } continue; }
+            if (i >= nc) { d.child[i] = 0x7FFFFFFF; dw.child[i] = 0x7FFFFFFF; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; } // an absent child: a point box out at 3e38 -- every axis' entry
+            // and exit distance is +-huge with the SAME sign, so neither the octant-specialised nor the general slab test lets a ray in (an INVERTED box passes the general one)
             mask |= 1u << i;
             BoxRef b = box(cand[i]);
             for (int k = 0; k < 3; k++) {
@@ -296,7 +310,7 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
             dw.child[i] = d.child[i];
         }
         d.exps = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (mask << 24);
-        dw.valid = mask;
+        dw.valid = mask; dw.pad[0] = sort_axis;
         wide.push_back(d);
         widef.push_back(dw);
     }

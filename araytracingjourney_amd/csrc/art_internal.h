@@ -38,7 +38,8 @@ struct alignas(16) DevNode4 { float ox, oy, oz; uint32_t exps; uint32_t q[6]; ui
 static_assert(sizeof(DevNode4) == 64, "DevNode4 layout");
 // 128-byte 4-wide node with full-precision child boxes, for the packet walk: a wave's iteration is bound by the latency of one
 // dependent (scalar) node fetch, so halving the number of iterations matters more than the bytes.
-//   box[c] = lo.xyz hi.xyz of child c (an absent child has lo = +3e38, hi = -3e38 and is masked by `valid`)
+//   box[c] = lo.xyz hi.xyz of child c, children sorted by box centre along axis pad[0] (the packet walk's front-to-back order); an absent
+//   child is a point box at +3e38, which no slab test passes
 struct alignas(16) DevNodeW { float box[4][6]; int32_t child[4]; uint32_t valid; uint32_t pad[3]; };
 static_assert(sizeof(DevNodeW) == 128, "DevNodeW layout");
 // 48-byte triangle in leaf order: v0.xyz|prim  v1.xyz|tri-in-prim  v2.xyz|gid

@@ -275,34 +275,37 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
     for (;;) {
         if (COUNT) steps++; // wave-uniform: nodes + triangles the packet visited (the fused frame's wave plan feeds on it; one s_add here costs 3.5 %, so only sampled frames count)
         if (cur >= 0 && WIDE) {
+            // 4-wide node, float boxes (128 B, two scalar loads).  Its children were sorted at build time along the axis `ax` their centroids spread
+            // most on, so the packet's front-to-back order is 0,1,2,3 or 3,2,1,0 by the sign of its rays' direction on that axis -- no per-lane
+            // distances, no votes.  (Order only steers the culling: the answer is order-independent)  Absent children carry a
+            // point box out at 3e38, which no ray passes (art_build.hip).  Measured against the binary walk on config 2 (profiles/README.md r2d):
+            // scalar instructions -43 %, vector instructions +9 % (all four boxes of a node are tested, also below a child the binary walk
+            // would have culled), rays/s +2 %: the frame is bound by vector issue, so this stays an A/B form (ArtTuning.packet_wide).
             const float4 *nq = reinterpret_cast<const float4 *>(a.widef + cur);
             float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
-            int cr[4] = {__float_as_int(w6.x), __float_as_int(w6.y), __float_as_int(w6.z), __float_as_int(w6.w)};
-            uint32_t valid = __float_as_uint(w7.x);
-            float te[4]; bool h[4];
-            h[0] = slab(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, tbest, te[0]) && on && (valid & 1u);
-            h[1] = slab(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, tbest, te[1]) && on && (valid & 2u);
-            h[2] = slab(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, tbest, te[2]) && on && (valid & 4u);
-            h[3] = slab(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, tbest, te[3]) && on && (valid & 8u);
-            float tnear = fminf(fminf(h[0] ? te[0] : 3.0e38f, h[1] ? te[1] : 3.0e38f), fminf(h[2] ? te[2] : 3.0e38f, h[3] ? te[3] : 3.0e38f));
-            int best = -1, bestn = -1; // continue with the hit child that is the first one for most rays; stack the others
-            uint64_t m[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                m[i] = ballot64(h[i]);
-                int cnt = m[i] ? (int)__popcll(ballot64(h[i] && te[i] == tnear)) : -1;
-                if (cnt > bestn) { bestn = cnt; best = i; }
+            const int c0 = __float_as_int(w6.x), c1 = __float_as_int(w6.y), c2 = __float_as_int(w6.z), c3 = __float_as_int(w6.w);
+            float te;
+            const uint64_t m0 = ballot64(slab_oct<OCT>(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, tbest, te));
+            const uint64_t m1 = ballot64(slab_oct<OCT>(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, tbest, te));
+            const uint64_t m2 = ballot64(slab_oct<OCT>(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, tbest, te));
+            const uint64_t m3 = ballot64(slab_oct<OCT>(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, tbest, te));
+            const uint32_t ax = __float_as_uint(w7.y);                   // 0..2 (wave-uniform)
+            // mixed packets (OCT 8) go by the majority sign on that axis
+            const bool rev = OCT < 8 ? ((OCT >> ax) & 1) != 0 : 2 * (int)__popcll(ballot64(on && (ax == 0 ? r.inv.x : (ax == 1 ? r.inv.y : r.inv.z)) < 0.0f)) > (int)__popcll(ballot64(on));
+            const bool lane0 = (threadIdx.x & 63u) == 0;
+            int next = kPop;
+            if (!rev) { // near -> far = 0,1,2,3: stack the far ones first
+                if (m3 != 0ull) next = c3;
+                if (m2 != 0ull) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c2; }
+                if (m1 != 0ull) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c1; }
+                if (m0 != 0ull) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c0; }
+            } else {
+                if (m0 != 0ull) next = c0;
+                if (m1 != 0ull) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c1; }
+                if (m2 != 0ull) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c2; }
+                if (m3 != 0ull) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c3; }
             }
-            if (best < 0) cur = kPop;
-            else {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (m[i] != 0ull && i != best) {
-                        if ((threadIdx.x & 63u) == 0) stk[min(sp, kPacketStack - 1)] = cr[i];
-                        sp = min(sp + 1, kPacketStack);
-                    }
-                cur = best == 0 ? cr[0] : (best == 1 ? cr[1] : (best == 2 ? cr[2] : cr[3]));
-            }
+            cur = next;
         } else if (cur >= 0) {
             const float4 *nq = reinterpret_cast<const float4 *>(a.nodes + cur);
             float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
@@ -358,16 +361,16 @@ __device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, 
     // direction signs per axis: all set, none set, or mixed over the packet's rays
     uint64_t nx = ballot64(on && r.inv.x < 0.0f), ny = ballot64(on && r.inv.y < 0.0f), nz = ballot64(on && r.inv.z < 0.0f);
     bool uniform = (nx == 0ull || nx == act) && (ny == 0ull || ny == act) && (nz == 0ull || nz == act);
-    int oct = !uniform || WIDE ? 8 : (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
+    int oct = !uniform ? 8 : (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
     switch (oct) {
-    case 0: packet_walk<ANY, WIDE, WIDE ? 8 : 0, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 1: packet_walk<ANY, WIDE, WIDE ? 8 : 1, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 2: packet_walk<ANY, WIDE, WIDE ? 8 : 2, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 3: packet_walk<ANY, WIDE, WIDE ? 8 : 3, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 4: packet_walk<ANY, WIDE, WIDE ? 8 : 4, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 5: packet_walk<ANY, WIDE, WIDE ? 8 : 5, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 6: packet_walk<ANY, WIDE, WIDE ? 8 : 6, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 7: packet_walk<ANY, WIDE, WIDE ? 8 : 7, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 0: packet_walk<ANY, WIDE, 0, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 1: packet_walk<ANY, WIDE, 1, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 2: packet_walk<ANY, WIDE, 2, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 3: packet_walk<ANY, WIDE, 3, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 4: packet_walk<ANY, WIDE, 4, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 5: packet_walk<ANY, WIDE, 5, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 6: packet_walk<ANY, WIDE, 6, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 7: packet_walk<ANY, WIDE, 7, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
     default: packet_walk<ANY, WIDE, 8, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
     }
 }
@@ -1105,7 +1108,7 @@ bool launch_frame(const FrameArgs &a, hipStream_t s) { // returns whether the la
         return true;
     }
     if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); return false; }
-    if (a.packet_wide) { if (one) k_frame<true, 5, true><<<g, kBlock, 0, s>>>(a); else k_frame<true, 5, false><<<g, kBlock, 0, s>>>(a); }
+    if (a.packet_wide) { if (one) k_frame<true, 8, true><<<g, kBlock, 0, s>>>(a); else k_frame<true, 8, false><<<g, kBlock, 0, s>>>(a); }
     else if (waves >= 8) { if (one) k_frame<false, 8, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); }
     else if (waves == 7) { if (one) k_frame<false, 7, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 7, false><<<g, kBlock, 0, s>>>(a); }
     else { if (one) k_frame<false, 6, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 6, false><<<g, kBlock, 0, s>>>(a); }

@@ -325,13 +325,14 @@ def test_packed_tiles_gather_to_the_packed_colour_image(R, get_scene):
     whole.close()
 
 
+@pytest.mark.parametrize("walk", [0, 2], ids=["default", "binary"])
 @pytest.mark.parametrize("name,detail,size,spp", [("cornell", 1.0, (256, 256), 16), ("sponza_like", 0.12, (480, 270), 16), ("sponza_like", 0.12, (200, 120), 5)])
-def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp):
+def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp, walk):
     """BASELINE config 5's pass: AO rays from the frame's depth + normal outputs; the 0..255 output is an integer: bit-exact"""
     sc = get_scene(name, detail)
     w, h = size
     radius = 0.2 * 1.457
-    r = R.renderer_for_scene(sc, (w, h))
+    r = R.renderer_for_scene(sc, (w, h), tuning={"ao_walk": walk} if walk else None)   # either walk the AO rays can take (ArtTuning.ao_walk) gives the same integers
     r.render_frame(sync=False)
     r.trace_ao(spp, radius)
     got = r.read_ao()
