@@ -550,7 +550,7 @@ struct TraceArgs {
 // come from eight per-XCD work cursors (one returning atomic per chunk), so neighbouring rays stay on one XCD's L2.
 // Every wave exits once all cursors are exhausted and its lanes are idle.
 template <int MODE, int WIDTH>
-__global__ __launch_bounds__(kBlock) void k_trace(TraceArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == MODE_AO ? 8 : 4, 8))) void k_trace(TraceArgs a) {
     constexpr bool ANY = MODE == MODE_SHADOW || MODE == MODE_QUERY_ANY || MODE == MODE_AO;
     __shared__ int stack[kLdsStack * kBlock];
     int ovf[WIDTH == 4 ? kOvfStack4 : kOvfStack];
