@@ -44,6 +44,7 @@ def parse():
                                                                       "default 16 on one GPU (one hardware queue each), 12 launches when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall clock the CPU baseline repeats the frame for (the contract: a bounded sample, ~10-30 s of CPU work)")
     ap.add_argument("--plain", action="store_true", help="only the contract's timed region (profiling passes: no single-frame spans, no steady-state / camera-path legs, no CPU baseline)")
     ap.add_argument("--tuning", default="", help="A/B sweeps: ArtTuning fields for the benchmarked context, key=value[,key=value...] (include/art.h: frame_form, tree_builder, frame_waves, "
                                                  "block_order, split_alpha ...); the default -- none -- is the product")
@@ -333,7 +334,7 @@ def main():
         S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)       # warm-up frame
         reps, cdt, cst = 0, 0.0, None
         c0 = time.perf_counter()
-        while cdt < 10.0 and reps < 400:   # the same whole frame, repeated for ~10 s of wall clock
+        while cdt < args.cpu_seconds and reps < 400:   # the same whole frame, repeated for ~10 s of wall clock
             cst = S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)["stats"]
             reps += 1
             cdt = time.perf_counter() - c0

@@ -100,3 +100,53 @@ def test_sharded_bench_job_of_child_processes_gathers_the_single_gpu_frame(ranks
     assert line["gathered_frame_equals_single_gpu_frame"] is True
     assert line["n_gpus"] == ranks and line["gathers"] >= 4 and line["value"] > 0
     assert ("B10G11R11" in line["config"]["parallelism"]) == ("packed" in extra) and ("RGBA32F HDR" in line["config"]["parallelism"]) == ("packed" not in extra)
+
+
+@pytest.mark.gpu
+def test_config4_eight_way_split_assembles_the_full_size_frame(get_scene):
+    """BASELINE config 4's split at its real size on the one GPU there is: eight shard contexts of the 2.8 M-triangle scene at 1920x1080, each
+    tracing its tiles; their compact tile buffers laid out as ncclGather leaves them on rank 0 and un-tiled by one launch give the unsharded
+    frame bit for bit; every shard owns 255 or 256 of the 2040 tiles"""
+    import torch
+    from araytracingjourney_amd import renderer as R
+    sc = get_scene("bistro_like", 1.0)
+    w, h, G = 1920, 1080, 8
+    whole = R.renderer_for_scene(sc, (w, h))
+    whole.render_frame()
+    want = whole.read_color()
+    st_whole = whole.stats()
+    whole.close()
+    bufs, owned, rays = [], [], 0
+    for k in range(G):                                   # one at a time: eight copies of the scene need not be resident together
+        s = R.renderer_for_scene(sc, (w, h), shard=(k, G))
+        s.render_frame()
+        bufs.append(torch.from_numpy(s.read_color_tiles()).cuda())
+        owned.append(s.shard_tile_count()[0])
+        rays += s.stats()["shadow_rays"]
+        if k < G - 1:
+            s.close()
+    gathered = torch.stack(bufs).contiguous()            # [rank][padded tiles][32][32][4]
+    torch.cuda.synchronize()
+    s.untile_gathered(gathered.data_ptr(), G)            # the last shard's context un-tiles (any shard's layout tables are the job's)
+    got = s.read_color()
+    s.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert sum(owned) == 60 * 34 and max(owned) - min(owned) <= 1 and rays == st_whole["shadow_rays"]
+
+
+@pytest.mark.gpu
+def test_bench_takes_a_glb_through_the_real_ingest(tmp_path, get_scene):
+    """bench.py --glb: the scene comes through art_glb_open + art_scene_add_glb (renderer.rs:346), the line says data: "real glb", the GPU's ray
+    counts equal the oracle's on the reader's own output (asserted inside bench.py), and the roofline's packet-level bytes are counted for it"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from glb_writer import write_glb
+    sc = get_scene("sponza_like", 0.05)
+    path = tmp_path / "atrium.glb"
+    write_glb(str(path), sc.primitives, png_modes=("RGBA", "RGBA", "RGBA"))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--glb", str(path), "--steps", "16", "--warmup", "4", "--width", "640", "--height", "360",
+                          "--cpu-seconds", "0.5", "--camera-path", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(lines[0])
+    assert line["data"] == "real glb" and "atrium.glb through art_scene_add_glb" in line["config"]["workload"] and line["value"] > 0
+    assert line["cpu_baseline"]["kind"] == "port" and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["packet_frac"] < 1
