@@ -149,7 +149,7 @@ struct ArtContext {
     ArtStats stats{};
     bool tiles_packed() const { return (cfg.flags & ART_FLAG_PACKED_TILES) != 0; }
     bool tiled() const { return cfg.shard_count > 1 || (cfg.flags & ART_FLAG_TILE_OUTPUT) != 0; } // writes the compact tile buffer beside the frame
-    size_t tile_px_bytes() const { return tiles_packed() ? 4 : 16; } // B10G11R11 words or float4 in the compact tile buffer
+    size_t tile_px_bytes() const { return tiles_packed() ? 4 : 12; } // B10G11R11 words or RGB32F (the colour without its constant alpha) in the compact tile buffer
     hipStream_t stream_of(uint32_t k) const { return (ext_stream && F == 1) ? ext_stream : slot[k].own; }
     hipStream_t main_stream() const { return stream_of(0); }
 };

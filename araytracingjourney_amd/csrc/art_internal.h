@@ -147,8 +147,8 @@ struct FrameArgs {
     bool fold_counters;        // packet walks use no work cursors: the last launch of the frame folds the count slots into counters[0..1] and clears them for the
                                // slot's next frame, instead of a memset launch in front of every frame
     float4 *color; float *depth; float4 *normal; // full frame, row-major
-    float4 *color_tiles;       // compact [n_local] (sharded mode) or nullptr
-    bool tiles_packed;         // color_tiles holds B10G11R11 words (4 B per pixel, the reference's output image format) instead of float4
+    float4 *color_tiles;       // compact tile buffer (sharded mode) or nullptr: [n_local] RGB32F texels, 12 B each (the colour's alpha is the constant 1) ...
+    bool tiles_packed;         // ... or B10G11R11 words (4 B per pixel, the reference's output image format)
     uint32_t *shadow_bits;     // debug, [n_local] or nullptr
     uint32_t *pix_bits;        // fused frame: [n_local] shadowed / traced bits per pixel (always written)
     bool keep_hits;            // fused frame: also store the hit records (art_read_hits)
@@ -161,7 +161,7 @@ struct FrameArgs {
     // fused frame, several frames per launch (art_set_frames_per_launch): grid.y = frame b of the launch.  Frame b uses cam (b = 0) or
     // cam_more[b - 1], and writes its outputs b * (W * H) pixels (color, depth, normal), b * n_local (pix_bits, hits) and
     // b * tiles_stride (color_tiles) further on.  A launch costs ~7 us of machine time whatever it traces (profiles/README.md r1o).
-    uint32_t batch; uint32_t tiles_stride; CameraArg cam_more[3];
+    uint32_t batch; uint32_t tiles_stride; CameraArg cam_more[3];   // tiles_stride: TEXELS between two frames' tiles
 };
 constexpr uint32_t kMaxBatch = 4;
 void launch_primary(const FrameArgs &a, hipStream_t s);

@@ -192,7 +192,7 @@ int32_t art_mgpu_create(ArtContext *ctx, const ArtMgpuConfig *cfg, const uint8_t
     m->root = cfg->rank == 0;
     m->renders = !(cfg->compositor == ART_MGPU_DEDICATED && cfg->rank == 0);
     m->slot_bytes = (size_t)m->B * m->lay.tiles_padded * m->lay.tile_bytes;
-    m->frame_bytes = (size_t)m->lay.width * m->lay.height * (m->lay.tile_bytes / kTilePixels);
+    m->frame_bytes = (size_t)m->lay.width * m->lay.height * (m->lay.tile_bytes == 4u * kTilePixels ? 4u : 16u);   // the assembled frame: B10G11R11 words, or RGBA32F (the tiles carry RGB; alpha is the constant 1)
     hipError_t e = hipMalloc(&m->tiles, (size_t)m->NBUF * m->F * m->slot_bytes);
     if (e == hipSuccess) e = hipMemset(m->tiles, 0, (size_t)m->NBUF * m->F * m->slot_bytes);
     if (e == hipSuccess && m->root) e = hipMalloc(&m->gathered, (size_t)cfg->world * m->GB * m->slot_bytes);

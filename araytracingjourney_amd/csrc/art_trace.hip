@@ -252,6 +252,10 @@ __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_b
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_nt(float4 *p, float4 v) { __builtin_nontemporal_store(f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f4v *>(p)); }
 __device__ __forceinline__ void st_nt(float *p, float v) { __builtin_nontemporal_store(v, p); }
+// the compact tile buffer holds RGB only (12 B per pixel): the colour output's alpha is the constant 1 of imageStore(vec4(rho, 1)), so the
+// gather moves three quarters of the bytes of the RGBA32F image and loses nothing
+typedef float f3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void st_nt_rgb(float4 *tiles, size_t texel, float4 v) { __builtin_nontemporal_store(f3v{v.x, v.y, v.z}, reinterpret_cast<f3v *>(reinterpret_cast<float *>(tiles) + 3 * texel)); }
 __device__ __forceinline__ float4 ld_nt(const float4 *p) { f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 
 // The walk of one packet: `cur` (node reference) and the stack are wave-uniform.  OCT 0..7: every ray of the packet has the
@@ -989,7 +993,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
         uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
         size_t ti = (size_t)fb * a.tiles_stride + (size_t)(p >> 10) * kTilePixels + ly * kTile + lx;
         if (a.tiles_packed) __builtin_nontemporal_store(pack_b10g11r11(o.x, o.y, o.z), reinterpret_cast<uint32_t *>(a.color_tiles) + ti);
-        else st_nt(&a.color_tiles[ti], o);
+        else st_nt_rgb(a.color_tiles, ti, o);
     }
     if (mine) a.pix_bits[frame_local + p] = sbits;
     if (COUNT && __lane_id() == 0) a.wave_cost[wid] = steps; // feedback for the next plan (art_api.hip plan_poll)
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
         uint32_t lx = (sub & 3u) * 8u + (l & 7u), ly = (sub >> 2) * 8u + (l >> 3);
         size_t ti = (size_t)(p >> 10) * kTilePixels + ly * kTile + lx;
         if (a.tiles_packed) __builtin_nontemporal_store(pack_b10g11r11(o.x, o.y, o.z), reinterpret_cast<uint32_t *>(a.color_tiles) + ti);
-        else st_nt(&a.color_tiles[ti], o);
+        else st_nt_rgb(a.color_tiles, ti, o);
     }
 }
 
@@ -1059,6 +1063,23 @@ template <class T, int V> __global__ __launch_bounds__(kBlock) void k_untile(con
     for (int i = 0; i < 4; i++) p[i] = *reinterpret_cast<const Pack *>(src + (size_t)i * 8u * kTile); // rows y0, y0 + 8, + 16, + 24 of the tile (padding rows of a bottom tile are readable)
 #pragma unroll
     for (int i = 0; i < 4; i++) if (y0 + 8u * i < H) *reinterpret_cast<Pack *>(dst + (size_t)i * 8u * W) = p[i];
+}
+
+// the same for RGB32F tiles (12 B per texel) into the RGBA32F frame: alpha = 1, the constant the colour output carries
+__global__ __launch_bounds__(kBlock) void k_untile_rgb(const float *__restrict__ gathered, const uint32_t *__restrict__ tile_slot, uint32_t shard_stride, uint32_t frame_stride,
+                                                       uint32_t W, uint32_t H, float4 *__restrict__ frame) {
+    const uint32_t tiles_x = (W + kTile - 1) / kTile;
+    const uint32_t x = blockIdx.x * 32u + (threadIdx.x & 31u), y0 = blockIdx.y * kTile + (threadIdx.x >> 5);
+    if (x >= W || y0 >= H) return;
+    const uint32_t ts = tile_slot[blockIdx.y * tiles_x + x / kTile];
+    const size_t tile = (size_t)(ts >> 24) * shard_stride + (size_t)blockIdx.z * frame_stride + (ts & 0xFFFFFFu);
+    const float *src = gathered + 3 * (tile * kTilePixels + (threadIdx.x >> 5) * kTile + (x % kTile));
+    float4 *dst = frame + (size_t)blockIdx.z * W * H + (size_t)y0 * W + x;
+    float4 p[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const float *q = src + (size_t)i * 8u * kTile * 3; p[i] = make_float4(q[0], q[1], q[2], 1.0f); }   // rows y0, y0 + 8, + 16, + 24 of the tile
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (y0 + 8u * i < H) dst[(size_t)i * 8u * W] = p[i];
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1161,7 +1182,7 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, in
 }
 void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {
     dim3 g((W + 31) / 32, (H + kTile - 1) / kTile, n_frames);
-    k_untile<float4, 1><<<g, kBlock, 0, s>>>(gathered, tile_slot, shard_stride, frame_stride, W, H, frame);
+    k_untile_rgb<<<g, kBlock, 0, s>>>(reinterpret_cast<const float *>(gathered), tile_slot, shard_stride, frame_stride, W, H, frame);
 }
 void launch_untile_packed(const uint32_t *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, uint32_t *frame, hipStream_t s) {
     if (W % 4 == 0 && ((uintptr_t)frame & 15u) == 0 && ((uintptr_t)gathered & 15u) == 0) { // four pixels (16 bytes) per thread

@@ -474,7 +474,7 @@ class Renderer:
 
     def read_color_tiles(self):
         _, padded = self.shard_tile_count()
-        a = np.empty((padded, 32, 32), np.uint32) if self.packed_tiles else np.empty((padded, 32, 32, 4), np.float32)
+        a = np.empty((padded, 32, 32), np.uint32) if self.packed_tiles else np.empty((padded, 32, 32, 3), np.float32)   # RGB32F: the colour without its constant alpha
         check(self._L.art_read_color_tiles(self._ctx, _ptr(a), a.nbytes))
         return a
 

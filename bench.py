@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--frames-per-launch", type=int, default=0, help="N>1: frames one launch traces (1..4; default: the largest of 4, 2, 1 that divides --steps and --warmup's launches; "
                                                                        "a launch costs ~7 us of machine time whatever it traces, which a 1/8 share feels)")
     ap.add_argument("--root-relief", type=int, default=-1, help="N>1, shared compositor: 1/256ths of rank 0's share handed to the other ranks (default 8 per GPU)")
-    ap.add_argument("--gather", default="fp32", choices=["fp32", "packed"], help="N>1 exchange payload: RGBA32F tiles -- the HDR buffer, 16 B per pixel (default, the contract) -- or "
+    ap.add_argument("--gather", default="fp32", choices=["fp32", "packed"], help="N>1 exchange payload: RGB32F tiles -- the HDR buffer, 12 B per pixel: its alpha is the constant 1 and stays at home (default, the contract) -- or "
                                                                                   "B10G11R11_UFLOAT_PACK32 words, the reference's colour image format (renderer.rs:268), 4 B per pixel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL inside libart (ncclGather on the tile buffers); gloo = rehearsal of the same loop with the "
                                                                                   "collective replaced by a host function (tiles staged through host memory, ranks may share one GPU)")
@@ -397,7 +397,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real glb" if glb else "synthetic",
         "config": {"workload": workload_name(sc, glb, W, H, lights, shadow_total, args), "width": W, "height": H, "lights": len(lights),
                    "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else f" (rank 0 composites too and traces {256 - relief}/256 of a share)")
-                                   + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGBA32F HDR (16 B/px)'} colour tiles to rank 0, {B} frames per launch, "
+                                   + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGB32F HDR (12 B/px; alpha is the constant 1)'} colour tiles to rank 0, {B} frames per launch, "
                                      f"{counts['launches_per_gather'] * B} frames per gather") + f", {F * B} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
         "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,

@@ -77,7 +77,7 @@ typedef struct ArtConfig {
 
 #define ART_FLAG_FAST_BUILD 2u /* traversal nodes keep the LBVH topology (PREFER_FAST_BUILD); default: binned-SAH rebuild = PREFER_FAST_TRACE, vk_model.rs:968 */
 #define ART_FLAG_PACKED_TILES 4u /* sharded contexts: the compact tile buffer (the gather's payload) holds B10G11R11_UFLOAT_PACK32 words -- the reference's colour
-                                   image format (renderer.rs:268) -- 4 B per pixel instead of RGBA32F; art_untile_gathered then assembles the packed colour image */
+                                   image format (renderer.rs:268) -- 4 B per pixel instead of RGB32F's 12; art_untile_gathered then assembles the packed colour image */
 #define ART_FLAG_DEVICE_TREE 8u /* build the PREFER_FAST_TRACE tree on the device (parallel locally-ordered clustering over the Morton-ordered leaves)
                                   instead of the binned SAH (also built on the device, art_sahdev.hip): a somewhat faster build, ~4 % fewer rays/s (profiles/README.md) */
 #define ART_FLAG_FIXED_WAVES 16u /* every 8x8 pixel block of a frame is traced by one wave, always.  Default: adaptive -- now and then a frame counts the packet
@@ -210,7 +210,9 @@ int32_t art_device_depth(ArtContext *ctx, void **dev_ptr, size_t *bytes);
 int32_t art_device_normal(ArtContext *ctx, void **dev_ptr, size_t *bytes);
 
 /* screen-tile sharding (new functionality, BASELINE.json): compact per-shard colour tiles for the RCCL gather, and
- * the un-tile step run by the root on the gathered buffer.  tile = 32x32 px, 16 KiB of RGBA32F each. */
+ * the un-tile step run by the root on the gathered buffer.  tile = 32x32 px of RGB32F = 12 KiB each: the colour without its alpha, which is
+ * the constant 1 of imageStore(vec4(rho, 1)) (raytrace.rgen.glsl:197) -- three quarters of the bytes on the links, nothing lost; the un-tile writes
+ * the RGBA32F frame. */
 int32_t art_shard_tile_count(ArtContext *ctx, uint32_t *owned, uint32_t *padded);
 /* Process-wide, before any context is created, the same on every rank of a job: shard 0 (the rank that also receives and un-tiles every
  * frame) gives up its tile in per_256 / 256 of the tile groups to the other shards in turn, so that its share + compositing takes as long
@@ -223,7 +225,7 @@ int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, 
                          uint32_t cap, uint32_t *owned, uint32_t *padded);
 int32_t art_device_color_tiles(ArtContext *ctx, void **dev_ptr, size_t *bytes);
 /* render ring slot `slot`'s compact tiles straight into a caller-owned device buffer (e.g. the tensor handed to the
- * gather); bytes must equal padded * 16 KiB; NULL unbinds */
+ * gather); bytes must equal padded * 12 KiB (4 KiB with ART_FLAG_PACKED_TILES) * frames per launch; NULL unbinds */
 int32_t art_bind_color_tiles(ArtContext *ctx, uint32_t slot, void *dev_ptr, size_t bytes);
 /* two buffers per slot: the slot's frames write them alternately (even / odd trips round the ring), so a frame never waits for the
  * exchange that is still reading the slot's previous tiles -- only for the one of two trips ago.  art_device_color_tiles and
@@ -250,7 +252,7 @@ typedef struct ArtLayout {
     uint32_t frames_per_launch;  /* frames one art_trace traces = frames per ring slot */
     uint32_t shard_rank, shard_count;
     uint32_t tiles_owned, tiles_padded; /* 32x32 tiles this shard renders; the largest count over all shards (the per-rank gather size) */
-    uint32_t tile_bytes;         /* bytes of one tile in the compact tile buffer: 16384 (RGBA32F) or 4096 (ART_FLAG_PACKED_TILES); 0: the context writes none */
+    uint32_t tile_bytes;         /* bytes of one tile in the compact tile buffer: 12288 (RGB32F) or 4096 (ART_FLAG_PACKED_TILES); 0: the context writes none */
     uint32_t reserved;
 } ArtLayout;
 int32_t art_get_layout(ArtContext *ctx, ArtLayout *out);
@@ -270,8 +272,8 @@ int32_t art_timestamp_elapsed(ArtContext *ctx, float *ms);
  * compact tile buffers (4 per ring slot, written in turn); the tiles of `frames_per_gather` launches travel as ONE ncclGather (RCCL, rccl.h:745)
  * to rank 0 on a stream of their own, submitted by the host once it has SEEN the group's frames finish (art_frames_done: no device-side wait
  * in front of the collective or of the next frames -- such waits cost the frames in flight their L2 contents, profiles/README.md r1n), and one
- * launch un-tiles the group on rank 0 (art_untile_gathered_frames).  The payload is the context's tile format: RGBA32F -- the HDR buffer --
- * by default, B10G11R11 words with ART_FLAG_PACKED_TILES.
+ * launch un-tiles the group on rank 0 (art_untile_gathered_frames).  The payload is the context's tile format: RGB32F -- the HDR buffer, 12 B per pixel
+ * (its alpha is the constant 1) -- by default, B10G11R11 words with ART_FLAG_PACKED_TILES.
  * RCCL is loaded at art_mgpu_create (dlopen of librccl.so.1: libart itself does not link it); ART_E_NO_DEVICE if it cannot be. */
 typedef struct ArtMgpu ArtMgpu;
 #define ART_MGPU_ID_BYTES 128

@@ -226,7 +226,7 @@ def test_tile_buffer_pairs_alternate_per_trip(R, get_scene):
     whole = R.renderer_for_scene(sc, (w, h))
     shards = [R.renderer_for_scene(sc, (w, h), shard=(k, G), frames_in_flight=F) for k in range(G)]
     owned, padded = shards[0].shard_tile_count()
-    bufs = [torch.zeros((2, F, padded, 32, 32, 4), dtype=torch.float32, device="cuda") for _ in range(G)]
+    bufs = [torch.zeros((2, F, padded, 32, 32, 3), dtype=torch.float32, device="cuda") for _ in range(G)]
     for s, b in zip(shards, bufs):
         for k in range(F):
             s.bind_color_tiles_pair(k, b[0, k].data_ptr(), b[1, k].data_ptr(), b[0, k].numel() * 4)
@@ -242,11 +242,11 @@ def test_tile_buffer_pairs_alternate_per_trip(R, get_scene):
         s.sync()
     for i in range(2 * F):
         for k, b in enumerate(bufs):
-            ref = sharding.tile_host(want[i], G, k)
+            ref = sharding.tile_host(want[i][..., :3], G, k)   # the tiles carry RGB; alpha is the constant 1
             n = shards[k].shard_tile_count()[0]
             assert np.array_equal(b[i // F % 2, i % F, :n].cpu().numpy().view(np.uint32), ref[:n].view(np.uint32)), (i, k)
     # the second trip's two frames, gathered [shard][slot] and un-tiled by ONE launch
-    gathered = torch.stack([b[1] for b in bufs]).contiguous()             # [G, F, padded, 32, 32, 4]
+    gathered = torch.stack([b[1] for b in bufs]).contiguous()             # [G, F, padded, 32, 32, 3]
     frames = torch.zeros((F, h, w, 4), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     shards[0].untile_gathered(gathered.data_ptr(), G, frames.data_ptr(), None, shard_stride_tiles=F * padded, n_frames=F)
@@ -269,7 +269,7 @@ def test_tile_buffer_ring_and_host_side_frame_completion(R, get_scene):
     whole = R.renderer_for_scene(sc, (w, h))
     s = R.renderer_for_scene(sc, (w, h), shard=(1, G), frames_in_flight=F)
     owned, padded = s.shard_tile_count()
-    b = torch.zeros((NB, F, padded, 32, 32, 4), dtype=torch.float32, device="cuda")
+    b = torch.zeros((NB, F, padded, 32, 32, 3), dtype=torch.float32, device="cuda")
     for k in range(F):
         s.bind_color_tiles_ring(k, [b[i, k].data_ptr() for i in range(NB)], b[0, k].numel() * 4)
     assert s.frames_traced() == 0 and s.frames_done(0, 0)
@@ -282,7 +282,7 @@ def test_tile_buffer_ring_and_host_side_frame_completion(R, get_scene):
             r.camera_mut().set_pos(pos)
             r.upload_state()
             r.trace()
-        want.append(sharding.tile_host(whole.read_color(), G, 1))
+        want.append(sharding.tile_host(whole.read_color()[..., :3], G, 1))
     assert s.frames_traced() == NB * F + 1
     s.sync()
     assert s.frames_done(0, NB * F + 1) and s.frames_done(NB * F, 1)
@@ -504,7 +504,7 @@ def test_several_frames_per_launch_equal_the_single_frames(R, get_scene):
         tiles = None
         if shard[1] > 1:
             owned, padded = many.shard_tile_count()
-            tiles = torch.zeros((2, B, padded, 32, 32, 4), dtype=torch.float32, device="cuda")
+            tiles = torch.zeros((2, B, padded, 32, 32, 3), dtype=torch.float32, device="cuda")
             with pytest.raises(ArtError):
                 many.bind_color_tiles(0, tiles[0, 0].data_ptr(), tiles[0, 0].numel() * 4)      # one frame's worth: too small
             for k in range(2):

@@ -52,7 +52,7 @@ def test_one_rank_job_over_rccl_assembles_the_frame(get_scene, packed):
     whole = R.renderer_for_scene(sc, (w, h))
     r = R.renderer_for_scene(sc, (w, h), frames_in_flight=F, tile_output=True, packed_tiles=packed)
     lay = r.layout()
-    assert (lay["shard_count"], lay["tiles_owned"], lay["tiles_padded"], lay["tile_bytes"]) == (1, 15 * 9, 15 * 9, 4096 if packed else 16384)
+    assert (lay["shard_count"], lay["tiles_owned"], lay["tiles_padded"], lay["tile_bytes"]) == (1, 15 * 9, 15 * 9, 4096 if packed else 12288)
     r.set_frames_per_launch(B)
     r.upload_state()
     for _ in range(3):
@@ -99,7 +99,7 @@ def test_sharded_bench_job_of_child_processes_gathers_the_single_gpu_frame(ranks
     line = json.loads(lines[0])
     assert line["gathered_frame_equals_single_gpu_frame"] is True
     assert line["n_gpus"] == ranks and line["gathers"] >= 4 and line["value"] > 0
-    assert ("B10G11R11" in line["config"]["parallelism"]) == ("packed" in extra) and ("RGBA32F HDR" in line["config"]["parallelism"]) == ("packed" not in extra)
+    assert ("B10G11R11" in line["config"]["parallelism"]) == ("packed" in extra) and ("RGB32F HDR" in line["config"]["parallelism"]) == ("packed" not in extra)
 
 
 @pytest.mark.gpu
