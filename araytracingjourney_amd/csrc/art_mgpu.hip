@@ -203,22 +203,22 @@ int32_t art_mgpu_create(ArtContext *ctx, const ArtMgpuConfig *cfg, const uint8_t
     for (size_t i = 0; i < m->events.size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&m->events[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return bail(mg_fail(ART_E_HIP, std::string("art_mgpu_create: ") + hipGetErrorString(e)));
-    for (uint32_t k = 0; k < m->F; k++) {              // slot k renders into tiles[trip % NBUF][k]
-        void *bufs[kTileRingMax];
-        for (uint32_t b = 0; b < m->NBUF; b++) bufs[b] = m->tiles + ((size_t)b * m->F + k) * m->slot_bytes;
-        r = art_bind_color_tiles_ring(ctx, k, bufs, m->NBUF, m->slot_bytes);
-        if (r) return bail(r);
-    }
-    // Ring slot, tile buffer and group boundaries follow the context's launch count, and every rank must cut its groups alike (a group is one
-    // collective): whatever the caller traced before, the count starts again from zero here, on every rank.
-    r = ring_rewind(ctx);
-    if (r) return bail(r);
     if (cfg->transport == ART_MGPU_RCCL) {
         if (!rccl().ok()) return bail(mg_fail(ART_E_NO_DEVICE, "art_mgpu_create: librccl.so.1 is not loadable"));
         RcclId u; std::memcpy(u.internal, id, ART_MGPU_ID_BYTES);
         int rc = rccl().CommInitRank(&m->comm, (int)cfg->world, u, (int)cfg->rank);   // on the context's device: art_get_layout made it current
         if (rc != 0) { m->comm = nullptr; return bail(mg_fail(ART_E_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(rc))); }
     }
+    for (uint32_t k = 0; k < m->F; k++) {              // slot k renders into tiles[trip % NBUF][k]
+        void *bufs[kTileRingMax];
+        for (uint32_t b = 0; b < m->NBUF; b++) bufs[b] = m->tiles + ((size_t)b * m->F + k) * m->slot_bytes;
+        r = art_bind_color_tiles_ring(ctx, k, bufs, m->NBUF, m->slot_bytes);
+        if (r) { for (uint32_t j = 0; j <= k; j++) (void)art_bind_color_tiles(ctx, j, nullptr, 0); return bail(r); }   // no slot keeps a pointer into the buffers bail() frees
+    }
+    // Ring slot, tile buffer and group boundaries follow the context's launch count, and every rank must cut its groups alike (a group is one
+    // collective): whatever the caller traced before, the count starts again from zero here, on every rank.
+    r = ring_rewind(ctx);
+    if (r) return bail(r);
     *out = m;
     return ART_OK;
 }

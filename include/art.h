@@ -307,6 +307,7 @@ int32_t art_mgpu_device_frame(ArtMgpu *mg, void **dev_ptr, size_t *bytes);
 int32_t art_mgpu_read_frame(ArtMgpu *mg, void *dst, size_t bytes);
 /* frames traced / gathers submitted so far, and how many launches travel per gather */
 int32_t art_mgpu_counts(ArtMgpu *mg, uint64_t *launches_traced, uint64_t *gathers, uint32_t *launches_per_gather);
+/* before art_destroy of its context (it unbinds the tile buffers it owns from the context's ring slots) */
 int32_t art_mgpu_destroy(ArtMgpu *mg);
 
 int32_t art_get_stats(ArtContext *ctx, ArtStats *out);

@@ -73,6 +73,10 @@ def test_one_rank_job_over_rccl_assembles_the_frame(get_scene, packed):
                 assert np.array_equal(got, whole.read_packed()[0]), i
             else:
                 assert np.array_equal(got.view(np.uint32), whole.read_color().view(np.uint32)), i
+    r.timestamp_mark(0)                                  # art_timestamp_*: device time between two points of the frame streams
+    r.trace(); r.trace()
+    r.timestamp_mark(1)
+    assert 0.0 < r.timestamp_elapsed_ms() < 100.0
     c = mg.counts()
     assert c["launches_traced"] == 11 and c["launches_per_gather"] == 2 and c["gathers"] >= 6
     with pytest.raises(_lib.ArtError):                  # a context that writes no tiles cannot take part
