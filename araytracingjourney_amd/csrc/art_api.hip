@@ -235,6 +235,13 @@ static void plan_build_items(const WavePlan &P, const std::vector<uint32_t> &cos
     while (out.size() & 3u) out.push_back(make_uint2(0, 0)); // whole workgroups: the blocks after them keep their place in a workgroup
     for (uint32_t blk : P.order)
         for (uint32_t w = 0; w < 4; w++) { uint32_t b = blk * 4 + w; out.push_back(make_uint2(b, P.level[b] ? 0u : 0xFFFFu)); } // a split block leaves an idle wave behind: the XCD order of the rest is untouched
+    // k_frame runs one wave per workgroup, and workgroup j lands on XCD j % 8 (round-robin dispatch): deal the items so that the four waves of launch
+    // block 8g + x (a 256-pixel block the XCD-aware order gave to XCD x) stay on XCD x -- positions 32g + 8k + x, k = 0..3.  A permutation whatever the
+    // hardware does; only the L2 locality depends on it.
+    std::vector<uint2> q(out);
+    for (size_t g = 0; (g + 1) * 32 <= out.size(); g++)
+        for (uint32_t x = 0; x < 8; x++) for (uint32_t k = 0; k < 4; k++) q[g * 32 + 8 * k + x] = out[g * 32 + 4 * x + k];
+    out.swap(q);
 }
 static int32_t plan_reset(ArtContext *c) {
     WavePlan &P = c->plan;

@@ -104,6 +104,7 @@ __device__ __forceinline__ bool moller_trumbore_flat(const Ray &r, V3 v0, V3 v1,
 constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], conflict-free); deeper entries spill to scratch
 constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (63 key bits + 32 index bits)
 constexpr int kBlock = 256;
+constexpr int kFrameBlock = 64;  // the fused frame: one wave per workgroup
 // tunables of the persistent tracer: {chunk, refill, blocks}.  Measured on config 2 (profiles/README.md):
 // one frame at a time is bound by the slowest wave's critical path -> small chunks, more waves; several frames in flight
 // are throughput-bound -> fewer cursor atomics, fewer resident waves.  art_set_tuning (trace_chunk / trace_refill / trace_blocks)
@@ -906,12 +907,14 @@ __device__ __forceinline__ bool frame_pixel(const FrameArgs &a, uint32_t wid, ui
     return x < a.W && y < a.H && mine;
 }
 template <bool WIDE, int WAVES, bool ONE_LIGHT, bool COUNT = false, bool BATCH = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
-    __shared__ int wstack[(kBlock / 64) * kPacketStack];
-    int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
+__global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
+    // One wave per workgroup: the waves of a frame are independent (nothing is shared, no barrier), and a workgroup of four held its LDS and its place
+    // in the dispatcher's books until its slowest wave was done -- packets differ 25x in steps.  Single-wave groups: +2.5 % rays/s (profiles/README.md r2).
+    __shared__ int wstack[kPacketStack];
+    int *stk = wstack;
     // multi-light instance: the surface record waits in LDS while a shadow packet walks, so the walk runs on as few live registers as the one-light form
-    __shared__ float surf[ONE_LIGHT ? 1 : 14 * kBlock]; // 8 blocks of 4 waves per CU must fit 160 KB with it
-    const uint32_t wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    __shared__ float surf[ONE_LIGHT ? 1 : 14 * kFrameBlock]; // 32 waves per CU must fit 160 KB with it: 4.7 KB a wave
+    const uint32_t wid = blockIdx.x;
     if (wid >= a.n_wave_items) return;
     uint32_t steps = 0; // packet steps of this wave, all walks
     const uint32_t fb = BATCH ? blockIdx.y : 0u;   // which frame of the launch (wave-uniform)
@@ -955,20 +958,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8
     // ONE_LIGHT: no loop, so the surface record is dead once the light is evaluated and the shadow walk runs on few live registers
     if (!ONE_LIGHT) {
         float *q = &surf[threadIdx.x];
-        q[0 * kBlock] = S.world_pos.x; q[1 * kBlock] = S.world_pos.y; q[2 * kBlock] = S.world_pos.z;
-        q[3 * kBlock] = S.N.x; q[4 * kBlock] = S.N.y; q[5 * kBlock] = S.N.z;
-        q[6 * kBlock] = S.Vv.x; q[7 * kBlock] = S.Vv.y; q[8 * kBlock] = S.Vv.z;
-        q[9 * kBlock] = S.albedo.x; q[10 * kBlock] = S.albedo.y; q[11 * kBlock] = S.albedo.z;
-        q[12 * kBlock] = S.metallic; q[13 * kBlock] = S.alpha; // the two N.V terms are recomputed (same operations as shade_surface)
+        q[0 * kFrameBlock] = S.world_pos.x; q[1 * kFrameBlock] = S.world_pos.y; q[2 * kFrameBlock] = S.world_pos.z;
+        q[3 * kFrameBlock] = S.N.x; q[4 * kFrameBlock] = S.N.y; q[5 * kFrameBlock] = S.N.z;
+        q[6 * kFrameBlock] = S.Vv.x; q[7 * kFrameBlock] = S.Vv.y; q[8 * kFrameBlock] = S.Vv.z;
+        q[9 * kFrameBlock] = S.albedo.x; q[10 * kFrameBlock] = S.albedo.y; q[11 * kFrameBlock] = S.albedo.z;
+        q[12 * kFrameBlock] = S.metallic; q[13 * kFrameBlock] = S.alpha; // the two N.V terms are recomputed (same operations as shade_surface)
     }
     for (uint32_t i = 0; i < (ONE_LIGHT ? 1u : a.n_lights); i++) { // uniform loop: the shadow packet needs the whole wave
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
         bool want = false;
         if (!ONE_LIGHT) {
             const float *q = &surf[launder_v((uint32_t)threadIdx.x)]; // reload, do not carry the record across the walk
-            S.world_pos = mk(q[0 * kBlock], q[1 * kBlock], q[2 * kBlock]); S.N = mk(q[3 * kBlock], q[4 * kBlock], q[5 * kBlock]);
-            S.Vv = mk(q[6 * kBlock], q[7 * kBlock], q[8 * kBlock]); S.albedo = mk(q[9 * kBlock], q[10 * kBlock], q[11 * kBlock]);
-            S.metallic = q[12 * kBlock]; S.alpha = q[13 * kBlock]; S.nc_NdotV = dot3(S.N, S.Vv); S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
+            S.world_pos = mk(q[0 * kFrameBlock], q[1 * kFrameBlock], q[2 * kFrameBlock]); S.N = mk(q[3 * kFrameBlock], q[4 * kFrameBlock], q[5 * kFrameBlock]);
+            S.Vv = mk(q[6 * kFrameBlock], q[7 * kFrameBlock], q[8 * kFrameBlock]); S.albedo = mk(q[9 * kFrameBlock], q[10 * kFrameBlock], q[11 * kFrameBlock]);
+            S.metallic = q[12 * kFrameBlock]; S.alpha = q[13 * kFrameBlock]; S.nc_NdotV = dot3(S.N, S.Vv); S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
         }
         if (hit) want = shade_light(a.lights[i], S, c4, ro, rd);
         if (want) sbits |= 1u << (16 + i);
@@ -1114,25 +1117,25 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
 }
 bool launch_frame(const FrameArgs &a, hipStream_t s) { // returns whether the launch wrote a.wave_cost
     const int waves = a.frame_waves; // both instances fit 63 registers without spills (the multi-light one parks its surface record in LDS during the shadow walks)
-    const uint32_t g = (a.n_wave_items + kBlock / 64 - 1) / (kBlock / 64);
+    const uint32_t g = a.n_wave_items;   // one workgroup per wave item
     if (g == 0) return false;
     const bool one = a.n_lights == 1;
     if (a.batch > 1) { // several frames per launch (art_api.hip checks: packets over the binary nodes, at least one light)
         const dim3 gb(g, a.batch);
         const bool count = a.wave_cost != nullptr;
-        if (a.n_lights == 1) { if (count) k_frame<false, 8, true, true, true><<<gb, kBlock, 0, s>>>(a); else k_frame<false, 8, true, false, true><<<gb, kBlock, 0, s>>>(a); }
-        else { if (count) k_frame<false, 8, false, true, true><<<gb, kBlock, 0, s>>>(a); else k_frame<false, 8, false, false, true><<<gb, kBlock, 0, s>>>(a); }
+        if (a.n_lights == 1) { if (count) k_frame<false, 8, true, true, true><<<gb, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, true, false, true><<<gb, kFrameBlock, 0, s>>>(a); }
+        else { if (count) k_frame<false, 8, false, true, true><<<gb, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, false, false, true><<<gb, kFrameBlock, 0, s>>>(a); }
         return count;
     }
     if (a.wave_cost && !a.packet_wide && waves >= 8 && a.n_lights > 0) { // a sampled frame of the wave plan: the step-counting instances
-        if (a.n_lights == 1) k_frame<false, 8, true, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 8, false, true><<<g, kBlock, 0, s>>>(a);
+        if (a.n_lights == 1) k_frame<false, 8, true, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, false, true><<<g, kFrameBlock, 0, s>>>(a);
         return true;
     }
-    if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); return false; }
-    if (a.packet_wide) { if (one) k_frame<true, 8, true><<<g, kBlock, 0, s>>>(a); else k_frame<true, 8, false><<<g, kBlock, 0, s>>>(a); }
-    else if (waves >= 8) { if (one) k_frame<false, 8, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 8, false><<<g, kBlock, 0, s>>>(a); }
-    else if (waves == 7) { if (one) k_frame<false, 7, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 7, false><<<g, kBlock, 0, s>>>(a); }
-    else { if (one) k_frame<false, 6, true><<<g, kBlock, 0, s>>>(a); else k_frame<false, 6, false><<<g, kBlock, 0, s>>>(a); }
+    if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kFrameBlock, 0, s>>>(a); return false; }
+    if (a.packet_wide) { if (one) k_frame<true, 8, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<true, 8, false><<<g, kFrameBlock, 0, s>>>(a); }
+    else if (waves >= 8) { if (one) k_frame<false, 8, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, false><<<g, kFrameBlock, 0, s>>>(a); }
+    else if (waves == 7) { if (one) k_frame<false, 7, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 7, false><<<g, kFrameBlock, 0, s>>>(a); }
+    else { if (one) k_frame<false, 6, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 6, false><<<g, kFrameBlock, 0, s>>>(a); }
     return false;
 }
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s) { k_frame_stats<<<blocks_for(a.n_local), kBlock, 0, s>>>(a, out); }
