@@ -105,6 +105,7 @@ constexpr int kLdsStack = 16;   // per-lane short stack in LDS ([entry][lane], c
 constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (63 key bits + 32 index bits)
 constexpr int kBlock = 256;
 constexpr int kFrameBlock = 64;  // the fused frame: one wave per workgroup
+constexpr int kTraceBlock = 64;  // the persistent per-ray tracer: likewise (its waves share nothing either)
 // tunables of the persistent tracer: {chunk, refill, blocks}.  Measured on config 2 (profiles/README.md):
 // one frame at a time is bound by the slowest wave's critical path -> small chunks, more waves; several frames in flight
 // are throughput-bound -> fewer cursor atomics, fewer resident waves.  art_set_tuning (trace_chunk / trace_refill / trace_blocks)
@@ -150,13 +151,13 @@ template <bool ANY, int OVF> struct TravBase {
     __device__ __forceinline__ void push(int ref, int *lds, int *ovf) {
         // the spill accesses are volatile so that the compiler keeps them apart from the LDS ones: merged, they become flat_load
         // / flat_store on a selected pointer, which waits on vmcnt AND lgkmcnt at every pop
-        if (sp < kLdsStack) lds[sp * kBlock] = ref; else if (sp < kLdsStack + OVF) *(volatile int *)&ovf[sp - kLdsStack] = ref;
+        if (sp < kLdsStack) lds[sp * kTraceBlock] = ref; else if (sp < kLdsStack + OVF) *(volatile int *)&ovf[sp - kLdsStack] = ref;
         sp = min(sp + 1, kLdsStack + OVF); // the tree cannot need more (see the bounds above); never index past the spill area
     }
     __device__ __forceinline__ bool pop(int *lds, int *ovf) { // true: stack empty, the ray is finished
         if (sp == 0) return true;
         sp--;
-        if (sp < kLdsStack) cur = lds[sp * kBlock]; else cur = *(volatile int *)&ovf[sp - kLdsStack];
+        if (sp < kLdsStack) cur = lds[sp * kTraceBlock]; else cur = *(volatile int *)&ovf[sp - kLdsStack];
         return false;
     }
     // accept() of DESIGN.md 1.1 for the triangle in `cur`: exact triangle-AABB slab, then Moeller-Trumbore
@@ -555,9 +556,9 @@ struct TraceArgs {
 // come from eight per-XCD work cursors (one returning atomic per chunk), so neighbouring rays stay on one XCD's L2.
 // Every wave exits once all cursors are exhausted and its lanes are idle.
 template <int MODE, int WIDTH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == MODE_AO ? 8 : 4, 8))) void k_trace(TraceArgs a) {
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MODE == MODE_AO ? 8 : 4, 8))) void k_trace(TraceArgs a) {
     constexpr bool ANY = MODE == MODE_SHADOW || MODE == MODE_QUERY_ANY || MODE == MODE_AO;
-    __shared__ int stack[kLdsStack * kBlock];
+    __shared__ int stack[kLdsStack * kTraceBlock];
     int ovf[WIDTH == 4 ? kOvfStack4 : kOvfStack];
     const uint32_t leaf_batch = a.leaf_batch;
     int *lds = &stack[threadIdx.x];
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 
     }
     if (MODE == MODE_SHADOW && a.count) { // rays this wave traced: one atomic per wave
         for (int off = 32; off >= 1; off >>= 1) traced += (uint32_t)__shfl_xor((int)traced, off);
-        if (lane == 0 && traced) atomicAdd(a.count + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlotCount) * kSlotStride, traced);
+        if (lane == 0 && traced) atomicAdd(a.count + (blockIdx.x % kSlotCount) * kSlotStride, traced);   // one wave per workgroup
     }
 }
 
@@ -1089,15 +1090,15 @@ __global__ __launch_bounds__(kBlock) void k_untile_rgb(const float *__restrict__
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 // persistent grid: enough waves to fill the chip (8 blocks of 4 waves per CU), never more than the work needs
 static inline uint32_t persistent_blocks(uint32_t total, bool pipelined) {
-    uint32_t need = (total + kBlock - 1) / kBlock, cap = tune(pipelined).blocks;
+    uint32_t need = (total + kTraceBlock - 1) / kTraceBlock, cap = tune(pipelined).blocks * (kBlock / kTraceBlock);   // the presets count 256-thread blocks
     return need < cap ? (need ? need : 1u) : cap;
 }
 template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipelined, hipStream_t s) {
     uint32_t nb = persistent_blocks(a.total, pipelined);
     const Tune &t = tune(pipelined);
     a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = 1; // batching was measured slower at every threshold (profiles/README.md)
-    if (kind == 4) k_trace<MODE, 4><<<nb, kBlock, 0, s>>>(a);
-    else k_trace<MODE, 2><<<nb, kBlock, 0, s>>>(a);
+    if (kind == 4) k_trace<MODE, 4><<<nb, kTraceBlock, 0, s>>>(a);
+    else k_trace<MODE, 2><<<nb, kTraceBlock, 0, s>>>(a);
 }
 void launch_primary(const FrameArgs &f, hipStream_t s) {
     if (f.trace_kind[0] == 8) { if (f.packet_wide) k_packet<PK_PRIMARY, true><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); else k_packet<PK_PRIMARY, false><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); return; } // packet walk over the binary nodes
