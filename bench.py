@@ -141,7 +141,7 @@ def main():
     tuning = {k: (float(v) if k == "split_alpha" else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)} or None
     r = make_renderer(device=local_rank, shard=shard, frames_in_flight=F, packed_tiles=packed, tuning=tuning)
     B = 1                             # frames per launch
-    if world > 1 and not args.ao:
+    if (world > 1 or args.frames_per_launch > 1) and not args.ao:
         B = args.frames_per_launch if args.frames_per_launch > 0 else next(b for b in (4, 2, 1) if args.steps % b == 0)
         if args.steps % B:
             raise SystemExit(f"--steps {args.steps} is not a multiple of --frames-per-launch {B}")
