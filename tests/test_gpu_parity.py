@@ -626,6 +626,63 @@ def test_single_triangle_known_answers(R):
     r.close()
 
 
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 5])
+def test_tiny_scenes_on_every_builder(R, orc, n_tris):
+    """one to five triangles (the tree builders' smallest inputs: no internal node, one, two ...): frame and ray queries against the oracle on the
+    default device SAH, the host SAH, PLOC and the LBVH topology"""
+    from araytracingjourney_amd import scenes
+    mb = scenes.MeshBuilder()
+    for k in range(n_tris):
+        z = 1.5 + 0.4 * k
+        mb.add([(-0.6 + 0.2 * k, -0.5, z), (0.7, -0.4 + 0.1 * k, z + 0.1), (0.0, 0.6, z)], [(0, 0), (1, 0), (0, 1)], [(0, 0, -1)] * 3, [(1, 0, 0, 1)] * 3, [0, 1, 2])
+    sc = scenes.Scene("tiny", [mb.finish(scenes.constant_texture((200, 180, 160)))], scenes.cornell().camera, scenes.cornell().lights)
+    S, L, nl = oracle_for(orc, sc)
+    ref = S.render(oracle_camera(orc, sc, 96, 64), L, nl, 96, 64, threads=2, debug=True)
+    rays = random_rays(4000, 11)
+    rtuv, rids, _, _ = S.trace_closest(rays)
+    for kw in ({}, {"tuning": {"tree_builder": 1}}, {"device_tree": True}, {"fast_build": True}):
+        r = R.renderer_for_scene(sc, (96, 64), keep_debug=True, **kw)
+        r.render_frame()
+        assert np.array_equal(r.read_hits()[1], ref["hit_id"]) and np.array_equal(r.read_shadow_bits(), ref["shadow_bits"]), kw
+        assert_radiance_close(r.read_color(), ref["color"])
+        tuv, ids = r.query_closest(rays)
+        assert np.array_equal(ids, rids) and np.array_equal(tuv.view(np.uint32)[:, :3], rtuv.view(np.uint32)[:, :3]), kw
+        assert r.stats()["num_triangles"] == n_tris
+        r.close()
+    assert (ref["hit_id"][..., 0] >= 0).sum() > 100
+
+
+def test_largest_frames_keep_the_size_independent_properties(R, get_scene):
+    """8192 x 4608 (37.7 M pixels, 2 304 x the Cornell fixture; the oracle would need minutes): what must hold whatever the size -- the fused frame
+    equals the staged per-ray frame bit for bit (colour, depth, normal, ray counts), a second trace of the same frame is the same frame, every pixel is
+    written (alpha 1, depth either a hit or the miss value), the eight-way shard sum of ray counts is the whole frame's"""
+    sc = get_scene("sponza_like", 0.12)
+    w, h = 8192, 4608
+    fused = R.renderer_for_scene(sc, (w, h), n_lights=1, frames_in_flight=2)
+    fused.render_frame()
+    c1, d1, n1, st1 = fused.read_color(), fused.read_depth(), fused.read_normal(), fused.stats()
+    fused.render_frame()
+    assert np.array_equal(fused.read_color().view(np.uint32), c1.view(np.uint32))
+    fused.close()
+    assert (c1[..., 3] == 1.0).all() and ((d1 < 10000.0) | (d1 == 10000.0)).all() and np.isfinite(c1).all()
+    assert st1["primary_rays"] == w * h and st1["hit_pixels"] == int((d1 < 10000.0).sum()) and 0 < st1["shadow_rays"] <= st1["hit_pixels"]
+    per_ray = R.renderer_for_scene(sc, (w, h), n_lights=1, tuning={"frame_form": 2})
+    per_ray.render_frame()
+    assert np.array_equal(per_ray.read_color().view(np.uint32), c1.view(np.uint32)) and np.array_equal(per_ray.read_depth().view(np.uint32), d1.view(np.uint32))
+    assert np.array_equal(per_ray.read_normal().view(np.uint32), n1.view(np.uint32))
+    st2 = per_ray.stats()
+    assert (st2["shadow_rays"], st2["hit_pixels"]) == (st1["shadow_rays"], st1["hit_pixels"])
+    per_ray.close()
+    del c1, n1
+    rays = 0
+    for k in range(8):
+        s = R.renderer_for_scene(sc, (w, h), n_lights=1, shard=(k, 8))
+        s.render_frame()
+        rays += s.stats()["shadow_rays"]
+        s.close()
+    assert rays == st1["shadow_rays"]
+
+
 def test_api_state_and_argument_errors(R, get_scene):
     """the reference panics on misuse (unwrap/expect); the C ABI returns ART_E_* with a message"""
     from araytracingjourney_amd import _lib
