@@ -907,6 +907,15 @@ __device__ __forceinline__ bool frame_pixel(const FrameArgs &a, uint32_t wid, ui
     y = (txy >> 16) * kTile + (sub >> 2) * 8u + (lane >> 3);
     return x < a.W && y < a.H && mine;
 }
+#ifdef ART_PHASE_PROF
+// profiling build only (make EXTRA=-DART_PHASE_PROF; tools/phase_prof.py): shader-clock cycles a wave spends in each phase of k_frame, summed over waves
+constexpr uint32_t kPhaseWaves = 1u << 18;
+__device__ uint32_t g_phase[8][kPhaseWaves]; // [phase][wave item]: the last frame that ran wrote it
+__device__ __forceinline__ uint64_t tick(float &dep) { uint64_t t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(dep)); return t; }
+#define PHASE(i, dep) { uint64_t t1_ = tick(dep); if (__lane_id() == 0 && blockIdx.x < kPhaseWaves) g_phase[i][blockIdx.x] = (uint32_t)(t1_ - t0_); t0_ = t1_; }
+#else
+#define PHASE(i, dep)
+#endif
 template <bool WIDE, int WAVES, bool ONE_LIGHT, bool COUNT = false, bool BATCH = false>
 __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
     // One wave per workgroup: the waves of a frame are independent (nothing is shared, no barrier), and a workgroup of four held its LDS and its place
@@ -925,6 +934,9 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
     // carried through the walks: the walks run at the 64-register edge.
     bool in;
     Ray r;
+#ifdef ART_PHASE_PROF
+    float dep0_ = 0.f; uint64_t t0_ = tick(dep0_);
+#endif
     {
         uint32_t p, x, y; bool mine;
         in = frame_pixel(a, wid, p, x, y, mine);
@@ -936,9 +948,11 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         ray_init(r, org, dir, 0.001f, 10000.0f);
     }
     bool on = in;
+    PHASE(0, r.inv.x)
     float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f;
     uint32_t bpos = kNoHit, bgid = kNoHit;
     walk_dispatch<false, WIDE, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps);
+    PHASE(1, tbest)
     uint32_t p, x, y; bool mine;
     frame_pixel(a, wid, p, x, y, mine);
     if (a.keep_hits && mine) a.hits[frame_local + p] = bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
@@ -954,6 +968,7 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         st_nt(&a.depth[pix], out_depth);
         st_nt(&a.normal[pix], make_float4(out_normal.x, out_normal.y, out_normal.z, 1.0f));
     }
+    PHASE(2, S.NdotV)
     float rx = 0.f, ry = 0.f, rz = 0.f;
     uint32_t sbits = 0;
     // ONE_LIGHT: no loop, so the surface record is dead once the light is evaluated and the shadow walk runs on few live registers
@@ -979,9 +994,11 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         Ray sr;
         ray_init(sr, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), 0.01f, ro.w);
         bool son = want;
+        PHASE(3, sr.inv.x)
         float st = son ? sr.tmax : -1.0f, su = 0.f, sv = 0.f;
         uint32_t spos = kNoHit, sgid = kNoHit;
         walk_dispatch<true, WIDE, COUNT>(a, sr, son, stk, st, su, sv, spos, sgid, steps);
+        PHASE(4, st)
         if (want && spos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
             c4 = make_float4(c4.x * 0.05f, c4.y * 0.05f, c4.z * 0.05f, c4.w);
             sbits |= 1u << i;
@@ -1000,6 +1017,10 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         else st_nt_rgb(a.color_tiles, ti, o);
     }
     if (mine) a.pix_bits[frame_local + p] = sbits;
+    PHASE(5, rx)
+#ifdef ART_PHASE_PROF
+    if (__lane_id() == 0 && blockIdx.x < kPhaseWaves) { g_phase[6][blockIdx.x] = 1u; g_phase[7][blockIdx.x] = steps; }
+#endif
     if (COUNT && __lane_id() == 0) a.wave_cost[wid] = steps; // feedback for the next plan (art_api.hip plan_poll)
 }
 
@@ -1155,6 +1176,14 @@ void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t
     launch_trace<MODE_QUERY_ANY>(a, b.kind, false, s);
 }
 // AO resolve: occluded count -> uint(pow(visibility, 2.2) * 255 + 0.5) through a host-built table; 255 where nothing was hit
+#ifdef ART_PHASE_PROF
+extern "C" int32_t art_debug_phase(uint32_t *out, int32_t reset) { // out[8][2^18]
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
+    void *dp = nullptr;
+    if (reset && (hipGetSymbolAddress(&dp, HIP_SYMBOL(g_phase)) != hipSuccess || hipMemset(dp, 0, sizeof(g_phase)) != hipSuccess)) return -1;
+    return 0;
+}
+#endif
 struct AoLut { uint32_t v[65]; };
 __global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_t *__restrict__ occl, uint32_t spp, AoLut lut, uint32_t *__restrict__ ao) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;

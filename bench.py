@@ -44,6 +44,8 @@ def parse():
                                                                       "default 16 on one GPU (one hardware queue each), 12 launches when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed set-up before the warm-up: frames are traced for at least this long (and at least 3 ring depths), so the wave plan "
+                    "has settled and the GPU has left its idle clocks; 0 = the 3 ring depths only")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall clock the CPU baseline repeats the frame for (the contract: a bounded sample, ~10-30 s of CPU work)")
     ap.add_argument("--plain", action="store_true", help="only the contract's timed region (profiling passes: no single-frame spans, no steady-state / camera-path legs, no CPU baseline)")
     ap.add_argument("--tuning", default="", help="A/B sweeps: ArtTuning fields for the benchmarked context, key=value[,key=value...] (include/art.h: frame_form, tree_builder, frame_waves, "
@@ -185,13 +187,15 @@ def main():
             mg.flush()                # every frame traced so far is on the root, un-tiled
         r.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1:                 # the contract's bracket: barrier + synchronize (one process: the synchronize above is the bracket)
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # ---- settle (untimed set-up, like the scene build): the wave plan has sampled frames and re-planned, every stream has run -----------------
-    for _ in range(3 * F):
-        step()
+    settle_launches, t_settle = 0, time.perf_counter()
+    while settle_launches < 3 * F or time.perf_counter() - t_settle < args.settle_seconds:   # ... and the GPU has left its idle clocks (tools/fenced_timeline.py:
+        step()                                                                                  # the first ~20 ms of frames after idling run ~10 % slower)
+        settle_launches += 1
     fence()
     # ---- the contract: W untimed warm-up steps, then EXACTLY K steps between two fences ------------------------------------------------------
     for _ in range((args.warmup + B - 1) // B):   # a step() is one launch = B frames
@@ -402,7 +406,7 @@ def main():
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
         "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
         "camera_path": campath,
-        "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": 3 * F * B,
+        "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": settle_launches * B,
         "tuning": tuning, "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
         "roofline": roof, "cpu_baseline": cpu,
     }
