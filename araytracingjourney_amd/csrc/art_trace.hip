@@ -274,6 +274,16 @@ template <int OCT> __device__ __forceinline__ bool slab_oct(const Ray &r, float 
     return fmaxf(tn, r.tmin) <= fminf(tf, tlimit);
 }
 
+// The packet walks read the tree through the CONSTANT address space: nothing writes nodes or triangles while a frame kernel runs, and only of
+// constant-space loads does the compiler believe that after the frame's own stores (hits, depth, normal) -- a wave-uniform global load behind a store
+// becomes a vector load of 64 equal addresses, which is what the shadow walks of k_frame were until round 2 (node data in 16 VGPRs, the vector L1's latency).
+struct ConstQuads {
+    typedef float Quad __attribute__((ext_vector_type(4)));
+    __attribute__((address_space(4))) const Quad *p;
+    __device__ __forceinline__ float4 operator[](int i) const { Quad v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+};
+template <class T> __device__ __forceinline__ ConstQuads const_quads(const T *p) { ConstQuads q; q.p = (__attribute__((address_space(4))) const ConstQuads::Quad *)(uintptr_t)p; return q; }
+
 template <bool ANY, bool WIDE, int OCT, bool COUNT = false>
 __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps) {
     int cur = 0, sp = 0; // wave-uniform
@@ -287,7 +297,7 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             // point box out at 3e38, which no ray passes (art_build.hip).  Measured against the binary walk on config 2 (profiles/README.md r2d):
             // scalar instructions -43 %, vector instructions +9 % (all four boxes of a node are tested, also below a child the binary walk
             // would have culled), rays/s +2 %: the frame is bound by vector issue, so this stays an A/B form (ArtTuning.packet_wide).
-            const float4 *nq = reinterpret_cast<const float4 *>(a.widef + cur);
+            ConstQuads nq = const_quads(a.widef + cur);
             float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
             const int c0 = __float_as_int(w6.x), c1 = __float_as_int(w6.y), c2 = __float_as_int(w6.z), c3 = __float_as_int(w6.w);
             float te;
@@ -313,7 +323,7 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             }
             cur = next;
         } else if (cur >= 0) {
-            const float4 *nq = reinterpret_cast<const float4 *>(a.nodes + cur);
+            ConstQuads nq = const_quads(a.nodes + cur);
             float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
             int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
             float te0, te1;
@@ -332,7 +342,7 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             else cur = kPop;
         } else {
             uint32_t pos = (uint32_t)~cur;
-            const float4 *tq = reinterpret_cast<const float4 *>(a.tris + pos);
+            ConstQuads tq = const_quads(a.tris + pos);
             float4 va = tq[0], vb = tq[1], vc = tq[2];
             float te = 0.f, t = 0.f, u = 0.f, v = 0.f;
             // accept() = slab(AABB(tri)) AND Moeller-Trumbore: the conjunction is evaluated triangle test first -- the parent already
