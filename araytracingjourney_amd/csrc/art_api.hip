@@ -119,7 +119,7 @@ struct ArtContext {
     bool fused = true;        // packet frames run as ONE launch (k_frame); frame_form 1: the four staged launches
     int tree_builder = 3;     // with fast_trace: 3 = binned SAH on the device (art_sahdev.hip), 1 = the same on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip)
     bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD: keep the Karras tree)
-    bool packet_wide = false; // packets walk the 128-byte 4-wide nodes (shorter critical path, ~4 % less throughput)
+    bool packet_wide = true;  // packets walk the 128-byte 4-wide float nodes (half the dependent node fetches); false: the 64-byte binary nodes
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised (measured: profiles/README.md)
     uint32_t macro = 2;       // XCD-aware launch order: macro-blocks of macro x macro tiles (0: identity)
     bool ao_entry = true;     // AO rays start at the per-pixel entry node (k_ao_entry)
@@ -551,7 +551,7 @@ int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     c->fast_trace = !(c->cfg.flags & ART_FLAG_FAST_BUILD);
     c->tree_builder = (c->cfg.flags & ART_FLAG_DEVICE_TREE) ? 2 : (t->tree_builder == 1 ? 1 : 3);
     c->frame_waves = t->frame_waves ? (int)t->frame_waves : 8;
-    c->packet_wide = t->packet_wide != 0;
+    c->packet_wide = t->packet_wide != 2;   // 0: the default (4-wide), 1: 4-wide, 2: binary
     c->macro = t->block_order == 0 ? 2u : (t->block_order == 1 ? 0u : t->block_order);
     c->ao_entry = t->ao_entry_off == 0;
     set_trace_tune(t->trace_chunk, t->trace_refill, t->trace_blocks);
@@ -701,7 +701,7 @@ int32_t art_set_camera(ArtContext *c, const ArtCamera *cam) {
 
 int32_t art_set_frames_per_launch(ArtContext *c, uint32_t n) {
     if (!c || n == 0 || n > kMaxBatch) return fail(ART_E_INVALID, "art_set_frames_per_launch: 1..4");
-    if (n > 1 && !(c->fused && c->kind_primary == 8 && c->kind_shadow == 8 && !c->packet_wide)) return fail(ART_E_STATE, "art_set_frames_per_launch: only the fused frame over the binary nodes traces several frames per launch");
+    if (n > 1 && !(c->fused && c->kind_primary == 8 && c->kind_shadow == 8)) return fail(ART_E_STATE, "art_set_frames_per_launch: only the fused frame traces several frames per launch");
     if (n == c->B) return ART_OK;
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
@@ -838,7 +838,7 @@ int32_t art_trace(ArtContext *c) {
     FrameArgs a = make_frame_args(c, S);
     if (c->tiled()) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
-    if (c->B > 1 && (!fused || c->packet_wide || c->frame_waves < 8)) return fail(ART_E_STATE, "art_trace: several frames per launch need the default fused frame");
+    if (c->B > 1 && (!fused || c->frame_waves < 8)) return fail(ART_E_STATE, "art_trace: several frames per launch need the default fused frame");
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     c->ev_fused[c->frame_no % ArtContext::kRing] = fused;
     if (c->graph_mode && !fused && S.ext_ring_n < 2) { // a fused frame is a single launch: nothing for a graph to save; alternating tile buffers change a kernel argument

@@ -294,9 +294,10 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             // 4-wide node, float boxes (128 B, two scalar loads).  Its children were sorted at build time along the axis `ax` their centroids spread
             // most on, so the packet's front-to-back order is 0,1,2,3 or 3,2,1,0 by the sign of its rays' direction on that axis -- no per-lane
             // distances, no votes.  (Order only steers the culling: the answer is order-independent)  Absent children carry a
-            // point box out at 3e38, which no ray passes (art_build.hip).  Measured against the binary walk on config 2 (profiles/README.md r2d):
-            // scalar instructions -43 %, vector instructions +9 % (all four boxes of a node are tested, also below a child the binary walk
-            // would have culled), rays/s +2 %: the frame is bound by vector issue, so this stays an A/B form (ArtTuning.packet_wide).
+            // point box out at 3e38, which no ray passes (art_build.hip).  Measured against the binary walk (profiles/README.md r2): scalar
+            // instructions -43 %, vector instructions +9 % (all four boxes of a node are tested, also below a child the binary walk would have
+            // culled), half the dependent node fetches: config 2 +1 %, config 3 +8 %, config 4 +11 % rays/s.  The default since round 2
+            // (ArtTuning.packet_wide = 2 selects the binary walk).
             ConstQuads nq = const_quads(a.widef + cur);
             float4 w0 = nq[0], w1 = nq[1], w2 = nq[2], w3 = nq[3], w4 = nq[4], w5 = nq[5], w6 = nq[6], w7 = nq[7];
             const int c0 = __float_as_int(w6.x), c1 = __float_as_int(w6.y), c2 = __float_as_int(w6.z), c3 = __float_as_int(w6.w);
@@ -908,8 +909,11 @@ __device__ __forceinline__ uint32_t launder(uint32_t v) { asm volatile("" : "+s"
 __device__ __forceinline__ uint32_t launder_v(uint32_t v) { asm volatile("" : "+v"(v)); return v; } // per-lane values
 // what lane `__lane_id()` of wave item `wid` traces: local pixel id, frame coordinates, whether the item's cell mask covers it; returns "traces a ray"
 __device__ __forceinline__ bool frame_pixel(const FrameArgs &a, uint32_t wid, uint32_t &p, uint32_t &x, uint32_t &y, bool &mine) {
-    const uint2 item = a.wave_items[wid];           // wave-uniform: scalar loads, no divisions
-    const uint32_t txy = a.tile_xy[item.x >> 4];    // the block's 32x32 tile: x | y << 16
+    // wave-uniform, read-only tables: constant address space, so these stay scalar loads behind the frame's stores too (no divisions either)
+    typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+    const U2 item_ = ((__attribute__((address_space(4))) const U2 *)(uintptr_t)a.wave_items)[wid];
+    const uint2 item = make_uint2(item_.x, item_.y);
+    const uint32_t txy = ((__attribute__((address_space(4))) const uint32_t *)(uintptr_t)a.tile_xy)[item.x >> 4];    // the block's 32x32 tile: x | y << 16
     const uint32_t lane = __lane_id(), sub = item.x & 15u;
     p = item.x * 64u + lane;
     mine = (item.y >> (((lane >> 4) << 2) | ((lane >> 1) & 3u))) & 1u; // cell = (y/2)*4 + x/2 of the 8x8 block
@@ -1147,28 +1151,27 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
 }
+template <bool WIDE, bool ONE_LIGHT> static void launch_frame_form(const FrameArgs &a, uint32_t g, bool count, hipStream_t s) {
+    if (a.batch > 1) { // several frames per launch
+        const dim3 gb(g, a.batch);
+        if (count) k_frame<WIDE, 8, ONE_LIGHT, true, true><<<gb, kFrameBlock, 0, s>>>(a); else k_frame<WIDE, 8, ONE_LIGHT, false, true><<<gb, kFrameBlock, 0, s>>>(a);
+    } else if (count) k_frame<WIDE, 8, ONE_LIGHT, true><<<g, kFrameBlock, 0, s>>>(a);
+    else k_frame<WIDE, 8, ONE_LIGHT><<<g, kFrameBlock, 0, s>>>(a);
+}
 bool launch_frame(const FrameArgs &a, hipStream_t s) { // returns whether the launch wrote a.wave_cost
-    const int waves = a.frame_waves; // both instances fit 63 registers without spills (the multi-light one parks its surface record in LDS during the shadow walks)
+    const int waves = a.frame_waves; // every instance fits 64 registers without spills (the multi-light one parks its surface record in LDS during the shadow walks)
     const uint32_t g = a.n_wave_items;   // one workgroup per wave item
     if (g == 0) return false;
     const bool one = a.n_lights == 1;
-    if (a.batch > 1) { // several frames per launch (art_api.hip checks: packets over the binary nodes, at least one light)
-        const dim3 gb(g, a.batch);
-        const bool count = a.wave_cost != nullptr;
-        if (a.n_lights == 1) { if (count) k_frame<false, 8, true, true, true><<<gb, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, true, false, true><<<gb, kFrameBlock, 0, s>>>(a); }
-        else { if (count) k_frame<false, 8, false, true, true><<<gb, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, false, false, true><<<gb, kFrameBlock, 0, s>>>(a); }
-        return count;
+    if (!a.packet_wide && waves < 8 && a.batch <= 1) { // A/B forms: the binary walk held to 7 or 6 waves per SIMD (ArtTuning.frame_waves)
+        if (waves == 7) { if (one) k_frame<false, 7, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 7, false><<<g, kFrameBlock, 0, s>>>(a); }
+        else { if (one) k_frame<false, 6, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 6, false><<<g, kFrameBlock, 0, s>>>(a); }
+        return false;
     }
-    if (a.wave_cost && !a.packet_wide && waves >= 8 && a.n_lights > 0) { // a sampled frame of the wave plan: the step-counting instances
-        if (a.n_lights == 1) k_frame<false, 8, true, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, false, true><<<g, kFrameBlock, 0, s>>>(a);
-        return true;
-    }
-    if (a.n_lights == 0) { k_frame<false, 8, false><<<g, kFrameBlock, 0, s>>>(a); return false; }
-    if (a.packet_wide) { if (one) k_frame<true, 8, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<true, 8, false><<<g, kFrameBlock, 0, s>>>(a); }
-    else if (waves >= 8) { if (one) k_frame<false, 8, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 8, false><<<g, kFrameBlock, 0, s>>>(a); }
-    else if (waves == 7) { if (one) k_frame<false, 7, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 7, false><<<g, kFrameBlock, 0, s>>>(a); }
-    else { if (one) k_frame<false, 6, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<false, 6, false><<<g, kFrameBlock, 0, s>>>(a); }
-    return false;
+    const bool count = a.wave_cost != nullptr && a.n_lights > 0; // a sampled frame of the wave plan: the step-counting instances
+    if (a.packet_wide) { if (one) launch_frame_form<true, true>(a, g, count, s); else launch_frame_form<true, false>(a, g, count, s); }
+    else { if (one) launch_frame_form<false, true>(a, g, count, s); else launch_frame_form<false, false>(a, g, count, s); }
+    return count;
 }
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s) { k_frame_stats<<<blocks_for(a.n_local), kBlock, 0, s>>>(a, out); }
 void launch_accumulate(const FrameArgs &a, hipStream_t s) { k_accumulate<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }

@@ -44,6 +44,8 @@ def parse():
                                                                       "default 16 on one GPU (one hardware queue each), 12 launches when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--watchdog-seconds", type=float, default=0.0, help="if the run has not finished after this long, every rank prints its Python stack and exits 1 (0 = off): a hung job "
+                    "then ends with a diagnosis instead of holding the GPU until someone kills it")
     ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed set-up before the warm-up: frames are traced for at least this long (and at least 3 ring depths), so the wave plan "
                     "has settled and the GPU has left its idle clocks; 0 = the 3 ring depths only")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall clock the CPU baseline repeats the frame for (the contract: a bounded sample, ~10-30 s of CPU work)")
@@ -79,6 +81,9 @@ def host_cores():
 
 def main():
     args = parse()
+    if args.watchdog_seconds > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -192,10 +197,19 @@ def main():
             torch.cuda.synchronize()
 
     # ---- settle (untimed set-up, like the scene build): the wave plan has sampled frames and re-planned, every stream has run -----------------
+    # ... and the GPU has left its idle clocks (tools/fenced_timeline.py).  Every rank makes the SAME number of launches (each is part of a gather):
+    # they come in rounds of 3 ring depths, and rank 0's clock decides after each round whether another one follows.
     settle_launches, t_settle = 0, time.perf_counter()
-    while settle_launches < 3 * F or time.perf_counter() - t_settle < args.settle_seconds:   # ... and the GPU has left its idle clocks (tools/fenced_timeline.py:
-        step()                                                                                  # the first ~20 ms of frames after idling run ~10 % slower)
-        settle_launches += 1
+    while True:
+        for _ in range(3 * F):
+            step()
+        settle_launches += 3 * F
+        more = [time.perf_counter() - t_settle < args.settle_seconds]
+        if world > 1:
+            fence()       # every gather of the round is through (they are submitted lazily, from later launches or the flush) before anyone waits on the control plane
+            dist.broadcast_object_list(more, src=0)
+        if not more[0]:
+            break
     fence()
     # ---- the contract: W untimed warm-up steps, then EXACTLY K steps between two fences ------------------------------------------------------
     for _ in range((args.warmup + B - 1) // B):   # a step() is one launch = B frames

@@ -324,7 +324,7 @@ typedef struct ArtTuning {
     uint32_t frame_form;        /* 0 one fused launch per frame (k_frame) | 1 four staged launches, packet walks | 2 four staged launches, per-ray walks */
     uint32_t tree_builder;      /* 0 the context's default (binned SAH on the device; ART_FLAG_FAST_BUILD: LBVH topology; ART_FLAG_DEVICE_TREE: PLOC) | 1 binned SAH on the host threads */
     uint32_t frame_waves;       /* fused frame: occupancy target per SIMD: 0 = 8 | 6 | 7 | 8 */
-    uint32_t packet_wide;       /* 1: packets walk the 128-byte 4-wide float nodes */
+    uint32_t packet_wide;       /* packet walks: 0 = default (the 128-byte 4-wide float nodes), 1 = 4-wide, 2 = the 64-byte binary nodes */
     uint32_t primary_walk, shadow_walk, ao_walk; /* override one ray type's walk: 0 default | 8 packet | 2 per-ray binary | 4 per-ray 4-wide quantised */
     uint32_t block_order;       /* launch order of the 256-pixel blocks: 0 XCD-aware macro-blocks of 2x2 tiles | 1 identity | n: macro-blocks of n x n tiles */
     uint32_t fixed_waves;       /* 1: no adaptive wave plan (like ART_FLAG_FIXED_WAVES) */

@@ -440,8 +440,8 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene):
     for name, got in (("staged packets", frame(4, tuning={"frame_form": 1})), ("per-ray", frame(1, tuning={"frame_form": 2})), ("fused, one frame in flight", frame(1)),
                       ("fused on the LBVH topology", frame(4, fast_build=True)), ("fused on the device-built (PLOC) tree", frame(4, device_tree=True)),
                       ("per-ray on the PLOC tree", frame(1, device_tree=True, tuning={"frame_form": 2})), ("per-ray on the LBVH topology", frame(1, fast_build=True, tuning={"frame_form": 2})),
-                      ("fused on the host-built SAH tree", frame(4, tuning={"tree_builder": 1})), ("fused, 7 waves/SIMD", frame(4, tuning={"frame_waves": 7})), ("fused, no block reordering", frame(4, tuning={"block_order": 1})),
-                      ("staged, per-ray primary + packet shadow", frame(2, tuning={"frame_form": 1, "primary_walk": 2})), ("fused, 4-wide float packet nodes", frame(4, tuning={"packet_wide": 1}))):
+                      ("fused on the host-built SAH tree", frame(4, tuning={"tree_builder": 1})), ("fused, 7 waves/SIMD", frame(4, tuning={"frame_waves": 7, "packet_wide": 2})), ("fused, no block reordering", frame(4, tuning={"block_order": 1})),
+                      ("staged, per-ray primary + packet shadow", frame(2, tuning={"frame_form": 1, "primary_walk": 2})), ("fused, binary packet nodes", frame(4, tuning={"packet_wide": 2}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
         assert got[3]["shadow_rays"] == ref[3]["shadow_rays"] and got[3]["hit_pixels"] == ref[3]["hit_pixels"], name

@@ -86,6 +86,20 @@ def test_one_rank_job_over_rccl_assembles_the_frame(get_scene, packed):
     mg.close(); r.close(); whole.close()
 
 
+def _run_job(cmd, env, seconds):
+    """the job in a process group of its own: a job that hangs fails its test and is killed with all its ranks, it does not take the run with it"""
+    import signal
+    import types
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=seconds)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        so, se = p.communicate()
+        return types.SimpleNamespace(returncode=-9, stdout=so, stderr=se + f"\n[killed after {seconds} s]")
+    return types.SimpleNamespace(returncode=p.returncode, stdout=so, stderr=se)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks,extra", [(2, []), (2, ["--gather", "packed"]), (3, ["--compositor", "dedicated"]), (2, ["--ao", "4"]), (3, ["--gather-launches", "3", "--frames-per-launch", "2"])],
                          ids=["shared", "shared-packed", "dedicated", "ao", "groups-of-3x2"])
@@ -96,8 +110,8 @@ def test_sharded_bench_job_of_child_processes_gathers_the_single_gpu_frame(ranks
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--detail", "0.12",
-           "--width", "640", "--height", "360", "--frames-in-flight", "6"] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+           "--width", "640", "--height", "360", "--frames-in-flight", "6", "--settle-seconds", "0.05", "--watchdog-seconds", "150"] + extra
+    out = _run_job(cmd, env, 240)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads(lines[0])
