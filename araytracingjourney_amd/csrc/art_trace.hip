@@ -349,14 +349,15 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             // accept() = slab(AABB(tri)) AND Moeller-Trumbore: the conjunction is evaluated triangle test first -- the parent already
             // tested this very box for the packet, so nearly every wave would pay for the slab, while few lanes survive the triangle test
             bool acc = moller_trumbore_flat(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v) && on;
-            if (acc) acc = slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
+            if (acc) acc = slab_oct<OCT>(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
                                 fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te);
             // the ray state changes through selects, outside the divergent branches (no register copies around them)
             if (ANY) { bpos = acc ? pos : bpos; on = on && !acc; tbest = acc ? -1.0f : tbest; } // first accepted triangle: this lane is done
             else {
-                float teff = fmaxf(t, te);
+                float teff;   // = fmaxf(t, te): one v_max_f32 (fmaxf first quiets both operands, which are the results of arithmetic here: two more instructions a step)
+                asm("v_max_f32 %0, %1, %2" : "=v"(teff) : "v"(t), "v"(te));
                 uint32_t gid = __float_as_uint(vc.w);
-                bool better = acc && (teff < tbest || (teff == tbest && gid < bgid));
+                bool better = acc & ((teff < tbest) | ((teff == tbest) & (gid < bgid))); // (bitwise: three compares and three mask operations, no nested exec regions)
                 tbest = better ? teff : tbest; bu = better ? u : bu; bv = better ? v : bv; bpos = better ? pos : bpos; bgid = better ? gid : bgid;
             }
             cur = kPop;
