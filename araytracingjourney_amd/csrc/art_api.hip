@@ -125,6 +125,7 @@ struct ArtContext {
     bool ao_entry = true;     // AO rays start at the per-pixel entry node (k_ao_entry)
     // device scene
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
+    std::vector<uint32_t> h_first_tri; // first global triangle id of every primitive slot (ascending): gid -> (primitive, triangle) on the host
     Lbvh bvh{};
     uint32_t T = 0;
     ArtCamera camera{};
@@ -453,6 +454,14 @@ bool mat4_inverse(const float *m, float *o) {
 
 } // namespace
 
+// hit records name a triangle by its global id: the primitive is the last slot whose first triangle is <= gid (k_soup's rule)
+static void gid_to_ids(const ArtContext *c, uint32_t gid, int32_t *ids) {
+    const std::vector<uint32_t> &f = c->h_first_tri;
+    size_t lo = 0, hi = f.size();
+    while (hi - lo > 1) { size_t mid = (lo + hi) >> 1; if (f[mid] <= gid) lo = mid; else hi = mid; }
+    ids[0] = (int32_t)lo; ids[1] = (int32_t)(gid - f[lo]);
+}
+
 int32_t art::ring_rewind(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "ring_rewind: null context");
     int32_t r = use_device(c); if (r) return r;
@@ -656,6 +665,7 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(c->d_prims.ensure(dp.size())); HIPC(c->d_first_tri.ensure(first.size()));
     HIPC(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(c->d_first_tri.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    c->h_first_tri = first;
     c->T = T;
     BuildInputs in{c->d_prims.p, (uint32_t)dp.size(), c->d_first_tri.p, T, c->cfg.morton_bits};
     hipEvent_t e0, e1;
@@ -1259,7 +1269,7 @@ int32_t art_read_hits(ArtContext *c, float *tuv, int32_t *ids, size_t n_pixels) 
         uint32_t pos; std::memcpy(&pos, &h[p].w, 4);
         tuv[4 * i] = h[p].x; tuv[4 * i + 1] = h[p].y; tuv[4 * i + 2] = h[p].z;
         if (pos == kNoHit) { ids[2 * i] = -1; ids[2 * i + 1] = -1; }
-        else { uint32_t pr, tr; std::memcpy(&pr, &tris[pos].v[0].w, 4); std::memcpy(&tr, &tris[pos].v[1].w, 4); ids[2 * i] = (int32_t)pr; ids[2 * i + 1] = (int32_t)tr; }
+        else { uint32_t gid; std::memcpy(&gid, &tris[pos].f[15], 4); gid_to_ids(c, gid, ids + 2 * i); }
     }
     return ART_OK;
 }
@@ -1308,7 +1318,7 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
         uint32_t pos; std::memcpy(&pos, &h[i].w, 4);
         tuv[4 * i] = h[i].x; tuv[4 * i + 1] = h[i].y; tuv[4 * i + 2] = h[i].z; tuv[4 * i + 3] = 0;
         if (pos == kNoHit) { ids[2 * i] = -1; ids[2 * i + 1] = -1; }
-        else { uint32_t pr, tr; std::memcpy(&pr, &tris[pos].v[0].w, 4); std::memcpy(&tr, &tris[pos].v[1].w, 4); ids[2 * i] = (int32_t)pr; ids[2 * i + 1] = (int32_t)tr; }
+        else { uint32_t gid; std::memcpy(&gid, &tris[pos].f[15], 4); gid_to_ids(c, gid, ids + 2 * i); }
     }
     return ART_OK;
 }

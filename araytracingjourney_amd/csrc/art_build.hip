@@ -139,9 +139,11 @@ __global__ __launch_bounds__(256) void k_leaves(uint32_t T, const uint32_t *__re
     const float *w = triw + (size_t)g * 9;
     uint32_t pr = tri_prim[g];
     DevTri t;
-    t.v[0] = make_float4(w[0], w[1], w[2], __uint_as_float(pr));
-    t.v[1] = make_float4(w[3], w[4], w[5], __uint_as_float(g - first_tri[pr]));
-    t.v[2] = make_float4(w[6], w[7], w[8], __uint_as_float(g));
+    for (int k = 0; k < 3; k++) {
+        t.f[k] = w[k]; t.f[3 + k] = w[3 + k] - w[k]; t.f[6 + k] = w[6 + k] - w[k];
+        t.f[9 + k] = fminf(fminf(w[k], w[3 + k]), w[6 + k]); t.f[12 + k] = fmaxf(fmaxf(w[k], w[3 + k]), w[6 + k]);
+    }
+    t.f[15] = __uint_as_float(g);
     tris[p] = t;
     // shading record: get_indices + three vertex fetches of raytrace.rgen.glsl:107-114, done once
     const DevPrim &P = prims[pr];

@@ -42,8 +42,12 @@ static_assert(sizeof(DevNode4) == 64, "DevNode4 layout");
 //   child is a point box at +3e38, which no slab test passes
 struct alignas(16) DevNodeW { float box[4][6]; int32_t child[4]; uint32_t valid; uint32_t pad[3]; };
 static_assert(sizeof(DevNodeW) == 128, "DevNodeW layout");
-// 48-byte triangle in leaf order: v0.xyz|prim  v1.xyz|tri-in-prim  v2.xyz|gid
-struct alignas(16) DevTri { float4 v[3]; };
+// 64-byte triangle in leaf order, everything accept() needs in the form it needs it (one 64-byte scalar load for a packet):
+//   f[0..2] v0 | f[3..5] e1 = v1 - v0 | f[6..8] e2 = v2 - v0 | f[9..11] box lo | f[12..14] box hi | f[15] gid (bits)
+// e1, e2 and the box are the very float operations the tests would otherwise repeat per ray (one subtraction each; min / max of the three vertices),
+// done once by k_leaves: Moeller-Trumbore and the triangle's own slab see the same bits.  (primitive, triangle-in-primitive follow from gid on the host.)
+struct alignas(16) DevTri { float f[16]; };
+static_assert(sizeof(DevTri) == 64, "DevTri layout");
 // 144-byte shading record in leaf order: everything raytrace.rgen.glsl:107-114 fetches through PrimitiveInfo -> indices ->
 // three 48-byte vertices, gathered once at build time so that hit reconstruction is one dependent fetch instead of three.
 //   f[0..8] object-space positions p0 p1 p2 | f[9..14] uv0 uv1 uv2 | f[15..23] normals | f[24..32] tangent.xyz | f[33] v0.tangent.w | f[34] primitive id (bits)

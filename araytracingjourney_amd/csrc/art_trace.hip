@@ -67,9 +67,8 @@ __device__ __forceinline__ bool slab(const Ray &r, float lx, float ly, float lz,
     return fmaxf(tn, r.tmin) <= fminf(tf, tlimit);
 }
 #define ART_BARY_EPS 1.0e-6f
-// Moller-Trumbore, two-sided (instance flags 0, vk_model.rs:374), edges fattened by ART_BARY_EPS, tmin < t < tmax
-__device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v2, float &t, float &u, float &v) {
-    V3 e1 = v1 - v0, e2 = v2 - v0;
+// Moller-Trumbore, two-sided (instance flags 0, vk_model.rs:374), edges fattened by ART_BARY_EPS, tmin < t < tmax; e1 = v1 - v0, e2 = v2 - v0 (DevTri)
+__device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 e1, V3 e2, float &t, float &u, float &v) {
     V3 p = cross3(r.d, e2);
     float det = dot3(e1, p);
     if (det == 0.0f) return false;
@@ -88,8 +87,7 @@ __device__ __forceinline__ bool moller_trumbore(const Ray &r, V3 v0, V3 v1, V3 v
 
 // the same arithmetic without the early exits: in a packet some lane nearly always survives each test, so the wave pays for
 // every stage anyway and the exits only add exec-mask bookkeeping (det == 0 lanes compute inf/NaN that the flag discards)
-__device__ __forceinline__ bool moller_trumbore_flat(const Ray &r, V3 v0, V3 v1, V3 v2, float &t, float &u, float &v) {
-    V3 e1 = v1 - v0, e2 = v2 - v0;
+__device__ __forceinline__ bool moller_trumbore_flat(const Ray &r, V3 v0, V3 e1, V3 e2, float &t, float &u, float &v) {
     V3 p = cross3(r.d, e2);
     float det = dot3(e1, p);
     float inv = 1.0f / det;
@@ -164,16 +162,15 @@ template <bool ANY, int OVF> struct TravBase {
     __device__ __forceinline__ bool step_leaf(const DevTri *__restrict__ tris, int *lds, int *ovf) {
         uint32_t pos = (uint32_t)~cur;
         const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
-        float4 va = tq[0], vb = tq[1], vc = tq[2];
+        float4 ta = tq[0], tb = tq[1], tc = tq[2], td = tq[3];   // v0 e1 e2 lo hi gid (DevTri)
         float te, t, u, v;
         // triangle test first: the lane is here because this very box passed in the parent, so the slab (needed for t_eff and for
         // the conjunction) would nearly always run; after the triangle test it runs for the few hits only.  Same accept().
-        if (moller_trumbore(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v)) {
-            if (slab(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
-                     fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te)) {
+        if (moller_trumbore(r, mk(ta.x, ta.y, ta.z), mk(ta.w, tb.x, tb.y), mk(tb.z, tb.w, tc.x), t, u, v)) {
+            if (slab(r, tc.y, tc.z, tc.w, td.x, td.y, td.z, tbest, te)) {
                 if (ANY) { bpos = pos; tbest = t; return true; }
                 float teff = fmaxf(t, te);
-                uint32_t gid = __float_as_uint(vc.w);
+                uint32_t gid = __float_as_uint(td.w);
                 if (teff < tbest || (teff == tbest && gid < bgid)) { tbest = teff; bu = u; bv = v; bpos = pos; bgid = gid; }
             }
         }
@@ -344,19 +341,18 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
         } else {
             uint32_t pos = (uint32_t)~cur;
             ConstQuads tq = const_quads(a.tris + pos);
-            float4 va = tq[0], vb = tq[1], vc = tq[2];
+            float4 ta = tq[0], tb = tq[1], tc = tq[2], td = tq[3];   // v0 e1 e2 lo hi gid: one 64-byte scalar load (DevTri)
             float te = 0.f, t = 0.f, u = 0.f, v = 0.f;
             // accept() = slab(AABB(tri)) AND Moeller-Trumbore: the conjunction is evaluated triangle test first -- the parent already
             // tested this very box for the packet, so nearly every wave would pay for the slab, while few lanes survive the triangle test
-            bool acc = moller_trumbore_flat(r, mk(va.x, va.y, va.z), mk(vb.x, vb.y, vb.z), mk(vc.x, vc.y, vc.z), t, u, v) && on;
-            if (acc) acc = slab_oct<OCT>(r, fminf(fminf(va.x, vb.x), vc.x), fminf(fminf(va.y, vb.y), vc.y), fminf(fminf(va.z, vb.z), vc.z),
-                                fmaxf(fmaxf(va.x, vb.x), vc.x), fmaxf(fmaxf(va.y, vb.y), vc.y), fmaxf(fmaxf(va.z, vb.z), vc.z), tbest, te);
+            bool acc = moller_trumbore_flat(r, mk(ta.x, ta.y, ta.z), mk(ta.w, tb.x, tb.y), mk(tb.z, tb.w, tc.x), t, u, v) && on;
+            if (acc) acc = slab_oct<OCT>(r, tc.y, tc.z, tc.w, td.x, td.y, td.z, tbest, te);
             // the ray state changes through selects, outside the divergent branches (no register copies around them)
             if (ANY) { bpos = acc ? pos : bpos; on = on && !acc; tbest = acc ? -1.0f : tbest; } // first accepted triangle: this lane is done
             else {
                 float teff;   // = fmaxf(t, te): one v_max_f32 (fmaxf first quiets both operands, which are the results of arithmetic here: two more instructions a step)
                 asm("v_max_f32 %0, %1, %2" : "=v"(teff) : "v"(t), "v"(te));
-                uint32_t gid = __float_as_uint(vc.w);
+                uint32_t gid = __float_as_uint(td.w);
                 bool better = acc & ((teff < tbest) | ((teff == tbest) & (gid < bgid))); // (bitwise: three compares and three mask operations, no nested exec regions)
                 tbest = better ? teff : tbest; bu = better ? u : bu; bv = better ? v : bv; bpos = better ? pos : bpos; bgid = better ? gid : bgid;
             }
