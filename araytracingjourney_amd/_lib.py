@@ -62,7 +62,7 @@ class ArtGlbCopyInfo(C.Structure):
 class ArtTuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("frame_form", "tree_builder", "frame_waves", "packet_wide", "primary_walk", "shadow_walk", "ao_walk", "block_order", "fixed_waves",
                                           "split_fixed_steps", "split_min_steps")] + [("split_alpha", C.c_float)] + \
-               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log")]
+               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder")]
 
 
 class ArtLayout(C.Structure):
@@ -159,6 +159,7 @@ SYMBOLS = {
     "art_query_any": (_I32, [_P, _P, _U32, _P]),
     "art_get_lbvh": (_I32, [_P] + [_P] * 7),
     "art_get_traversal_tree": (_I32, [_P, _P, _P, _P]),
+    "art_get_wide_nodes": (_I32, [_P, _P, _P, _SZ, _P]),
     "art_glb_last_error": (C.c_char_p, []),
     "art_glb_open": (_I32, [C.c_char_p, _I32, _I32, _P]),
     "art_glb_close": (_I32, [_P]),

@@ -123,6 +123,7 @@ struct ArtContext {
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised (measured: profiles/README.md)
     uint32_t macro = 2;       // XCD-aware launch order: macro-blocks of macro x macro tiles (0: identity)
     bool ao_entry = true;     // AO rays start at the per-pixel entry node (k_ao_entry)
+    bool wide_on_host = false; // ArtTuning.wide_builder
     // device scene
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
     std::vector<uint32_t> h_first_tri; // first global triangle id of every primitive slot (ascending): gid -> (primitive, triangle) on the host
@@ -207,7 +208,7 @@ int32_t ensure_wide(ArtContext *c, bool needed) {
     hipEvent_t e0, e1; float ms = 0;
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     HIPC(hipEventRecord(e0, c->main_stream()));
-    hipError_t e = wide_build(c->bvh, c->T, c->main_stream());
+    hipError_t e = wide_build(c->bvh, c->T, c->main_stream(), c->wide_on_host);
     if (e == hipSuccess) e = hipEventRecord(e1, c->main_stream());
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
@@ -563,6 +564,7 @@ int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     c->packet_wide = t->packet_wide != 2;   // 0: the default (4-wide), 1: 4-wide, 2: binary
     c->macro = t->block_order == 0 ? 2u : (t->block_order == 1 ? 0u : t->block_order);
     c->ao_entry = t->ao_entry_off == 0;
+    c->wide_on_host = t->wide_builder == 1;
     set_trace_tune(t->trace_chunk, t->trace_refill, t->trace_blocks);
     g_build_log = t->log;
     c->built = false; c->frame_ready = false; c->traced = false;   // the tree and the frame layout are made again with the new choices
@@ -1373,6 +1375,21 @@ int32_t art_get_traversal_tree(ArtContext *c, int32_t *child, float *node_lo, fl
     if (child && NI) HIPC(hipMemcpy(child, sah ? c->bvh.trav_child : c->bvh.child, NI * 8, hipMemcpyDeviceToHost));
     if (node_lo && NI) HIPC(hipMemcpy(node_lo, sah ? c->bvh.trav_lo : c->bvh.node_lo, NI * 12, hipMemcpyDeviceToHost));
     if (node_hi && NI) HIPC(hipMemcpy(node_hi, sah ? c->bvh.trav_hi : c->bvh.node_hi, NI * 12, hipMemcpyDeviceToHost));
+    return ART_OK;
+}
+
+// the 4-wide collapse of that tree, as the walks read it: n_nodes records of 64 B (quantised, per-ray walks) and of 128 B (float boxes, packet walks).
+// Builds it if no walk has needed it yet.  Either pointer may be NULL; *n_nodes is always set.
+int32_t art_get_wide_nodes(ArtContext *c, void *quantised, void *floats, size_t capacity_nodes, uint32_t *n_nodes) {
+    if (!c || !n_nodes) return fail(ART_E_INVALID, "art_get_wide_nodes: null argument");
+    if (!c->built) return fail(ART_E_STATE, "art_get_wide_nodes: scene not built");
+    int32_t r = use_device(c); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    r = ensure_wide(c, true); if (r) return r;
+    *n_nodes = c->bvh.n_wide;
+    if ((quantised || floats) && capacity_nodes < c->bvh.n_wide) return fail(ART_E_INVALID, "art_get_wide_nodes: buffers too small");
+    if (quantised) HIPC(hipMemcpy(quantised, c->bvh.wide, (size_t)c->bvh.n_wide * sizeof(DevNode4), hipMemcpyDeviceToHost));
+    if (floats) HIPC(hipMemcpy(floats, c->bvh.widef, (size_t)c->bvh.n_wide * sizeof(DevNodeW), hipMemcpyDeviceToHost));
     return ART_OK;
 }
 

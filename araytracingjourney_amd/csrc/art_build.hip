@@ -226,7 +226,11 @@ inline float half_area(const float *lo, const float *hi) {
 }
 } // namespace
 
-hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
+// ceil(log2(x)) for x > 0, exactly (frexp is exact; log2 of a double is not guaranteed to be the same on the host and the device)
+__host__ __device__ inline int ceil_log2(double x) { int ex; double m = frexp(x, &ex); return m == 0.5 ? ex - 1 : ex; }
+
+// the collapse on the host, one thread (ArtTuning.wide_builder = 1; what round 1 shipped): the reference the device collapse below is tested against
+static hipError_t wide_build_host(Lbvh &l, uint32_t T, hipStream_t s) {
     if (l.wide) return hipSuccess; // already built for this tree
     const uint32_t NI = T > 1 ? T - 1 : 0;
     std::vector<int32_t> child(NI ? (size_t)NI * 2 : 2);
@@ -286,7 +290,7 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
         for (int k = 0; k < 3; k++) {
             // smallest power of two with 255 * scale >= extent (as evaluated by the device's fma), at least 2^-100
             double ext = (double)top[k] - (double)org[k];
-            int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -100;
+            int e = ext > 0 ? ceil_log2(ext / 255.0) : -100;
             if (e < -100) e = -100;
             for (;;) { scale[k] = std::ldexp(1.0f, e); if (std::fmaf(255.0f, scale[k], org[k]) >= top[k]) break; e++; }
             ebits[k] = (uint32_t)(e + 127);
@@ -322,6 +326,148 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s) {
     HIPQ(hipMalloc(&l.widef, widef.size() * sizeof(DevNodeW)));
     HIPQ(hipMemcpy(l.widef, widef.data(), widef.size() * sizeof(DevNodeW), hipMemcpyHostToDevice));
     return hipSuccess;
+}
+
+// ---- the same collapse on the device, level by level -------------------------------------------------------------------------------------------
+// A wide node is a binary node whose two children are expanded greedily (largest half-area first) to at most four.  Level L's wide nodes are the
+// internal children of level L-1's, in order: the index of a child is (first index of its level) + (exclusive scan of the internal-children counts),
+// which is exactly the breadth-first numbering the host loop produces -- the two builders emit the same arrays, bit for bit.
+struct WideIn { const int32_t *child; const float *nlo, *nhi, *llo, *lhi; };
+__device__ inline void wide_box(const WideIn &in, int32_t ref, const float *&lo, const float *&hi) {
+    if (ref < 0) { lo = in.llo + 3 * (size_t)(~ref); hi = in.lhi + 3 * (size_t)(~ref); }
+    else { lo = in.nlo + 3 * (size_t)ref; hi = in.nhi + 3 * (size_t)ref; }
+}
+// pass 1: the (sorted) children of every wide node of the level, and how many of them are internal
+__global__ __launch_bounds__(256) void k_wide_expand(WideIn in, const int32_t *__restrict__ front, uint32_t n, int32_t *__restrict__ cand_out /*4 per node*/,
+                                                     uint32_t *__restrict__ meta /*nc | axis << 8*/, uint32_t *__restrict__ n_internal) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    int32_t cand[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}; int nc = 0;
+    const int32_t root = front[w];
+    if (root < 0) cand[nc++] = root; // single triangle: a root with one leaf child
+    else {
+        cand[nc++] = in.child[2 * (size_t)root]; cand[nc++] = in.child[2 * (size_t)root + 1];
+        while (nc < 4) {
+            int best = -1; float ba = -1.0f;
+            for (int i = 0; i < nc; i++)
+                if (cand[i] >= 0) { const float *lo, *hi; wide_box(in, cand[i], lo, hi); float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2]; float a = dx * dy + dy * dz + dz * dx; if (a > ba) { ba = a; best = i; } }
+            if (best < 0) break;
+            int32_t nn = cand[best];
+            cand[best] = in.child[2 * (size_t)nn];
+            cand[nc++] = in.child[2 * (size_t)nn + 1];
+        }
+    }
+    uint32_t sort_axis = 0; float best_spread = -1.0f;
+    float cen[3][4];
+    for (uint32_t k = 0; k < 3; k++) {
+        float lo_c = INFINITY, hi_c = -INFINITY;
+        for (int i = 0; i < nc; i++) { const float *lo, *hi; wide_box(in, cand[i], lo, hi); float c = 0.5f * lo[k] + 0.5f * hi[k]; cen[k][i] = c; lo_c = fminf(lo_c, c); hi_c = fmaxf(hi_c, c); }
+        if (hi_c - lo_c > best_spread) { best_spread = hi_c - lo_c; sort_axis = k; }
+    }
+    float key[4];
+    for (int i = 0; i < nc; i++) key[i] = sort_axis == 0 ? cen[0][i] : (sort_axis == 1 ? cen[1][i] : cen[2][i]);
+    for (int i = 1; i < nc; i++) // stable insertion sort by centre (std::stable_sort's order)
+        for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { float tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk; int32_t tc = cand[j]; cand[j] = cand[j - 1]; cand[j - 1] = tc; }
+    uint32_t ni = 0;
+    for (int i = 0; i < nc; i++) ni += cand[i] >= 0;
+    for (int i = 0; i < 4; i++) cand_out[4 * (size_t)w + i] = cand[i];
+    meta[w] = (uint32_t)nc | (sort_axis << 8);
+    n_internal[w] = ni;
+}
+// pass 2: the two node records of every wide node of the level; its internal children become the next level's wide nodes
+__global__ __launch_bounds__(256) void k_wide_emit(WideIn in, uint32_t n, uint32_t first /*wide index of this level's first node*/, const int32_t *__restrict__ cand_in,
+                                                   const uint32_t *__restrict__ meta, const uint32_t *__restrict__ offs, DevNode4 *__restrict__ wide,
+                                                   DevNodeW *__restrict__ widef, int32_t *__restrict__ next_front) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const int nc = (int)(meta[w] & 255u); const uint32_t sort_axis = meta[w] >> 8;
+    int32_t cand[4];
+    for (int i = 0; i < 4; i++) cand[i] = cand_in[4 * (size_t)w + i];
+    DevNode4 d; DevNodeW dw;
+    for (int k = 0; k < 6; k++) d.q[k] = 0;
+    d.spare[0] = d.spare[1] = 0; dw.pad[1] = dw.pad[2] = 0;
+    float org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < nc; i++) { const float *lo, *hi; wide_box(in, cand[i], lo, hi); for (int k = 0; k < 3; k++) { org[k] = fminf(org[k], lo[k]); top[k] = fmaxf(top[k], hi[k]); } }
+    d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
+    uint32_t ebits[3]; float scale[3];
+    for (int k = 0; k < 3; k++) { // smallest power of two with 255 * scale >= extent (as evaluated by the tracer's fma), at least 2^-100
+        double ext = (double)top[k] - (double)org[k];
+        int e = ext > 0 ? ceil_log2(ext / 255.0) : -100;
+        if (e < -100) e = -100;
+        for (;;) { scale[k] = ldexpf(1.0f, e); if (fmaf(255.0f, scale[k], org[k]) >= top[k]) break; e++; }
+        ebits[k] = (uint32_t)(e + 127);
+    }
+    uint32_t mask = 0, next = first + n + offs[w]; // this node's internal children follow those of the nodes before it
+    for (int i = 0; i < 4; i++) {
+        if (i >= nc) { d.child[i] = 0x7FFFFFFF; dw.child[i] = 0x7FFFFFFF; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; }
+        mask |= 1u << i;
+        const float *lo, *hi; wide_box(in, cand[i], lo, hi);
+        for (int k = 0; k < 3; k++) {
+            int ql = (int)floor(((double)lo[k] - (double)org[k]) / (double)scale[k]);
+            int qh = (int)ceil(((double)hi[k] - (double)org[k]) / (double)scale[k]);
+            ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+            while (ql > 0 && fmaf((float)ql, scale[k], org[k]) > lo[k]) ql--;
+            while (qh < 255 && fmaf((float)qh, scale[k], org[k]) < hi[k]) qh++;
+            d.q[k] |= (uint32_t)ql << (8 * i);
+            d.q[3 + k] |= (uint32_t)qh << (8 * i);
+            dw.box[i][k] = lo[k]; dw.box[i][3 + k] = hi[k];
+        }
+        if (cand[i] < 0) d.child[i] = cand[i];
+        else { d.child[i] = (int32_t)next; next_front[next - (first + n)] = cand[i]; next++; }
+        dw.child[i] = d.child[i];
+    }
+    d.exps = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (mask << 24);
+    dw.valid = mask; dw.pad[0] = sort_axis;
+    wide[first + w] = d;
+    widef[first + w] = dw;
+}
+
+hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
+    if (l.wide) return hipSuccess; // already built for this tree
+    if (on_host) return wide_build_host(l, T, s);
+    const uint32_t NI = T > 1 ? T - 1 : 0;
+    const uint32_t cap = NI ? NI : 1;   // a wide node stands on a distinct binary node: at most NI of them (one for a single triangle)
+    WideIn in{l.trav_child ? l.trav_child : l.child, l.trav_child ? l.trav_lo : l.node_lo, l.trav_child ? l.trav_hi : l.node_hi, l.leaf_lo, l.leaf_hi};
+    int32_t *front[2] = {nullptr, nullptr}, *cand = nullptr; uint32_t *meta = nullptr, *cnt = nullptr, *offs = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
+    DevNode4 *wide = nullptr; DevNodeW *widef = nullptr;
+    auto body = [&]() -> hipError_t {
+        HIPQ(hipMalloc(&front[0], (size_t)cap * 4)); HIPQ(hipMalloc(&front[1], (size_t)cap * 4)); HIPQ(hipMalloc(&cand, (size_t)cap * 16));
+        HIPQ(hipMalloc(&meta, (size_t)cap * 4)); HIPQ(hipMalloc(&cnt, ((size_t)cap + 1) * 4)); HIPQ(hipMalloc(&offs, ((size_t)cap + 1) * 4));
+        HIPQ(hipMalloc(&wide, (size_t)cap * sizeof(DevNode4))); HIPQ(hipMalloc(&widef, (size_t)cap * sizeof(DevNodeW)));
+        HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, offs, 0u, (size_t)cap + 1, rocprim::plus<uint32_t>(), s));
+        HIPQ(hipMalloc(&tmp, tmp_bytes));
+        const int32_t root = NI ? 0 : ~0;
+        HIPQ(hipMemcpyAsync(front[0], &root, 4, hipMemcpyHostToDevice, s));
+        uint32_t first = 0, n = 1; int cur = 0;
+        while (n) {
+            if (first + n > cap) return hipErrorInvalidValue; // (cannot happen: see cap)
+            const uint32_t g = (n + 255) / 256;
+            k_wide_expand<<<g, 256, 0, s>>>(in, front[cur], n, cand, meta, cnt);
+            HIPQ(hipMemsetAsync(cnt + n, 0, 4, s));                                  // the scan's last element = the level's total
+            size_t tb = tmp_bytes;
+            HIPQ(rocprim::exclusive_scan(tmp, tb, cnt, offs, 0u, (size_t)n + 1, rocprim::plus<uint32_t>(), s));
+            k_wide_emit<<<g, 256, 0, s>>>(in, n, first, cand, meta, offs, wide, widef, front[cur ^ 1]);
+            uint32_t n_next = 0;
+            HIPQ(hipMemcpyAsync(&n_next, offs + n, 4, hipMemcpyDeviceToHost, s));
+            HIPQ(hipStreamSynchronize(s));
+            first += n; n = n_next; cur ^= 1;
+        }
+        HIPQ(hipGetLastError());
+        l.n_wide = first;
+        return hipSuccess;
+    };
+    hipError_t e = body();
+    hipFree(front[0]); hipFree(front[1]); hipFree(cand); hipFree(meta); hipFree(cnt); hipFree(offs); hipFree(tmp);
+    if (e == hipSuccess) { // the work arrays are sized for the worst case (NI nodes); a 4-wide collapse of a binary tree has about a third of that
+        e = hipMalloc(&l.wide, (size_t)l.n_wide * sizeof(DevNode4));
+        if (e == hipSuccess) e = hipMalloc(&l.widef, (size_t)l.n_wide * sizeof(DevNodeW));
+        if (e == hipSuccess) e = hipMemcpyAsync(l.wide, wide, (size_t)l.n_wide * sizeof(DevNode4), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(l.widef, widef, (size_t)l.n_wide * sizeof(DevNodeW), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { hipFree(l.wide); hipFree(l.widef); l.wide = nullptr; l.widef = nullptr; l.n_wide = 0; }
+    }
+    hipFree(wide); hipFree(widef);
+    return e;
 }
 
 void lbvh_free(Lbvh &l) {

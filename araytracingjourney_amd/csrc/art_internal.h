@@ -89,7 +89,7 @@ struct Lbvh {               // canonical binary LBVH, device arrays
 bool decode_jpeg(const uint8_t *data, size_t n, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, int &channels, std::string &err);
 hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s); // allocates out.*, frees temporaries
 // the 4-wide collapses (DevNode4, DevNodeW): built on first use -- only the per-ray shadow/AO walks and ART_PACKET_WIDE need them
-hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s);
+hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host = false); // level by level on the device, or the one-thread host loop (A/B)
 // PREFER_FAST_TRACE: rebuilds l.nodes as a binned-SAH tree over the same leaves (host threads); frames are unchanged by construction
 hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s);
 // the same purpose on the device: parallel locally-ordered clustering over the Morton-ordered leaves; *depth_out = depth of the tree

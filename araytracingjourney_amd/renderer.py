@@ -544,6 +544,14 @@ class Renderer:
         check(self._L.art_get_traversal_tree(self._ctx, _ptr(out["child"]), _ptr(out["node_lo"]), _ptr(out["node_hi"])))
         return out
 
+    def get_wide_nodes(self):
+        """the 4-wide collapse the walks read: (n, 16) uint32 quantised records and (n, 32) uint32 float-box records (art_get_wide_nodes)"""
+        n = C.c_uint32()
+        check(self._L.art_get_wide_nodes(self._ctx, None, None, 0, C.byref(n)))
+        q, f = np.zeros((n.value, 16), np.uint32), np.zeros((n.value, 32), np.uint32)
+        check(self._L.art_get_wide_nodes(self._ctx, _ptr(q), _ptr(f), n.value, C.byref(n)))
+        return q, f
+
 
 def mgpu_shard(rank, world, dedicated=False):
     """(shard_rank, shard_count) the context of `rank` is created with (art_mgpu_shard)"""

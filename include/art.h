@@ -335,6 +335,7 @@ typedef struct ArtTuning {
     uint32_t trace_chunk, trace_refill, trace_blocks; /* persistent per-ray tracer (process-wide): slots per cursor pop, idle lanes that trigger a refill, resident blocks; 0 = presets */
     uint32_t hw_queues;         /* hardware queues the HOST gave the process (GPU_MAX_HW_QUEUES; 0 = HIP's default of 4): the wave plan counts min(frames in flight, this) launches in flight */
     uint32_t log;               /* to stderr: 1 build phase times, 2 wave-plan decisions, 4 every wave-plan poll */
+    uint32_t wide_builder;      /* the 4-wide collapse of the binary tree: 0 level by level on the device | 1 one host thread (the form the device one is tested against) */
 } ArtTuning;
 int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
 /* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */
@@ -351,6 +352,10 @@ int32_t art_get_lbvh(ArtContext *ctx, uint32_t *leaf_gid, uint64_t *keys, int32_
 /* the topology and node boxes the walks use over those leaves (child[2*(T-1)], node_lo/hi[3*(T-1)]): the binned-SAH tree by
  * default, the canonical tree with ART_FLAG_FAST_BUILD.  Node 0 is the root; child >= 0: internal node, < 0: ~leaf position. */
 int32_t art_get_traversal_tree(ArtContext *ctx, int32_t *child, float *node_lo, float *node_hi);
+/* the 4-wide collapse of that tree as the walks read it (new functionality: the reference's acceleration structures are opaque, vk_blas_builder.rs:88-170):
+ * n_nodes records of 64 B (8-bit quantised child boxes: the per-ray walks) and of 128 B (float child boxes, children sorted along one axis: the packet
+ * walks); node 0 is the root, child >= 0: node index, < 0: ~leaf position, 0x7FFFFFFF: absent.  Either pointer may be NULL; *n_nodes is always set. */
+int32_t art_get_wide_nodes(ArtContext *ctx, void *quantised, void *floats, size_t capacity_nodes, uint32_t *n_nodes);
 
 /* ---- GLB ingest: the step right before the path (model_reader/gltf_model_reader.rs), host only ------------------ */
 typedef struct ArtGlb ArtGlb;

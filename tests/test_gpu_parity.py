@@ -325,6 +325,37 @@ def test_packed_tiles_gather_to_the_packed_colour_image(R, get_scene):
     whole.close()
 
 
+@pytest.mark.parametrize("name,detail,fast", [("cornell", 1.0, False), ("sponza_like", 0.12, False), ("sponza_like", 0.12, True), ("sponza_like", 1.0, False)])
+def test_wide_collapse_on_the_device_equals_the_host_loop(R, get_scene, name, detail, fast):
+    """the 4-wide nodes the packet and per-ray walks read (art_get_wide_nodes): the level-by-level device collapse emits, bit for bit, the arrays of the
+    one-thread host loop it replaced (same greedy expansion, same child order, same breadth-first numbering, same quantisation); and they are a tree
+    over all leaves with boxes that contain their children's"""
+    sc = get_scene(name, detail)
+    dev = R.renderer_for_scene(sc, (64, 64), fast_build=fast)
+    host = R.renderer_for_scene(sc, (64, 64), fast_build=fast, tuning={"wide_builder": 1})
+    qd, fd = dev.get_wide_nodes()
+    qh, fh = host.get_wide_nodes()
+    assert qd.shape == qh.shape and len(qd) >= 1
+    assert np.array_equal(qd, qh) and np.array_equal(fd, fh)
+    T = dev.stats()["num_triangles"]
+    child = fd[:, 24:28].view(np.int32)
+    valid = child != 0x7FFFFFFF
+    assert np.array_equal(child, qd[:, 12:16].view(np.int32))
+    leaves = np.sort(~child[valid & (child < 0)])
+    assert np.array_equal(leaves, np.arange(T))                                  # every leaf exactly once
+    inner = np.sort(child[valid & (child >= 0)])
+    assert np.array_equal(inner, np.arange(1, len(fd)))                          # every node but the root has exactly one parent
+    boxes = fd[:, :24].view(np.float32).reshape(-1, 4, 6)
+    for k in range(4):                                                           # a child's box contains its own children's boxes
+        sel = valid[:, k] & (child[:, k] >= 0)
+        sub = boxes[child[sel, k]]
+        sub_valid = valid[child[sel, k]]
+        lo = np.where(sub_valid[..., None], sub[..., :3], np.inf).min(1)
+        hi = np.where(sub_valid[..., None], sub[..., 3:], -np.inf).max(1)
+        assert np.all(boxes[sel, k, :3] <= lo) and np.all(boxes[sel, k, 3:] >= hi)
+    dev.close(); host.close()
+
+
 @pytest.mark.parametrize("walk", [0, 2], ids=["default", "binary"])
 @pytest.mark.parametrize("name,detail,size,spp", [("cornell", 1.0, (256, 256), 16), ("sponza_like", 0.12, (480, 270), 16), ("sponza_like", 0.12, (200, 120), 5)])
 def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp, walk):
@@ -441,7 +472,8 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene):
                       ("fused on the LBVH topology", frame(4, fast_build=True)), ("fused on the device-built (PLOC) tree", frame(4, device_tree=True)),
                       ("per-ray on the PLOC tree", frame(1, device_tree=True, tuning={"frame_form": 2})), ("per-ray on the LBVH topology", frame(1, fast_build=True, tuning={"frame_form": 2})),
                       ("fused on the host-built SAH tree", frame(4, tuning={"tree_builder": 1})), ("fused, 7 waves/SIMD", frame(4, tuning={"frame_waves": 7, "packet_wide": 2})), ("fused, no block reordering", frame(4, tuning={"block_order": 1})),
-                      ("staged, per-ray primary + packet shadow", frame(2, tuning={"frame_form": 1, "primary_walk": 2})), ("fused, binary packet nodes", frame(4, tuning={"packet_wide": 2}))):
+                      ("staged, per-ray primary + packet shadow", frame(2, tuning={"frame_form": 1, "primary_walk": 2})), ("fused, binary packet nodes", frame(4, tuning={"packet_wide": 2})),
+                      ("fused, 4-wide collapse on the host", frame(4, tuning={"wide_builder": 1}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
         assert got[3]["shadow_rays"] == ref[3]["shadow_rays"] and got[3]["hit_pixels"] == ref[3]["hit_pixels"], name

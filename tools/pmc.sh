@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage: tools/pmc.sh <tag> -- collects PMC counters for bench.py (separate passes; kernel-trace only, as gpurun requires)
+# usage: tools/pmc.sh <tag> [bench.py arguments ...] -- collects PMC counters for bench.py (separate passes; kernel-trace only, as gpurun requires)
 set -e
-TAG=$1
+TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$TAG
@@ -13,7 +13,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --plain > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --plain --settle-seconds 0 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections
