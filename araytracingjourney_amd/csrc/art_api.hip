@@ -52,7 +52,7 @@ struct FrameSlot {
     DevBuf<float4> d_hits, d_contrib, d_shadow_rays, d_color, d_normal, d_color_tiles;
     DevBuf<float> d_depth;
     DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; bool ao_valid = false;
-    DevBuf<int> d_ao_entry;            // per local pixel: the node its AO rays start from
+    DevBuf<float4> d_ao_pix;           // per local pixel: the AO rays' origin | start node, world normal | noise index (k_ao_pixels)
     DevBuf<uint32_t> d_wave_cost;      // fused frame: packet steps of each wave of the slot's last launch (feedback for the wave plan)
     DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     hipEvent_t done_alias = nullptr;   // the latest frame's completion is this ring event (fused frames: one record less per frame) instead of `done`
@@ -67,7 +67,7 @@ struct FrameSlot {
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
-        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_entry.release(); d_wave_cost.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
+        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_pix.release(); d_wave_cost.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
     }
 };
 constexpr uint32_t kMaxFrames = kMaxFrameSlots;
@@ -124,6 +124,7 @@ struct ArtContext {
     uint32_t macro = 2;       // XCD-aware launch order: macro-blocks of macro x macro tiles (0: identity)
     bool ao_entry = true;     // AO rays start at the per-pixel entry node (k_ao_entry)
     bool wide_on_host = false; // ArtTuning.wide_builder
+    DevBuf<float4> d_ao_tab; uint32_t ao_tab_spp = 0; // art_trace_ao's sample table and the sample count it was made for
     // device scene
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
     std::vector<uint32_t> h_first_tri; // first global triangle id of every primitive slot (ascending): gid -> (primitive, triangle) on the host
@@ -529,7 +530,7 @@ int32_t art_destroy(ArtContext *c) {
     for (uint32_t k = 0; k < c->F; k++) if (c->stream_of(k)) (void)hipStreamSynchronize(c->stream_of(k));
     drop_graphs(c);
     lbvh_free(c->bvh);
-    c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release();
+    c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release(); c->d_ao_tab.release();
     c->d_tile_list.release(); c->d_tile_xy.release(); c->d_tile_slot.release(); c->d_block_order.release(); c->plan.release();
     for (uint32_t k = 0; k < kMaxFrames; k++) {
         c->slot[k].release();
@@ -926,17 +927,24 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     r = ensure_wide(c, c->kind_ao == 4 || (c->kind_ao == 8 && c->packet_wide)); if (r) return r;
     FrameSlot &S = c->slot[c->last];
     hipStream_t s = c->stream_of(c->last);
-    if (S.d_occl.n < (size_t)c->n_local * spp || S.d_ao.n < (size_t)c->W * c->H || S.d_ao_entry.n < c->n_local) {
+    if (S.d_occl.n < (size_t)c->n_local * spp || S.d_ao.n < (size_t)c->W * c->H || S.d_ao_pix.n < 2 * (size_t)c->n_local) {
         HIPC(hipStreamSynchronize(s));
-        HIPC(S.d_occl.ensure((size_t)c->n_local * spp)); HIPC(S.d_ao.ensure((size_t)c->W * c->H)); HIPC(S.d_ao_entry.ensure(c->n_local));
+        HIPC(S.d_occl.ensure((size_t)c->n_local * spp)); HIPC(S.d_ao.ensure((size_t)c->W * c->H)); HIPC(S.d_ao_pix.ensure(2 * (size_t)c->n_local));
         HIPC(hipMemset(S.d_ao.p, 0, (size_t)c->W * c->H * 4)); HIPC(hipDeviceSynchronize());
+    }
+    if (c->ao_tab_spp != spp) { // the sample directions in the tangent frame: a function of (sample, position in the 64x64 noise tile) only
+        r = sync_all(c); if (r) return r;
+        HIPC(c->d_ao_tab.ensure((size_t)spp * kAoTableEntriesPerSample));
+        launch_ao_table(spp, c->d_ao_tab.p, c->main_stream());
+        HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(c->main_stream()));
+        c->ao_tab_spp = spp;
     }
     uint32_t lut[65] = {0};
     for (uint32_t k = 0; k <= spp; k++) lut[k] = (uint32_t)(std::pow(1.0 - (double)k / (double)spp, 2.2) * 255.0 + 0.5); // XE_GTAO_DEFAULT_FINAL_VALUE_POWER (vk_xe_gtao.rs:22)
     FrameArgs a = make_frame_args(c, S);
     HIPC(hipMemsetAsync(S.d_counters.p + 64 + 16 * 32, 0, 8 * 32 * 4, s)); // the AO launch's work cursors
     HIPC(hipEventRecord(S.ao_ev[0], s));
-    if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, c->ao_entry ? S.d_ao_entry.p : nullptr, S.d_ao.p, lut, s);
+    if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, S.d_ao_pix.p, c->d_ao_tab.p, c->ao_entry, S.d_ao.p, lut, s);
     HIPC(hipEventRecord(S.ao_ev[1], s));
     HIPC(hipEventRecord(S.done, s)); S.done_alias = nullptr;
     HIPC(hipGetLastError());

@@ -175,7 +175,10 @@ void launch_accumulate(const FrameArgs &a, hipStream_t s);
 bool launch_frame(const FrameArgs &a, hipStream_t s);      // the fused frame: primary + shade + shadow + accumulate in one launch; true: it also wrote a.wave_cost (a.wave_cost set and a counting instance exists)
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s); // out[0] += shadow rays, out[1] += hit pixels
 // ambient occlusion on the frame's depth/normal outputs; occl: n_local*spp bytes; lut: spp+1 output values; cursors at counters[64+512..] are reused (queries never overlap a frame)
-void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, int *entry, uint32_t *ao, const uint32_t *lut, hipStream_t s); // entry: n_local ints of scratch (per-pixel start node) or null
+constexpr uint32_t kAoTableEntriesPerSample = 64 * 64;
+void launch_ao_table(uint32_t spp, float4 *tab, hipStream_t s); // tab: spp * kAoTableEntriesPerSample float4
+// pix: 2 * n_local float4 of scratch (per-pixel origin | start node, normal | noise index); tab: launch_ao_table's; entry_search: start the rays below the root
+void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, float4 *pix, const float4 *tab, bool entry_search, uint32_t *ao, const uint32_t *lut, hipStream_t s);
 struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevTri *tris; int kind; }; // kind: 2 | 4
 void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);

@@ -477,7 +477,10 @@ __device__ __forceinline__ void sincos_turns(float u, float &c, float &s) {
     c = k == 0 ? cp : (k == 1 ? -sp : (k == 2 ? -cp : sp));
     s = k == 0 ? sp : (k == 1 ? cp : (k == 2 ? -sp : -cp));
 }
-__device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float depth, float4 nm, uint32_t smp, V3 &o, V3 &d) {
+// an AO ray in three parts, so that the tracer's refill pays only for what differs from ray to ray: the pixel's point and world normal (once per
+// pixel: k_ao_pixels), the sample's direction in the tangent frame (a function of the pixel's position in its 64x64 noise tile and the sample
+// index only: a table, k_ao_table), and the frame itself.  ao_ray() composes the three: the same operations in the same order wherever a ray is made.
+__device__ __forceinline__ void ao_pixel(const CameraArg &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float depth, float4 nm, V3 &o, V3 &N) {
     float px = (float)x + 0.5f, py = (float)y + 0.5f;
     float dx = (px / (float)W) * 2.0f - 1.0f, dy = (py / (float)H) * 2.0f - 1.0f;
     V3 org = mat4_mul(cam.view_inv, 0.f, 0.f, 0.f, 1.f);
@@ -487,15 +490,36 @@ __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_
     o = mk(org.x + dir.x * sc, org.y + dir.y * sc, org.z + dir.z * sc); // the primary ray scaled to the stored view depth
     float nx = nm.x * 2.0f - 1.0f, ny = -(nm.y * 2.0f - 1.0f), nz = -(nm.z * 2.0f - 1.0f); // raytrace.rgen.glsl:192-194 inverted
     const float *VI = cam.view_inv;
-    V3 N = nrm3(mk((VI[0] * nx + VI[4] * ny) + VI[8] * nz, (VI[1] * nx + VI[5] * ny) + VI[9] * nz, (VI[2] * nx + VI[6] * ny) + VI[10] * nz));
-    float sg = copysignf(1.0f, N.z), aa = -1.0f / (sg + N.z), bb = N.x * N.y * aa; // branchless orthonormal basis (Duff et al. 2017)
-    V3 T = mk(1.0f + sg * N.x * N.x * aa, sg * bb, -sg * N.x), B = mk(bb, sg + N.y * N.y * aa, -N.y);
-    float fi = (float)(hilbert_index(x & 63u, y & 63u) + 288u * smp);
+    N = nrm3(mk((VI[0] * nx + VI[4] * ny) + VI[8] * nz, (VI[1] * nx + VI[5] * ny) + VI[9] * nz, (VI[2] * nx + VI[6] * ny) + VI[10] * nz));
+}
+// cosine-weighted direction of sample `smp` of the pixel whose Hilbert index in its 64x64 tile is `hil`, in the tangent frame: (r cos, r sin, sqrt(1 - u1))
+__device__ __forceinline__ void ao_sample(uint32_t hil, uint32_t smp, float &tx, float &ty, float &tz) {
+    float fi = (float)(hil + 288u * smp);
     float v1 = 0.5f + fi * 0.75487766624669276f, v2 = 0.5f + fi * 0.56984029099805327f;
     float u1 = v1 - floorf(v1), u2 = v2 - floorf(v2);
-    float r = sqrtf(u1), cz = sqrtf(1.0f - u1), cc, ss;
+    float r = sqrtf(u1), cc, ss;
+    tz = sqrtf(1.0f - u1);
     sincos_turns(u2, cc, ss);
-    d = (T * (r * cc) + B * (r * ss)) + N * cz;
+    tx = r * cc; ty = r * ss;
+}
+__device__ __forceinline__ V3 ao_dir(V3 N, float tx, float ty, float tz) {
+    float sg = copysignf(1.0f, N.z), aa = -1.0f / (sg + N.z), bb = N.x * N.y * aa; // branchless orthonormal basis (Duff et al. 2017)
+    V3 T = mk(1.0f + sg * N.x * N.x * aa, sg * bb, -sg * N.x), B = mk(bb, sg + N.y * N.y * aa, -N.y);
+    return (T * tx + B * ty) + N * tz;
+}
+__device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float depth, float4 nm, uint32_t smp, V3 &o, V3 &d) {
+    V3 N; float tx, ty, tz;
+    ao_pixel(cam, W, H, x, y, depth, nm, o, N);
+    ao_sample(hilbert_index(x & 63u, y & 63u), smp, tx, ty, tz);
+    d = ao_dir(N, tx, ty, tz);
+}
+constexpr uint32_t kAoNoiseTile = 64 * 64; // the sample table has one entry per (sample, Hilbert index in the 64x64 tile)
+__global__ __launch_bounds__(kBlock) void k_ao_table(uint32_t spp, float4 *__restrict__ tab) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= spp * kAoNoiseTile) return;
+    float tx, ty, tz;
+    ao_sample(i % kAoNoiseTile, i / kAoNoiseTile, tx, ty, tz);
+    tab[i] = make_float4(tx, ty, tz, 0.f);
 }
 
 // AO rays are short: the 16 rays of a pixel stay inside a ball of the AO radius around one point.  Descend the 4-wide tree while
@@ -503,39 +527,44 @@ __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_
 // and let the pixel's rays start there (or skip them when nothing overlaps).  Quantised boxes contain the float boxes, so the test
 // errs on the side of overlap; the rays' answers are those of a walk from the root (accept() is per triangle).
 constexpr int kAoNothingNear = (int)0x80000000; // no leaf has position 2^31 - 1
-__global__ __launch_bounds__(kBlock) void k_ao_entry(FrameArgs a, const DevNode4 *__restrict__ wide, float radius, int *__restrict__ entry) {
+// per local pixel, once: pix[2p] = the AO rays' origin | the node they start from (or kAoNothingNear: a miss pixel, or nothing within the radius),
+// pix[2p + 1] = the world normal | the pixel's Hilbert index in its noise tile.  wide == null: every pixel starts at the root (binary walk, or entry search off).
+__global__ __launch_bounds__(kBlock) void k_ao_pixels(FrameArgs a, const DevNode4 *__restrict__ wide, float radius, float4 *__restrict__ pix) {
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= a.n_local) return;
     uint32_t x, y;
     bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
     float depth = in ? a.depth[(size_t)y * a.W + x] : 10000.0f;
-    if (!(depth < 10000.0f)) { entry[p] = kAoNothingNear; return; }
-    V3 o, d;
-    ao_ray(a.cam, a.W, a.H, x, y, depth, a.normal[(size_t)y * a.W + x], 0, o, d);
-    const float R = radius * 1.01f; // t runs to `radius` along a direction of length 1 +- rounding
-    const float lox = o.x - R, loy = o.y - R, loz = o.z - R, hix = o.x + R, hiy = o.y + R, hiz = o.z + R;
+    if (!(depth < 10000.0f)) { pix[2 * (size_t)p] = make_float4(0.f, 0.f, 0.f, __int_as_float(kAoNothingNear)); pix[2 * (size_t)p + 1] = make_float4(0.f, 0.f, 1.f, 0.f); return; }
+    V3 o, N;
+    ao_pixel(a.cam, a.W, a.H, x, y, depth, a.normal[(size_t)y * a.W + x], o, N);
     int cur = 0;
-    for (int level = 0; level < 64; level++) {
-        const uint4 *nq = reinterpret_cast<const uint4 *>(wide + cur);
-        uint4 qa = nq[0], qb = nq[1], qc = nq[2], qd = nq[3];
-        float ox = __uint_as_float(qa.x), oy = __uint_as_float(qa.y), oz = __uint_as_float(qa.z);
-        float sx = __uint_as_float((qa.w & 255u) << 23), sy = __uint_as_float(((qa.w >> 8) & 255u) << 23), sz = __uint_as_float(((qa.w >> 16) & 255u) << 23);
-        uint32_t mask = qa.w >> 24;
-        int refs[4] = {(int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w};
-        int n_over = 0, which = 0;
+    if (wide) {
+        const float R = radius * 1.01f; // t runs to `radius` along a direction of length 1 +- rounding
+        const float lox = o.x - R, loy = o.y - R, loz = o.z - R, hix = o.x + R, hiy = o.y + R, hiz = o.z + R;
+        for (int level = 0; level < 64; level++) {
+            const uint4 *nq = reinterpret_cast<const uint4 *>(wide + cur);
+            uint4 qa = nq[0], qb = nq[1], qc = nq[2], qd = nq[3];
+            float ox = __uint_as_float(qa.x), oy = __uint_as_float(qa.y), oz = __uint_as_float(qa.z);
+            float sx = __uint_as_float((qa.w & 255u) << 23), sy = __uint_as_float(((qa.w >> 8) & 255u) << 23), sz = __uint_as_float(((qa.w >> 16) & 255u) << 23);
+            uint32_t mask = qa.w >> 24;
+            int refs[4] = {(int)qd.x, (int)qd.y, (int)qd.z, (int)qd.w};
+            int n_over = 0, which = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float lx = fmaf((float)((qb.x >> (8 * i)) & 255u), sx, ox), ly = fmaf((float)((qb.y >> (8 * i)) & 255u), sy, oy), lz = fmaf((float)((qb.z >> (8 * i)) & 255u), sz, oz);
-            float hx = fmaf((float)((qb.w >> (8 * i)) & 255u), sx, ox), hy = fmaf((float)((qc.x >> (8 * i)) & 255u), sy, oy), hz = fmaf((float)((qc.y >> (8 * i)) & 255u), sz, oz);
-            bool over = ((mask >> i) & 1u) && lx <= hix && hx >= lox && ly <= hiy && hy >= loy && lz <= hiz && hz >= loz;
-            if (over) { n_over++; which = refs[i]; }
+            for (int i = 0; i < 4; i++) {
+                float lx = fmaf((float)((qb.x >> (8 * i)) & 255u), sx, ox), ly = fmaf((float)((qb.y >> (8 * i)) & 255u), sy, oy), lz = fmaf((float)((qb.z >> (8 * i)) & 255u), sz, oz);
+                float hx = fmaf((float)((qb.w >> (8 * i)) & 255u), sx, ox), hy = fmaf((float)((qc.x >> (8 * i)) & 255u), sy, oy), hz = fmaf((float)((qc.y >> (8 * i)) & 255u), sz, oz);
+                bool over = ((mask >> i) & 1u) && lx <= hix && hx >= lox && ly <= hiy && hy >= loy && lz <= hiz && hz >= loz;
+                if (over) { n_over++; which = refs[i]; }
+            }
+            if (n_over == 0) { cur = kAoNothingNear; break; }
+            if (n_over > 1) break;          // the rays may go either way from here: this node is the entry
+            cur = which;
+            if (cur < 0) break;             // a single triangle is all there is
         }
-        if (n_over == 0) { cur = kAoNothingNear; break; }
-        if (n_over > 1) break;          // the rays may go either way from here: this node is the entry
-        cur = which;
-        if (cur < 0) break;             // a single triangle is all there is
     }
-    entry[p] = cur;
+    pix[2 * (size_t)p] = make_float4(o.x, o.y, o.z, __int_as_float(cur));
+    pix[2 * (size_t)p + 1] = make_float4(N.x, N.y, N.z, __uint_as_float(hilbert_index(x & 63u, y & 63u)));
 }
 
 // what a persistent tracing wave reads its rays from and writes its results to
@@ -556,7 +585,8 @@ struct TraceArgs {
     uint32_t *any_out;
     // MODE_AO: rays are generated from the frame's depth + view-space normal outputs (XeGTAO's inputs); slot = local pixel * spp + sample
     const float *depth; const float4 *normal; uint32_t spp; float ao_radius; uint8_t *occl;
-    const int *ao_entry;      // MODE_AO with the 4-wide nodes: per local pixel, the node its AO rays start from (k_ao_entry), or null
+    const float4 *ao_pix;     // MODE_AO: per local pixel, origin | start node and world normal | Hilbert index (k_ao_pixels)
+    const float4 *ao_tab;     // MODE_AO: [sample][Hilbert index] tangent-frame direction (k_ao_table)
 };
 
 // Persistent-threads wavefront tracer.  Each wave keeps up to 64 rays in flight; when kRefill or more lanes have
@@ -617,20 +647,19 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
                             active = true;
                         } else a.hits[sidx] = make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit));
                     } else if (MODE == MODE_AO) {
-                        uint32_t p = sidx / a.spp, smp = sidx - p * a.spp, x, y;
-                        bool on = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
-                        float depth = on ? a.depth[(size_t)y * a.W + x] : 10000.0f;
-                        if (depth < 10000.0f) {
-                            V3 o, d;
-                            int entry = a.ao_entry ? a.ao_entry[p] : 0;
-                            if (entry == kAoNothingNear) a.occl[sidx] = 0; // no box within the AO radius of this pixel: unoccluded, nothing to trace
-                            else {
-                                ao_ray(a.cam, a.W, a.H, x, y, depth, a.normal[(size_t)y * a.W + x], smp, o, d);
-                                tr.start(o, d, a.ao_radius * 0.01f, a.ao_radius);
-                                tr.cur = entry;                            // the walk starts below the part of the tree that every ray of this pixel would cross alike
-                                active = true;
-                            }
-                        } else a.occl[sidx] = 0;
+                        // everything but the direction was made once per pixel (k_ao_pixels), the direction's tangent-frame part once per context (k_ao_table):
+                        // a refill is three 16-byte loads, a frame from the normal and ray_init -- cheap enough to refill at few idle lanes
+                        uint32_t p = sidx / a.spp, smp = sidx - p * a.spp;
+                        float4 po = a.ao_pix[2 * (size_t)p];
+                        int entry = __float_as_int(po.w);
+                        if (entry == kAoNothingNear) a.occl[sidx] = 0; // a miss pixel, or no box within the AO radius: unoccluded, nothing to trace
+                        else {
+                            float4 pn = a.ao_pix[2 * (size_t)p + 1];
+                            float4 t = a.ao_tab[smp * kAoNoiseTile + __float_as_uint(pn.w)];
+                            tr.start(mk(po.x, po.y, po.z), ao_dir(mk(pn.x, pn.y, pn.z), t.x, t.y, t.z), a.ao_radius * 0.01f, a.ao_radius);
+                            tr.cur = entry;                            // the walk starts below the part of the tree that every ray of this pixel would cross alike
+                            active = true;
+                        }
                     } else {
                         float4 r0 = a.rays[2 * (size_t)sidx];
                         if (MODE != MODE_SHADOW || r0.w > 0.0f) {
@@ -1205,7 +1234,8 @@ __global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_
     for (uint32_t s = 0; s < spp; s++) k += occl[(size_t)p * spp + s];
     ao[pix] = a.depth[pix] < 10000.0f ? lut.v[k] : 255u;
 }
-void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, int *entry, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
+void launch_ao_table(uint32_t spp, float4 *tab, hipStream_t s) { k_ao_table<<<blocks_for(spp * kAoNoiseTile), kBlock, 0, s>>>(spp, tab); }
+void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, float4 *pix, const float4 *tab, bool entry_search, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
     AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
     if (f.trace_kind[2] == 8) { // measured 2x slower than the per-ray walk (incoherent directions): off by default
         PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl;
@@ -1216,10 +1246,8 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, in
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
-    if (f.trace_kind[2] == 4 && entry) { // one entry node per pixel for its spp rays
-        k_ao_entry<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, f.wide, radius, entry);
-        a.ao_entry = entry;
-    }
+    k_ao_pixels<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, (f.trace_kind[2] == 4 && entry_search) ? f.wide : nullptr, radius, pix); // one point, normal and entry node per pixel for its spp rays
+    a.ao_pix = pix; a.ao_tab = tab;
     launch_trace<MODE_AO>(a, f.trace_kind[2], f.pipelined, s);
     k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
