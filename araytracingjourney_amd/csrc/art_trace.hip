@@ -109,12 +109,15 @@ constexpr int kTraceBlock = 64;  // the persistent per-ray tracer: likewise (its
 // are throughput-bound -> fewer cursor atomics, fewer resident waves.  art_set_tuning (trace_chunk / trace_refill / trace_blocks)
 // overrides both presets for sweeps.
 struct Tune { uint32_t chunk, refill, blocks; };
-static Tune g_tune[2] = {{64, 12, 1536}, {128, 24, 1024}};
-static const Tune &tune(bool pipelined) { return g_tune[pipelined ? 1 : 0]; }
+// [0] / [1]: primary, shadow and query rays, one frame at a time / several in flight; [2] / [3]: AO rays likewise -- sixteen consecutive slots are one
+// pixel's rays, a refill is cheap (k_ao_pixels + k_ao_table), and the kernel fits 8 waves per SIMD: larger chunks (a wave stays on 64 neighbouring
+// pixels), all 8 192 wave slots (config 5: 13 700 -> 14 280 Mray/s over the presets of the other rays)
+static const Tune kPreset[4] = {{64, 12, 1536}, {128, 24, 1024}, {256, 16, 2048}, {1024, 24, 2048}};
+static Tune g_tune[4] = {kPreset[0], kPreset[1], kPreset[2], kPreset[3]};
+static const Tune &tune(bool pipelined, bool ao = false) { return g_tune[(ao ? 2 : 0) + (pipelined ? 1 : 0)]; }
 void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks) {
-    static const Tune preset[2] = {{64, 12, 1536}, {128, 24, 1024}};
-    for (int k = 0; k < 2; k++) {
-        g_tune[k] = preset[k];
+    for (int k = 0; k < 4; k++) {
+        g_tune[k] = kPreset[k];
         if (chunk >= 64 && chunk <= 65536) g_tune[k].chunk = chunk;
         if (refill >= 1 && refill <= 64) g_tune[k].refill = refill;
         if (blocks >= 1 && blocks <= 16384) g_tune[k].blocks = blocks;
@@ -1150,13 +1153,13 @@ __global__ __launch_bounds__(kBlock) void k_untile_rgb(const float *__restrict__
 // ------------------------------------------------------------------------------------------------ launchers
 static inline uint32_t blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 // persistent grid: enough waves to fill the chip (8 blocks of 4 waves per CU), never more than the work needs
-static inline uint32_t persistent_blocks(uint32_t total, bool pipelined) {
-    uint32_t need = (total + kTraceBlock - 1) / kTraceBlock, cap = tune(pipelined).blocks * (kBlock / kTraceBlock);   // the presets count 256-thread blocks
+static inline uint32_t persistent_blocks(uint32_t total, const Tune &t) {
+    uint32_t need = (total + kTraceBlock - 1) / kTraceBlock, cap = t.blocks * (kBlock / kTraceBlock);   // the presets count 256-thread blocks
     return need < cap ? (need ? need : 1u) : cap;
 }
 template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipelined, hipStream_t s) {
-    uint32_t nb = persistent_blocks(a.total, pipelined);
-    const Tune &t = tune(pipelined);
+    const Tune &t = tune(pipelined, MODE == MODE_AO);
+    uint32_t nb = persistent_blocks(a.total, t);
     a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = 1; // batching was measured slower at every threshold (profiles/README.md)
     if (kind == 4) k_trace<MODE, 4><<<nb, kTraceBlock, 0, s>>>(a);
     else k_trace<MODE, 2><<<nb, kTraceBlock, 0, s>>>(a);
