@@ -108,11 +108,14 @@ constexpr int kTraceBlock = 64;  // the persistent per-ray tracer: likewise (its
 // one frame at a time is bound by the slowest wave's critical path -> small chunks, more waves; several frames in flight
 // are throughput-bound -> fewer cursor atomics, fewer resident waves.  art_set_tuning (trace_chunk / trace_refill / trace_blocks)
 // overrides both presets for sweeps.
-struct Tune { uint32_t chunk, refill, blocks; };
+struct Tune { uint32_t chunk, refill, blocks, leaf_batch; };
 // [0] / [1]: primary, shadow and query rays, one frame at a time / several in flight; [2] / [3]: AO rays likewise -- sixteen consecutive slots are one
 // pixel's rays, a refill is cheap (k_ao_pixels + k_ao_table), and the kernel fits 8 waves per SIMD: larger chunks (a wave stays on 64 neighbouring
-// pixels), all 8 192 wave slots (config 5: 13 700 -> 14 280 Mray/s over the presets of the other rays)
-static const Tune kPreset[4] = {{64, 12, 1536}, {128, 24, 1024}, {256, 16, 2048}, {1024, 24, 2048}};
+// pixels), all 8 192 wave slots (config 5: 13 700 -> 14 280 Mray/s over the presets of the other rays).  leaf_batch: lanes that must stand on a triangle
+// before the wave runs the triangle test.  1 for the other rays (one frame of them at a time is bound by its slowest wave: waiting lanes lengthen it,
+// round 1); AO launches are throughput-bound, and a triangle test run for every lone lane was a third of their issued instructions at a tenth of the
+// lanes: 2 / 4 / 8 / 12 / 16 lanes -> 14 510 / 14 930 / 15 370 / 15 330 / 15 070 Mray/s on config 5
+static const Tune kPreset[4] = {{64, 12, 1536, 1}, {128, 24, 1024, 1}, {256, 16, 2048, 8}, {1024, 24, 2048, 8}};
 static Tune g_tune[4] = {kPreset[0], kPreset[1], kPreset[2], kPreset[3]};
 static const Tune &tune(bool pipelined, bool ao = false) { return g_tune[(ao ? 2 : 0) + (pipelined ? 1 : 0)]; }
 void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks) {
@@ -1160,7 +1163,7 @@ static inline uint32_t persistent_blocks(uint32_t total, const Tune &t) {
 template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipelined, hipStream_t s) {
     const Tune &t = tune(pipelined, MODE == MODE_AO);
     uint32_t nb = persistent_blocks(a.total, t);
-    a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = 1; // batching was measured slower at every threshold (profiles/README.md)
+    a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = t.leaf_batch;
     if (kind == 4) k_trace<MODE, 4><<<nb, kTraceBlock, 0, s>>>(a);
     else k_trace<MODE, 2><<<nb, kTraceBlock, 0, s>>>(a);
 }
