@@ -968,8 +968,6 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
     // in the dispatcher's books until its slowest wave was done -- packets differ 25x in steps.  Single-wave groups: +2.5 % rays/s (profiles/README.md r2).
     __shared__ int wstack[kPacketStack];
     int *stk = wstack;
-    // multi-light instance: the surface record waits in LDS while a shadow packet walks, so the walk runs on as few live registers as the one-light form
-    __shared__ float surf[ONE_LIGHT ? 1 : 14 * kFrameBlock]; // 32 waves per CU must fit 160 KB with it: 4.7 KB a wave
     const uint32_t wid = blockIdx.x;
     if (wid >= a.n_wave_items) return;
     uint32_t steps = 0; // packet steps of this wave, all walks
@@ -1017,24 +1015,10 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
     PHASE(2, S.NdotV)
     float rx = 0.f, ry = 0.f, rz = 0.f;
     uint32_t sbits = 0;
-    // ONE_LIGHT: no loop, so the surface record is dead once the light is evaluated and the shadow walk runs on few live registers
-    if (!ONE_LIGHT) {
-        float *q = &surf[threadIdx.x];
-        q[0 * kFrameBlock] = S.world_pos.x; q[1 * kFrameBlock] = S.world_pos.y; q[2 * kFrameBlock] = S.world_pos.z;
-        q[3 * kFrameBlock] = S.N.x; q[4 * kFrameBlock] = S.N.y; q[5 * kFrameBlock] = S.N.z;
-        q[6 * kFrameBlock] = S.Vv.x; q[7 * kFrameBlock] = S.Vv.y; q[8 * kFrameBlock] = S.Vv.z;
-        q[9 * kFrameBlock] = S.albedo.x; q[10 * kFrameBlock] = S.albedo.y; q[11 * kFrameBlock] = S.albedo.z;
-        q[12 * kFrameBlock] = S.metallic; q[13 * kFrameBlock] = S.alpha; // the two N.V terms are recomputed (same operations as shade_surface)
-    }
+    // (until the walks fetched their nodes into SGPRs the multi-light instance parked the surface record in LDS across each shadow walk; it fits now)
     for (uint32_t i = 0; i < (ONE_LIGHT ? 1u : a.n_lights); i++) { // uniform loop: the shadow packet needs the whole wave
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
         bool want = false;
-        if (!ONE_LIGHT) {
-            const float *q = &surf[launder_v((uint32_t)threadIdx.x)]; // reload, do not carry the record across the walk
-            S.world_pos = mk(q[0 * kFrameBlock], q[1 * kFrameBlock], q[2 * kFrameBlock]); S.N = mk(q[3 * kFrameBlock], q[4 * kFrameBlock], q[5 * kFrameBlock]);
-            S.Vv = mk(q[6 * kFrameBlock], q[7 * kFrameBlock], q[8 * kFrameBlock]); S.albedo = mk(q[9 * kFrameBlock], q[10 * kFrameBlock], q[11 * kFrameBlock]);
-            S.metallic = q[12 * kFrameBlock]; S.alpha = q[13 * kFrameBlock]; S.nc_NdotV = dot3(S.N, S.Vv); S.NdotV = clampf(S.nc_NdotV, 1e-5f, 1.0f);
-        }
         if (hit) want = shade_light(a.lights[i], S, c4, ro, rd);
         if (want) sbits |= 1u << (16 + i);
         Ray sr;
@@ -1191,7 +1175,7 @@ template <bool WIDE, bool ONE_LIGHT> static void launch_frame_form(const FrameAr
     else k_frame<WIDE, 8, ONE_LIGHT><<<g, kFrameBlock, 0, s>>>(a);
 }
 bool launch_frame(const FrameArgs &a, hipStream_t s) { // returns whether the launch wrote a.wave_cost
-    const int waves = a.frame_waves; // every instance fits 64 registers without spills (the multi-light one parks its surface record in LDS during the shadow walks)
+    const int waves = a.frame_waves; // every instance fits 64 registers without spills
     const uint32_t g = a.n_wave_items;   // one workgroup per wave item
     if (g == 0) return false;
     const bool one = a.n_lights == 1;
