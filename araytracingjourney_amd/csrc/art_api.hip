@@ -337,6 +337,24 @@ static int32_t plan_poll(ArtContext *c) {
     return ART_OK;
 }
 
+// A directional light's L vector, its length and the shadow ray's reciprocal direction are the same for every pixel (light.glsl:96: -dir * 10): the
+// kernel-argument copy of such a record carries them in fields a directional light does not use (area_pos2 = L, penumbra_angle = |nn_L|, area_pos3 =
+// 1 / safe(L)), made here with the operations the kernel would run per lane -- correctly rounded sqrt and division, explicit fma, nothing contracted
+// (the library is built with -ffp-contract=off): the same bits.  The caller's records are untouched.
+static void directional_constants(ArtLight &l) {
+    if (l.type != 2u) return;
+    const float nx = -l.dir[0] * 10.0f, ny = -l.dir[1] * 10.0f, nz = -l.dir[2] * 10.0f;           // neg(dir) * 10
+    const float d = std::fmaf(nz, nz, std::fmaf(ny, ny, nx * nx));                               // dot3
+    const float len = std::sqrt(d), inv = 1.0f / std::sqrt(d);
+    const float L[3] = {nx * inv, ny * inv, nz * inv};                                           // nrm3
+    for (int k = 0; k < 3; k++) {
+        l.area_pos2[k] = L[k];
+        const float sd = std::fabs(L[k]) < 1e-20f ? std::copysign(1e-20f, L[k]) : L[k];          // safe_dir
+        l.area_pos3[k] = 1.0f / sd;
+    }
+    l.penumbra_angle = len;
+}
+
 int32_t setup_frame(ArtContext *c) {
     // tile ownership + per-frame buffers for the current extent / light count
     c->tiles_x = (c->W + kTile - 1) / kTile; c->tiles_y = (c->H + kTile - 1) / kTile;
@@ -824,6 +842,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
     a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
     a.n_lights = (uint32_t)c->lights.size();
     if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
+    for (uint32_t i = 0; i < a.n_lights; i++) directional_constants(a.lights[i]);
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
     a.color_tiles = c->tiled() ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)

@@ -57,6 +57,10 @@ __device__ __forceinline__ void ray_init(Ray &r, V3 o, V3 d, float tmin, float t
     r.inv = mk(1.0f / safe_dir(d.x), 1.0f / safe_dir(d.y), 1.0f / safe_dir(d.z));
     r.ood = mk(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
 }
+__device__ __forceinline__ void ray_init_inv(Ray &r, V3 o, V3 d, V3 inv, float tmin, float tmax) { // inv = 1 / safe_dir(d), made elsewhere with the same operations
+    r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax; r.inv = inv;
+    r.ood = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+}
 // monotone slab test against [tmin, tlimit]; tn = un-clamped entry distance
 __device__ __forceinline__ bool slab(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float tlimit, float &tn) {
     float t0x = fmaf(lx, r.inv.x, -r.ood.x), t1x = fmaf(hx, r.inv.x, -r.ood.x);
@@ -862,8 +866,10 @@ __device__ __forceinline__ void shade_surface(const FrameArgs &a, const CameraAr
 
 // rgen:152-185 up to the shadow ray: c = (rho_s + rho_d) * radiance, c.w = NdotL; the shadow ray (origin, tmax | direction) if one is due
 __device__ __forceinline__ bool shade_light(const ArtLight &l, const Surface &S, float4 &c4, float4 &ro, float4 &rd) {
-    V3 nn_L = get_unnormalized_L_vec(l, S.world_pos);
-    V3 L = nrm3(nn_L);
+    // a directional light's L and |nn_L| do not depend on the pixel: the host made them (art_api.hip directional_constants, the same operations)
+    const bool directional = l.type == 2u;
+    V3 nn_L = directional ? mk(0.f, 0.f, 0.f) : get_unnormalized_L_vec(l, S.world_pos);
+    V3 L = directional ? ld3(l.area_pos2) : nrm3(nn_L);
     V3 Hh = nrm3(S.Vv + L);
     float nc_NdotL = dot3(S.N, L);
     float NdotL = clampf(nc_NdotL, 0.0f, 1.0f);
@@ -880,7 +886,7 @@ __device__ __forceinline__ bool shade_light(const ArtLight &l, const Surface &S,
     V3 c = (rho_s + rho_d) * rad;
     c4 = make_float4(c.x, c.y, c.z, NdotL);
     if (l.casts_shadows && nc_NdotL > 0.0f) { // raytrace.rgen.glsl:165: origin world_pos, dir L, tmax length(nn_L)
-        ro = make_float4(S.world_pos.x, S.world_pos.y, S.world_pos.z, len3(nn_L));
+        ro = make_float4(S.world_pos.x, S.world_pos.y, S.world_pos.z, directional ? l.penumbra_angle : len3(nn_L));
         rd = make_float4(L.x, L.y, L.z, 0.f);
         return true;
     }
@@ -1022,7 +1028,8 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         if (hit) want = shade_light(a.lights[i], S, c4, ro, rd);
         if (want) sbits |= 1u << (16 + i);
         Ray sr;
-        ray_init(sr, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), 0.01f, ro.w);
+        if (a.lights[i].type == 2u) ray_init_inv(sr, mk(ro.x, ro.y, ro.z), ld3(a.lights[i].area_pos2), ld3(a.lights[i].area_pos3), 0.01f, a.lights[i].penumbra_angle); // (wave-uniform branch)
+        else ray_init(sr, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), 0.01f, ro.w);
         bool son = want;
         PHASE(3, sr.inv.x)
         float st = son ? sr.tmax : -1.0f, su = 0.f, sv = 0.f;
