@@ -71,15 +71,16 @@ class ArtLayout(C.Structure):
 
 
 # int32_t (*)(void *user, const void *send_dev, size_t bytes, void *recv_dev, void *hip_stream)
-ArtMgpuExchangeFn = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p)
+ArtMgpuExchangeFn = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p)
 ART_MGPU_ID_BYTES = 128
 ART_MGPU_SHARED, ART_MGPU_DEDICATED = 0, 1
 ART_MGPU_RCCL, ART_MGPU_HOST_EXCHANGE = 0, 1
+ART_MGPU_ROOT_RANK0, ART_MGPU_ROOT_SPREAD = 0, 1
 
 
 class ArtMgpuConfig(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("compositor", C.c_uint32), ("launches_per_gather", C.c_uint32), ("tile_buffers", C.c_uint32),
-                ("transport", C.c_uint32), ("exchange", ArtMgpuExchangeFn), ("exchange_user", C.c_void_p)]
+                ("transport", C.c_uint32), ("exchange", ArtMgpuExchangeFn), ("exchange_user", C.c_void_p), ("roots", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 assert C.sizeof(ArtVertex) == 48 and C.sizeof(ArtLight) == 80 and C.sizeof(ArtCamera) == 268

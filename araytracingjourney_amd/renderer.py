@@ -568,20 +568,22 @@ def mgpu_unique_id() -> bytes:
 
 
 class MultiGpu:
-    """The sharded frame behind the C ABI (art_mgpu_*): this rank's share traced, the tiles of a group of launches gathered to rank 0 by one
-    RCCL gather, un-tiled by one launch.  `exchange` (a Python function (send_ptr, nbytes, recv_ptr, stream_ptr) -> None) replaces RCCL for
-    rehearsals on one GPU."""
+    """The sharded frame behind the C ABI (art_mgpu_*): this rank's share traced, the tiles of a group of launches gathered by RCCL -- to rank 0
+    (one gather per group), or with `spread` frame f to rank f mod world (one grouped send / receive per group) -- and un-tiled by one launch.
+    `exchange` (a Python function (send_ptr, nbytes, recv_ptr, root, stream_ptr) -> None: every rank's nbytes, rank order, into recv_ptr on `root`)
+    replaces RCCL for rehearsals on one GPU."""
 
-    def __init__(self, renderer: "Renderer", rank, world, unique_id: bytes = None, dedicated=False, launches_per_gather=0, tile_buffers=0, exchange=None):
+    def __init__(self, renderer: "Renderer", rank, world, unique_id: bytes = None, dedicated=False, launches_per_gather=0, tile_buffers=0, exchange=None, spread=False):
         self._L = _lib.load()
         self.renderer, self.rank, self.world = renderer, rank, world
         cfg = _lib.ArtMgpuConfig(rank=rank, world=world, compositor=_lib.ART_MGPU_DEDICATED if dedicated else _lib.ART_MGPU_SHARED,
-                                 launches_per_gather=launches_per_gather, tile_buffers=tile_buffers, transport=_lib.ART_MGPU_HOST_EXCHANGE if exchange else _lib.ART_MGPU_RCCL)
+                                 launches_per_gather=launches_per_gather, tile_buffers=tile_buffers, transport=_lib.ART_MGPU_HOST_EXCHANGE if exchange else _lib.ART_MGPU_RCCL,
+                                 roots=_lib.ART_MGPU_ROOT_SPREAD if spread else _lib.ART_MGPU_ROOT_RANK0)
         self._cb = None
         if exchange:
-            def _cb(user, send, nbytes, recv, stream):
+            def _cb(user, send, nbytes, recv, root, stream):
                 try:
-                    exchange(send, nbytes, recv, stream)
+                    exchange(send, nbytes, recv, root, stream)
                     return 0
                 except Exception:   # nothing may unwind into the C caller
                     import traceback
@@ -605,7 +607,7 @@ class MultiGpu:
         return dict(launches_traced=a.value, gathers=b.value, launches_per_gather=c.value)
 
     def read_frame(self):
-        """rank 0, after flush(): the most recent frame -- [h, w, 4] float32, or [h, w] uint32 B10G11R11 words with packed tiles"""
+        """a root (rank 0; every rank with spread roots), after flush(): the most recent frame it assembled -- [h, w, 4] float32, or [h, w] uint32 B10G11R11 words with packed tiles"""
         w, h = self.renderer.extent
         a = np.empty((h, w), np.uint32) if self.renderer.packed_tiles else np.empty((h, w, 4), np.float32)
         check(self._L.art_mgpu_read_frame(self._h, _ptr(a), a.nbytes))

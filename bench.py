@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--camera-path", type=int, default=8, help="N = 1 extra leg: the camera moves every frame along a closed path of this many poses (0 = skip); ray counts of every pose "
                                                                "are checked against the oracle's committed ones")
     ap.add_argument("--gather-launches", type=int, default=0, help="N>1: ring slots (launches) per RCCL gather; 0 = the whole ring (the slots are contiguous, so a group travels as one message per peer)")
+    ap.add_argument("--roots", default="spread", choices=["spread", "rank0"],
+                    help="N>1: where frames are assembled.  'spread' (default) = frame f on rank f mod N: every group of launches is one grouped ncclSend / ncclRecv (each frame's "
+                         "gather, all at once), every xGMI link carries its share in both directions; 'rank0' = one ncclGather per group to rank 0, which then receives over its own "
+                         "links only (2 GPUs: 12.4 MB of RGB32F tiles per 1080p frame over ONE link).  A dedicated compositor implies rank0")
     ap.add_argument("--compositor", default="shared", choices=["dedicated", "shared"],
                     help="N>1: 'shared' = rank 0 traces a share AND receives / un-tiles every frame; 'dedicated' = rank 0 only composites, ranks 1..N-1 trace 1/(N-1) each "
                          "(rehearsed on one GPU: a root that also traces a 1/8 share spends 35.5 us per frame where the tracers of a 7 + 1 layout need 39.1, profiles/README.md r1n)")
@@ -128,7 +132,8 @@ def main():
     renders = not (dedicated and rank == 0)
     # rank 0 also receives and un-tiles every frame: its share shrinks by 1/32 per GPU (2 GPUs: 6 %, 8 GPUs: 25 % of an equal share), which
     # is what levels its loop with the others' on the rehearsal (profiles/README.md r1n: 35.7 -> 31 us per frame at N = 8)
-    relief = 0 if (world == 1 or dedicated) else min(255, (8 * world if args.root_relief < 0 else args.root_relief))
+    spread = world > 1 and args.roots == "spread" and not dedicated
+    relief = 0 if (world == 1 or dedicated or spread) else min(255, (8 * world if args.root_relief < 0 else args.root_relief))
     renderer.set_root_relief(relief)
     shard = renderer.mgpu_shard(rank, world, dedicated) if world > 1 else (0, 1)
 
@@ -161,22 +166,22 @@ def main():
         if args.backend == "nccl":
             ids = [renderer.mgpu_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            mg = renderer.MultiGpu(r, rank, world, unique_id=ids[0], dedicated=dedicated, launches_per_gather=args.gather_launches)
-            transport = "RCCL ncclGather inside libart (art_mgpu_*)"
+            mg = renderer.MultiGpu(r, rank, world, unique_id=ids[0], dedicated=dedicated, launches_per_gather=args.gather_launches, spread=spread)
+            transport = "RCCL inside libart (art_mgpu_*): " + ("grouped ncclSend / ncclRecv" if spread else "ncclGather")
         else:
             import ctypes as C
             hip = C.CDLL("libamdhip64.so")
             hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
-            def gloo_gather(send, nbytes, recv, stream):   # the collective of the rehearsal: same call sequence, payload through host memory
+            def gloo_gather(send, nbytes, recv, root, stream):   # the collective of the rehearsal: same call sequence, payload through host memory
                 host = torch.empty(nbytes, dtype=torch.uint8)
                 assert hip.hipMemcpy(host.data_ptr(), send, nbytes, 2) == 0
-                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, parts, dst=0)
-                if rank == 0:
+                parts = [torch.empty_like(host) for _ in range(world)] if rank == root else None
+                dist.gather(host, parts, dst=root)
+                if rank == root:
                     for w_, part in enumerate(parts):
                         assert hip.hipMemcpy(recv + w_ * nbytes, part.data_ptr(), nbytes, 1) == 0
-            mg = renderer.MultiGpu(r, rank, world, dedicated=dedicated, launches_per_gather=args.gather_launches, exchange=gloo_gather)
+            mg = renderer.MultiGpu(r, rank, world, dedicated=dedicated, launches_per_gather=args.gather_launches, exchange=gloo_gather, spread=spread)
             transport = "host function over gloo (rehearsal)"
 
     def step():                       # one launch: B frames of this rank's share (+ its part of the exchange)
@@ -308,7 +313,7 @@ def main():
 
     # ---- outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit ---------------------------
     frame_ok = None
-    if world > 1 and rank == 0:
+    if world > 1 and (rank == 0 or spread):          # every rank that assembles frames checks the newest one it holds
         got = mg.read_frame()
         whole = make_renderer(device=local_rank)
         whole.render_frame()
@@ -318,6 +323,10 @@ def main():
         else:
             frame_ok = bool(np.array_equal(got.view(np.uint32), whole.read_color().view(np.uint32)))
         whole.close()
+    if spread:
+        oks = [None] * world
+        dist.all_gather_object(oks, frame_ok)
+        frame_ok = all(oks)
     counts = mg.counts() if mg else None
     if world > 1:
         t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["frame_ms"]], dtype=torch.float64)
@@ -414,9 +423,9 @@ def main():
         "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real glb" if glb else "synthetic",
         "config": {"workload": workload_name(sc, glb, W, H, lights, shadow_total, args), "width": W, "height": H, "lights": len(lights),
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else f" (rank 0 composites too and traces {256 - relief}/256 of a share)")
-                                   + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGB32F HDR (12 B/px; alpha is the constant 1)'} colour tiles to rank 0, {B} frames per launch, "
-                                     f"{counts['launches_per_gather'] * B} frames per gather") + f", {F * B} frames in flight"},
+                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else (" (every rank assembles the frames f with f mod N = its rank)" if spread else f" (rank 0 composites too and traces {256 - relief}/256 of a share)"))
+                                   + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGB32F HDR (12 B/px; alpha is the constant 1)'} colour tiles to {'the root of each frame' if spread else 'rank 0'}, {B} frames per launch, "
+                                     f"{counts['launches_per_gather'] * B} frames per exchange") + f", {F * B} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
         "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
         "camera_path": campath,

@@ -281,9 +281,14 @@ typedef struct ArtMgpu ArtMgpu;
 #define ART_MGPU_DEDICATED 1u  /* rank 0 only receives and un-tiles; ranks 1..world-1 trace 1/(world-1) each */
 #define ART_MGPU_RCCL 0u
 #define ART_MGPU_HOST_EXCHANGE 1u /* the collective is the caller's function (rehearsals on one GPU, where RCCL refuses two ranks per device; other fabrics) */
-/* must leave, ordered before anything enqueued on hip_stream afterwards, every rank's `bytes` bytes (rank order) in recv_dev on rank 0
+#define ART_MGPU_ROOT_RANK0 0u   /* every frame is assembled on rank 0: one ncclGather per group of launches */
+#define ART_MGPU_ROOT_SPREAD 1u  /* frame f (counted over the job, from 0) is assembled on rank f mod world: per group one ncclGroupStart .. ncclGroupEnd of ncclSend /
+                                    ncclRecv, i.e. every frame's gather at once.  xGMI is point to point, one link per pair of GPUs: a single root receives over its own
+                                    links only (2 GPUs: a half frame of RGB32F tiles, 12.4 MB at 1080p, per frame over ONE link); spread roots use every link in both
+                                    directions.  art_mgpu_device_frame / art_mgpu_read_frame then give, on every rank, the newest frame that fell to it. */
+/* must leave, ordered before anything enqueued on hip_stream afterwards, every rank's `bytes` bytes (rank order) in recv_dev on rank `root`
  * (recv_dev is NULL elsewhere); send_dev is complete when it is called.  Returns 0 or an error the library passes on as ART_E_HIP. */
-typedef int32_t (*ArtMgpuExchangeFn)(void *user, const void *send_dev, size_t bytes, void *recv_dev, void *hip_stream);
+typedef int32_t (*ArtMgpuExchangeFn)(void *user, const void *send_dev, size_t bytes, void *recv_dev, uint32_t root, void *hip_stream);
 typedef struct ArtMgpuConfig {
     uint32_t rank, world;        /* this process; processes (= GPUs) of the job */
     uint32_t compositor;         /* ART_MGPU_SHARED | ART_MGPU_DEDICATED */
@@ -292,6 +297,8 @@ typedef struct ArtMgpuConfig {
     uint32_t transport;          /* ART_MGPU_RCCL | ART_MGPU_HOST_EXCHANGE */
     ArtMgpuExchangeFn exchange;  /* ART_MGPU_HOST_EXCHANGE only */
     void *exchange_user;
+    uint32_t roots;              /* ART_MGPU_ROOT_RANK0 | ART_MGPU_ROOT_SPREAD (ART_MGPU_SHARED only) */
+    uint32_t reserved;
 } ArtMgpuConfig;
 /* host only: the shard (ArtConfig.shard_rank / shard_count) rank `rank` of `world` creates its context with */
 int32_t art_mgpu_shard(uint32_t rank, uint32_t world, uint32_t compositor, uint32_t *shard_rank, uint32_t *shard_count);
@@ -302,7 +309,7 @@ int32_t art_mgpu_create(ArtContext *ctx, const ArtMgpuConfig *cfg, const uint8_t
 int32_t art_mgpu_trace(ArtMgpu *mg);
 /* every frame traced so far has been gathered and (rank 0) un-tiled when it returns.  Collective. */
 int32_t art_mgpu_flush(ArtMgpu *mg);
-/* rank 0, after art_mgpu_flush: the most recently traced frame, assembled (width x height RGBA32F, or B10G11R11 words with packed tiles) */
+/* a root (rank 0; every rank with spread roots), after art_mgpu_flush: the most recently traced frame it assembled (width x height RGBA32F, or B10G11R11 words with packed tiles) */
 int32_t art_mgpu_device_frame(ArtMgpu *mg, void **dev_ptr, size_t *bytes);
 int32_t art_mgpu_read_frame(ArtMgpu *mg, void *dst, size_t bytes);
 /* frames traced / gathers submitted so far, and how many launches travel per gather */
