@@ -268,12 +268,13 @@ int32_t art_timestamp_elapsed(ArtContext *ctx, float *ms);
  * from the SAME 128-byte id (rank 0 makes it with art_mgpu_unique_id and passes it on by whatever channel the host has: a file, a socket,
  * MPI, torch.distributed).  Then every rank calls, frame after frame and in the same order,
  *     art_set_camera(ctx, ..)   (all ranks the same camera)        art_mgpu_trace(mg)
- * and rank 0 finds the assembled frames behind art_mgpu_flush / art_mgpu_read_frame.  Inside: the rank's share is traced into a ring of
- * compact tile buffers (4 per ring slot, written in turn); the tiles of `frames_per_gather` launches travel as ONE ncclGather (RCCL, rccl.h:745)
- * to rank 0 on a stream of their own, submitted by the host once it has SEEN the group's frames finish (art_frames_done: no device-side wait
- * in front of the collective or of the next frames -- such waits cost the frames in flight their L2 contents, profiles/README.md r1n), and one
- * launch un-tiles the group on rank 0 (art_untile_gathered_frames).  The payload is the context's tile format: RGB32F -- the HDR buffer, 12 B per pixel
- * (its alpha is the constant 1) -- by default, B10G11R11 words with ART_FLAG_PACKED_TILES.
+ * and the assembled frames are found behind art_mgpu_flush / art_mgpu_read_frame (on rank 0, or with ART_MGPU_ROOT_SPREAD frame f on rank f mod world).
+ * Inside: the rank's share is traced into a ring of compact tile buffers (4 per ring slot, written in turn); the tiles of `launches_per_gather`
+ * launches travel as ONE exchange -- an ncclGather (RCCL, rccl.h:745) to rank 0, or one ncclGroupStart .. ncclGroupEnd of ncclSend / ncclRecv that
+ * takes every frame to its own root -- on a stream of their own, submitted by the host once it has SEEN the group's frames finish (art_frames_done:
+ * no device-side wait in front of the collective or of the next frames -- such waits cost the frames in flight their L2 contents, profiles/README.md
+ * r1n), and one launch un-tiles a root's frames of the group (art_untile_gathered_frames).  The payload is the context's tile format: RGB32F -- the
+ * HDR buffer, 12 B per pixel (its alpha is the constant 1) -- by default, B10G11R11 words with ART_FLAG_PACKED_TILES.
  * RCCL is loaded at art_mgpu_create (dlopen of librccl.so.1: libart itself does not link it); ART_E_NO_DEVICE if it cannot be. */
 typedef struct ArtMgpu ArtMgpu;
 #define ART_MGPU_ID_BYTES 128
