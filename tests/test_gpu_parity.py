@@ -745,6 +745,10 @@ def test_api_state_and_argument_errors(R, get_scene):
     assert e.value.code == _lib.ART_E_INVALID
     with pytest.raises(_lib.ArtError):
         r.trace_ao(65)                                # spp out of range
+    n = C.c_uint32()
+    assert r._L.art_get_wide_nodes(r._ctx, None, None, 0, None) == _lib.ART_E_INVALID                          # nowhere to put the count
+    small = np.zeros((1, 16), np.uint32)
+    assert r._L.art_get_wide_nodes(r._ctx, small.ctypes.data, None, 1, C.byref(n)) == _lib.ART_E_INVALID and n.value > 1   # buffer too small: the count is still reported
     p = sc.primitives[0]
     bad = p.indices.copy(); bad[0] = p.verts.shape[0]  # index out of range is rejected on the host, never reaches a kernel
     with pytest.raises(_lib.ArtError) as e:
