@@ -44,7 +44,8 @@ def parse():
                                                                       "default 16 on one GPU (one hardware queue each), 12 launches when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--watchdog-seconds", type=float, default=0.0, help="if the run has not finished after this long, every rank prints its Python stack and exits 1 (0 = off): a hung job "
+    ap.add_argument("--watchdog-seconds", type=float, default=-1.0, help="if the run has not finished after this long, every rank prints its Python stack and exits 1 (0 = off; default: off "
+                    "for one GPU, 900 for N > 1, whose exchange no machine in reach could rehearse over RCCL): a hung job "
                     "then ends with a diagnosis instead of holding the GPU until someone kills it")
     ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed set-up before the warm-up: frames are traced for at least this long (and at least 3 ring depths), so the wave plan "
                     "has settled and the GPU has left its idle clocks; 0 = the 3 ring depths only")
@@ -54,7 +55,9 @@ def parse():
                                                  "block_order, split_alpha ...); the default -- none -- is the product")
     ap.add_argument("--camera-path", type=int, default=8, help="N = 1 extra leg: the camera moves every frame along a closed path of this many poses (0 = skip); ray counts of every pose "
                                                                "are checked against the oracle's committed ones")
-    ap.add_argument("--gather-launches", type=int, default=0, help="N>1: ring slots (launches) per RCCL gather; 0 = the whole ring (the slots are contiguous, so a group travels as one message per peer)")
+    ap.add_argument("--gather-launches", type=int, default=-1, help="N>1: ring slots (launches) per exchange; 0 = the whole ring (the slots are contiguous, so a group travels as one message "
+                    "per peer); default: a quarter of the timed launches, at most the ring -- a run of a few launches then still overlaps its exchanges with its tracing "
+                    "instead of paying one exchange of everything behind the last frame")
     ap.add_argument("--roots", default="spread", choices=["spread", "rank0"],
                     help="N>1: where frames are assembled.  'spread' (default) = frame f on rank f mod N: every group of launches is one grouped ncclSend / ncclRecv (each frame's "
                          "gather, all at once), every xGMI link carries its share in both directions; 'rank0' = one ncclGather per group to rank 0, which then receives over its own "
@@ -85,9 +88,10 @@ def host_cores():
 
 def main():
     args = parse()
-    if args.watchdog_seconds > 0:
+    watchdog = args.watchdog_seconds if args.watchdog_seconds >= 0 else (900.0 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0.0)
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -160,13 +164,15 @@ def main():
         r.set_frames_per_launch(B)
     r.upload_state()
 
+    # launches per exchange: explicit, or a quarter of the timed launches (libart rounds it down to a divisor of the ring)
+    gather_launches = args.gather_launches if args.gather_launches >= 0 else max(1, min(F, (args.steps // B) // 4))
     # ---- N > 1: the sharded frame behind the C ABI -------------------------------------------------------------------------------------
     mg, transport = None, None
     if world > 1:
         if args.backend == "nccl":
             ids = [renderer.mgpu_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            mg = renderer.MultiGpu(r, rank, world, unique_id=ids[0], dedicated=dedicated, launches_per_gather=args.gather_launches, spread=spread)
+            mg = renderer.MultiGpu(r, rank, world, unique_id=ids[0], dedicated=dedicated, launches_per_gather=gather_launches, spread=spread)
             transport = "RCCL inside libart (art_mgpu_*): " + ("grouped ncclSend / ncclRecv" if spread else "ncclGather")
         else:
             import ctypes as C
@@ -181,7 +187,7 @@ def main():
                 if rank == root:
                     for w_, part in enumerate(parts):
                         assert hip.hipMemcpy(recv + w_ * nbytes, part.data_ptr(), nbytes, 1) == 0
-            mg = renderer.MultiGpu(r, rank, world, dedicated=dedicated, launches_per_gather=args.gather_launches, exchange=gloo_gather, spread=spread)
+            mg = renderer.MultiGpu(r, rank, world, dedicated=dedicated, launches_per_gather=gather_launches, exchange=gloo_gather, spread=spread)
             transport = "host function over gloo (rehearsal)"
 
     def step():                       # one launch: B frames of this rank's share (+ its part of the exchange)
