@@ -166,7 +166,12 @@ int32_t poll(ArtMgpu *m, bool force) {
         if (m->renders) {
             int32_t done = 0;
             MGA(art_frames_done(m->ctx, g.first_launch, g.n, &done, nullptr));
-            if (!done) { if (!force) return ART_OK; MGA(art_sync(m->ctx)); }
+            if (!done) {
+                if (!force) return ART_OK;
+                // wait for THIS group's frames only (the host spins on their events): at a flush behind a short burst of launches the first group's
+                // exchange then runs while the later launches still trace, instead of every exchange queueing up behind the last frame (art_sync)
+                while (!done) MGA(art_frames_done(m->ctx, g.first_launch, g.n, &done, nullptr));
+            }
         }
         m->fifo.pop_front();
         MGA(run_exchange(m, g));
