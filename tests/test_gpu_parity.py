@@ -783,6 +783,22 @@ def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
     r.close()
 
 
+@pytest.mark.parametrize("form", ["fused", "staged", "per-ray"])
+def test_directional_lights_along_the_axes_and_unnormalised(R, orc, get_scene, scenes, form):
+    """a directional light's L, |nn_L| and the shadow ray's reciprocal direction are made on the host, once (art_api.hip directional_constants), with the
+    operations the oracle runs per pixel: axis-aligned directions (zero components: the reciprocal's safe_dir branch, signed zeros), an unnormalised and a
+    tiny one, in every form of the frame -- hits, shadow bits and ray counts bit-equal to the oracle's, radiance within 1e-4"""
+    sc = get_scene("cornell")
+    lights = [dict(kind="point", pos=(0.1, 0.3, 0.2), color=(3.0, 3.0, 3.0), falloff=3.0, casts_shadows=True),   # (the light table lists point lights first: lights.rs)
+              dict(kind="directional", dir=(0.0, -1.0, 0.0), color=(2.0, 2.0, 2.0), casts_shadows=True),
+              dict(kind="directional", dir=(-1.0, 0.0, 0.0), color=(0.5, 1.0, 0.5), casts_shadows=True),
+              dict(kind="directional", dir=(0.0, 0.0, 1.0), color=(1.0, 0.5, 0.5), casts_shadows=True),
+              dict(kind="directional", dir=(-3.0, -7.0, 2.0), color=(0.7, 0.7, 1.5), casts_shadows=True),
+              dict(kind="directional", dir=(1e-12, -2e-12, -1e-12), color=(0.4, 0.4, 0.4), casts_shadows=True)]
+    ref = _frame_parity(R, orc, scenes.Scene(sc.name, sc.primitives, sc.camera, lights), 128, 96, None, form=form)
+    assert ref["stats"]["shadow_rays"] > 128 * 96 * 2
+
+
 def test_lights_change_every_frame_while_sixteen_frames_are_in_flight(R, orc, get_scene, scenes):
     """a light animated every frame with 16 frames in flight (a double-buffered device table was overwritten while launches queued
     frames ago still read it): the light records travel by value with each launch, so every frame shows ITS lights -- each one against the oracle"""
