@@ -6,7 +6,7 @@
 //
 // Pipeline: soup (index fetch + object->world) -> centroid bounds (ordered-int atomics) -> Morton keys ->
 // stable radix sort (rocPRIM) -> Karras 2012 radix tree -> bottom-up AABB refit (arrival counters) ->
-// 64-byte traversal nodes + 48-byte leaf-ordered triangles.
+// 64-byte traversal nodes + 64-byte leaf-ordered triangle records; the 4-wide collapse of the traversal tree, level by level (wide_build).
 #include "art_internal.h"
 #include <rocprim/rocprim.hpp>
 #include <cmath>
