@@ -106,10 +106,11 @@ int32_t run_exchange_spread(ArtMgpu *m, const Group &g, const char *send) {
     const bool nccl = m->cfg.transport == ART_MGPU_RCCL;
     uint32_t mine = 0;
     int rc = 0;
+    bool overflow = false;
     if (nccl && (rc = rccl().GroupStart()) != 0) return mg_fail(ART_E_HIP, std::string("ncclGroupStart: ") + rccl().GetErrorString(rc));
     for (uint32_t j = 0; j < nf; j++) {
         const uint32_t q = (uint32_t)((g.first_frame + j) % W);
-        if (q == r && mine >= m->nf_cap) return mg_fail(ART_E_STATE, "art_mgpu: more frames of a group fall to this rank than it has room for");   // (cannot happen: nf_cap = ceil(GB * B / world))
+        if (q == r && mine >= m->nf_cap) { overflow = true; break; }   // (cannot happen: nf_cap = ceil(GB * B / world); checked so that no receive can land outside the buffer)
         if (nccl) {
             if ((rc = rccl().Send(send + (size_t)j * ftb, ftb, kNcclUint8, (int)q, m->comm, m->xs)) != 0) break;
             if (q == r) for (uint32_t p = 0; p < W && rc == 0; p++) rc = rccl().Recv(m->gathered + ((size_t)p * m->nf_cap + mine) * ftb, ftb, kNcclUint8, (int)p, m->comm, m->xs);
@@ -128,6 +129,7 @@ int32_t run_exchange_spread(ArtMgpu *m, const Group &g, const char *send) {
         int rc2 = rccl().GroupEnd();   // (always closed, also after a failed call inside it)
         if (rc != 0 || rc2 != 0) return mg_fail(ART_E_HIP, std::string("ncclSend / ncclRecv / ncclGroupEnd: ") + rccl().GetErrorString(rc ? rc : rc2));
     }
+    if (overflow) return mg_fail(ART_E_STATE, "art_mgpu: more frames of a group fall to this rank than it has room for");
     if (mine) {
         MGA(art_untile_gathered_frames(m->ctx, m->gathered, W, m->nf_cap * m->lay.tiles_padded, mine, m->frames, m->xs));
         m->newest = mine - 1; m->have_frame = true;
