@@ -25,6 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # N > 1: 12 launches of 4 frames each in flight on 16 hardware queues -- the exchange stream and RCCL's streams get queues of their own, and
 # the command processor's cliff at 24 queues in use (3x slower: profiles/README.md r1k) stays far away.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between the processes of a job on this driver
 
 
 def parse():
