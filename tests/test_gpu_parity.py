@@ -50,7 +50,7 @@ def test_ray_queries_match_oracle_bitwise(R, orc, get_scene, name, detail):
     r.close()
 
 
-FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"frame_form": 1}), "per-ray": (1, {"frame_form": 2})}   # ArtTuning (art_set_tuning)
+FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"frame_form": 1}), "per-ray": (1, {"frame_form": 2}), "fused-binary": (3, {"packet_wide": 2})}   # ArtTuning (art_set_tuning)
 
 
 def _frame_parity(R, orc, sc, w, h, n_lights, form="fused"):
@@ -781,6 +781,39 @@ def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
             r.lights_mut().get_point_lights_mut().append(R.PointLight((0, 0.5, 0), (1, 1, 1), 3.0, False))
         r.upload_state()
     r.close()
+
+
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "staged", "per-ray"])
+def test_degenerate_geometry_resolves_as_the_oracle_does(R, orc, get_scene, scenes, form):
+    """what a driver's traversal leaves undefined and DESIGN.md 1.1 defines: two IDENTICAL triangles (the hit goes to the lower global id), coplanar overlapping
+    triangles, zero-area triangles (three collinear points, three equal points: never hit), a sliver a fraction of a pixel wide, and a fan whose shared vertex and
+    edges lie under pixel centres -- hit ids, t, u, v and shadow bits bit-equal to the oracle's in every form of the frame and on every tree"""
+    import numpy as np
+    sc = get_scene("cornell")
+    mb = scenes.MeshBuilder()
+    n, t = (0.0, 0.0, -1.0), (1.0, 0.0, 0.0, 1.0)
+    def tri(a, b, c):
+        mb.add([a, b, c], [(0.0, 0.0), (1.0, 0.0), (0.0, 1.0)], [n] * 3, [t] * 3, [0, 1, 2])
+    z = 0.2
+    tri((-0.5, -0.3, z), (0.1, -0.3, z), (-0.5, 0.4, z)); tri((-0.5, -0.3, z), (0.1, -0.3, z), (-0.5, 0.4, z))   # the same triangle twice
+    tri((-0.3, -0.2, z), (0.4, -0.2, z), (-0.3, 0.5, z))                                                        # coplanar with them, overlapping
+    tri((0.2, 0.1, 0.1), (0.3, 0.2, 0.1), (0.4, 0.3, 0.1)); tri((0.2, -0.2, 0.1), (0.2, -0.2, 0.1), (0.2, -0.2, 0.1))   # zero area: a line, a point
+    tri((-0.6, 0.5, 0.0), (0.6, 0.5004, 0.0), (0.6, 0.5, 0.0))                                                  # a sliver
+    c = (0.0, 0.0, 0.05)                                                                                         # a fan round the view axis: its centre and spokes under pixel centres
+    ring = [(0.3 * np.cos(a), 0.3 * np.sin(a), 0.05) for a in np.linspace(0.0, 2.0 * np.pi, 9)[:-1]]
+    for k in range(8):
+        tri(c, ring[k], ring[(k + 1) % 8])
+    extra = mb.finish(scenes.constant_texture((180, 180, 60)))
+    lights = [dict(kind="point", pos=(0.0, 0.3, -0.3), color=(6.0, 6.0, 6.0), falloff=3.0, casts_shadows=True),
+              dict(kind="directional", dir=(0.2, -0.4, 1.0), color=(1.0, 1.0, 1.0), casts_shadows=True)]
+    ref = _frame_parity(R, orc, scenes.Scene("cornell+degenerate", list(sc.primitives) + [extra], sc.camera, lights), 129, 97, None, form=form)   # odd extent: a pixel centre on the view axis
+    ids = ref["hit_id"]
+    on_extra = ids[..., 0] == len(sc.primitives)
+    assert on_extra.sum() > 500
+    tris_hit = set(np.unique(ids[on_extra][:, 1]).tolist())
+    assert 0 in tris_hit and 1 not in tris_hit           # of the two identical triangles only the first is ever the hit
+    assert 3 not in tris_hit and 4 not in tris_hit       # zero-area triangles are never hit
+    assert tris_hit & set(range(6, 14))                  # the fan is
 
 
 @pytest.mark.parametrize("form", ["fused", "staged", "per-ray"])
