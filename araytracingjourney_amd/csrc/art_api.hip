@@ -466,13 +466,22 @@ bool mat4_inverse(const float *m, float *o) {
     inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
     inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
     float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
-    if (det == 0.0f) return false;
+    if (!(std::fabs(det) > 0.0f)) return false; // singular, or NaN somewhere in m
     det = 1.0f / det;
-    for (int i = 0; i < 16; i++) o[i] = inv[i] * det;
-    return true;
+    bool finite = true;
+    for (int i = 0; i < 16; i++) { o[i] = inv[i] * det; finite = finite && std::isfinite(o[i]); }
+    return finite;
 }
 
 } // namespace
+
+// a camera block with a NaN or an infinity in it makes rays no triangle can be tested against (the packed struct is read through a copy: its floats are unaligned)
+static bool camera_finite(const ArtCamera *cam) {
+    float v[sizeof(ArtCamera) / 4];
+    std::memcpy(v, cam, sizeof(ArtCamera));
+    for (float x : v) if (!std::isfinite(x)) return false;
+    return true;
+}
 
 // hit records name a triangle by its global id: the primitive is the last slot whose first triangle is <= gid (k_soup's rule)
 static void gid_to_ids(const ArtContext *c, uint32_t gid, int32_t *ids) {
@@ -723,6 +732,7 @@ int32_t art_scene_build(ArtContext *c) {
 
 int32_t art_set_camera(ArtContext *c, const ArtCamera *cam) {
     if (!c || !cam) return fail(ART_E_INVALID, "art_set_camera: null argument");
+    if (!camera_finite(cam)) return fail(ART_E_INVALID, "art_set_camera: non-finite value in the camera block");
     if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) drop_graphs(c); // the camera block is a kernel argument
     if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) { c->plan.next_sample = c->frame_no; c->plan.interval = 1; } // the heavy blocks move with the view
     c->camera = *cam; c->have_camera = true;
@@ -744,6 +754,7 @@ int32_t art_set_frames_per_launch(ArtContext *c, uint32_t n) {
 int32_t art_set_camera_batch(ArtContext *c, const ArtCamera *cams, uint32_t n) {
     if (!c || !cams) return fail(ART_E_INVALID, "art_set_camera_batch: null argument");
     if (n != c->B) return fail(ART_E_INVALID, "art_set_camera_batch: one camera per frame of a launch (art_set_frames_per_launch)");
+    for (uint32_t i = 1; i < n; i++) if (!camera_finite(&cams[i])) return fail(ART_E_INVALID, "art_set_camera_batch: non-finite value in a camera block");
     int32_t r = art_set_camera(c, &cams[0]); if (r) return r;
     for (uint32_t i = 1; i < n; i++) c->cam_more[i - 1] = cams[i];
     return ART_OK;
@@ -773,7 +784,8 @@ int32_t art_camera_from_params(const float pos[3], const float dir[3], float asp
     std::memset(P, 0, 64);
     float cc = 1.0f / std::tan(fovy * 0.5f);
     P[0] = cc / aspect; P[5] = cc; P[10] = (zfar + znear) / (znear - zfar); P[14] = 2.0f * zfar * znear / (znear - zfar); P[11] = -1.0f;
-    if (!mat4_inverse(out->view, out->view_inv) || !mat4_inverse(out->proj, out->proj_inv)) return fail(ART_E_INVALID, "art_camera_from_params: singular matrix");
+    // (a direction along the up axis (0, -1, 0) has no side vector: look_at_rh's cross product is zero and the view matrix NaN -- an error here, where the reference would render NaN)
+    if (!mat4_inverse(out->view, out->view_inv) || !mat4_inverse(out->proj, out->proj_inv)) return fail(ART_E_INVALID, "art_camera_from_params: singular or non-finite view / projection matrix (direction along the up axis, zero field of view, znear == zfar ...)");
     out->camera_pos[0] = pos[0]; out->camera_pos[1] = pos[1]; out->camera_pos[2] = pos[2];
     return ART_OK;
 }

@@ -297,8 +297,9 @@ static hipError_t wide_build_host(Lbvh &l, uint32_t T, hipStream_t s) {
         }
         uint32_t mask = 0;
         for (int i = 0; i < 4; i++) {
-            if (i >= nc) { d.child[i] = 0x7FFFFFFF; dw.child[i] = 0x7FFFFFFF; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; } // an absent child: a point box out at 3e38 -- every axis' entry
-            // and exit distance is +-huge with the SAME sign, so neither the octant-specialised nor the general slab test lets a ray in (an INVERTED box passes the general one)
+            if (i >= nc) { d.child[i] = kAbsentChild; dw.child[i] = kAbsentChild; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; } // an absent child: a point box out at 3e38 -- every axis' entry
+            // and exit distance is +-huge with the SAME sign, so neither the octant-specialised nor the general slab test lets a finite ray in (an INVERTED box passes the general one);
+            // its reference is the walks' "pop" value, so a ray that passes every box (NaN: fminf / fmaxf drop a NaN operand) still cannot leave the node array
             mask |= 1u << i;
             BoxRef b = box(cand[i]);
             for (int k = 0; k < 3; k++) {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void k_wide_expand(WideIn in, const int32_t *_
                                                      uint32_t *__restrict__ meta /*nc | axis << 8*/, uint32_t *__restrict__ n_internal) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n) return;
-    int32_t cand[4] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}; int nc = 0;
+    int32_t cand[4] = {kAbsentChild, kAbsentChild, kAbsentChild, kAbsentChild}; int nc = 0;
     const int32_t root = front[w];
     if (root < 0) cand[nc++] = root; // single triangle: a root with one leaf child
     else {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256) void k_wide_emit(WideIn in, uint32_t n, uint32
     }
     uint32_t mask = 0, next = first + n + offs[w]; // this node's internal children follow those of the nodes before it
     for (int i = 0; i < 4; i++) {
-        if (i >= nc) { d.child[i] = 0x7FFFFFFF; dw.child[i] = 0x7FFFFFFF; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; }
+        if (i >= nc) { d.child[i] = kAbsentChild; dw.child[i] = kAbsentChild; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; }
         mask |= 1u << i;
         const float *lo, *hi; wide_box(in, cand[i], lo, hi);
         for (int k = 0; k < 3; k++) {

@@ -42,6 +42,8 @@ static_assert(sizeof(DevNode4) == 64, "DevNode4 layout");
 //   child is a point box at +3e38, which no slab test passes
 struct alignas(16) DevNodeW { float box[4][6]; int32_t child[4]; uint32_t valid; uint32_t pad[3]; };
 static_assert(sizeof(DevNodeW) == 128, "DevNodeW layout");
+// reference of an absent child in both 4-wide records: INT32_MIN, the packet walk's own "take the next node from the stack" value (no leaf sits at position 2^31 - 1)
+constexpr int32_t kAbsentChild = (int32_t)0x80000000;
 // 64-byte triangle in leaf order, everything accept() needs in the form it needs it (one 64-byte scalar load for a packet):
 //   f[0..2] v0 | f[3..5] e1 = v1 - v0 | f[6..8] e2 = v2 - v0 | f[9..11] box lo | f[12..14] box hi | f[15] gid (bits)
 // e1, e2 and the box are the very float operations the tests would otherwise repeat per ray (one subtraction each; min / max of the three vertices),

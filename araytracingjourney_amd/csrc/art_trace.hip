@@ -61,6 +61,13 @@ __device__ __forceinline__ void ray_init_inv(Ray &r, V3 o, V3 d, V3 inv, float t
     r.o = o; r.d = d; r.tmin = tmin; r.tmax = tmax; r.inv = inv;
     r.ood = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
 }
+// A ray with a non-finite origin or direction accepts no triangle (every Moeller-Trumbore quantity involves both, and a comparison with NaN is false),
+// but it passes every box: fminf / fmaxf drop a NaN operand.  Its lane is switched off before the walk -- the same miss, without the walk of the whole tree.
+// (0 * x is 0 for a finite x and NaN otherwise; nothing here is compiled with fast-math.)
+__device__ __forceinline__ bool ray_finite(V3 o, V3 d) {
+    float z = 0.0f * o.x; z = fmaf(0.0f, o.y, z); z = fmaf(0.0f, o.z, z); z = fmaf(0.0f, d.x, z); z = fmaf(0.0f, d.y, z); z = fmaf(0.0f, d.z, z);
+    return z == 0.0f;
+}
 // monotone slab test against [tmin, tlimit]; tn = un-clamped entry distance
 __device__ __forceinline__ bool slab(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float tlimit, float &tn) {
     float t0x = fmaf(lx, r.inv.x, -r.ood.x), t1x = fmaf(hx, r.inv.x, -r.ood.x);
@@ -154,7 +161,8 @@ template <bool ANY, int OVF> struct TravBase {
     int cur, sp;
     __device__ __forceinline__ void start(V3 o, V3 d, float tmin, float tmax) {
         ray_init(r, o, d, tmin, tmax);
-        tbest = tmax; bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; cur = 0; sp = 0;
+        tbest = (ray_finite(o, d) && tmax == tmax) ? tmax : -INFINITY; // a non-finite ray (or range) fails the root's box test and ends as a miss
+        bu = 0.f; bv = 0.f; bpos = kNoHit; bgid = kNoHit; cur = 0; sp = 0;
     }
     __device__ __forceinline__ void push(int ref, int *lds, int *ovf) {
         // the spill accesses are volatile so that the compiler keeps them apart from the LDS ones: merged, they become flat_load
@@ -294,7 +302,7 @@ template <class T> __device__ __forceinline__ ConstQuads const_quads(const T *p)
 template <bool ANY, bool WIDE, int OCT, bool COUNT = false>
 __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps) {
     int cur = 0, sp = 0; // wave-uniform
-    constexpr int kPop = (int)0x80000000; // "take the next node from the stack" (no leaf has position 2^31 - 1)
+    constexpr int kPop = kAbsentChild; // "take the next node from the stack" (no leaf has position 2^31 - 1); also what an absent child of a 4-wide node refers to
     for (;;) {
         if (COUNT) steps++; // wave-uniform: nodes + triangles the packet visited (the fused frame's wave plan feeds on it; one s_add here costs 3.5 %, so only sampled frames count)
         if (cur >= 0 && WIDE) {
@@ -441,6 +449,7 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
         ray_init(r, o, d, x.ao_radius * 0.01f, x.ao_radius);
     }
     const bool traced = on;
+    on = on && ray_finite(r.o, r.d);
     float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f; // -1: below every tmin, no box test passes (lanes without a ray, occluded lanes)
     uint32_t bpos = kNoHit, bgid = kNoHit;
     uint32_t steps = 0;
@@ -997,7 +1006,7 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         V3 dir = mat4_mul(cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
         ray_init(r, org, dir, 0.001f, 10000.0f);
     }
-    bool on = in;
+    bool on = in && ray_finite(r.o, r.d);
     PHASE(0, r.inv.x)
     float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f;
     uint32_t bpos = kNoHit, bgid = kNoHit;
@@ -1030,7 +1039,7 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         Ray sr;
         if (a.lights[i].type == 2u) ray_init_inv(sr, mk(ro.x, ro.y, ro.z), ld3(a.lights[i].area_pos2), ld3(a.lights[i].area_pos3), 0.01f, a.lights[i].penumbra_angle); // (wave-uniform branch)
         else ray_init(sr, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), 0.01f, ro.w);
-        bool son = want;
+        bool son = want && ray_finite(sr.o, sr.d);
         PHASE(3, sr.inv.x)
         float st = son ? sr.tmax : -1.0f, su = 0.f, sv = 0.f;
         uint32_t spos = kNoHit, sgid = kNoHit;

@@ -157,7 +157,9 @@ int32_t art_scene_set_primitive_enabled(ArtContext *ctx, uint32_t primitive_id, 
  * (vk_tlas_builder.rs:38-233): device LBVH over the world-space triangle soup. */
 int32_t art_scene_build(ArtContext *ctx);
 
-/* VkCamera::update_host_buffer (vk_camera.rs:104-126): the 268-byte block; and its producer */
+/* VkCamera::update_host_buffer (vk_camera.rs:104-126): the 268-byte block; and its producer.  A block holding a NaN or an infinity is ART_E_INVALID, and so
+ * are parameters that have no finite matrices (a direction along the up axis (0, -1, 0) or of zero length, fovy 0, znear == zfar): the reference would
+ * render NaN.  Rays that still come out non-finite (a finite but singular block) are misses, as in the oracle. */
 int32_t art_set_camera(ArtContext *ctx, const ArtCamera *cam);
 int32_t art_camera_from_params(const float pos[3], const float dir[3], float aspect, float fovy, float znear,
                                float zfar, ArtCamera *out);
@@ -362,7 +364,7 @@ int32_t art_get_lbvh(ArtContext *ctx, uint32_t *leaf_gid, uint64_t *keys, int32_
 int32_t art_get_traversal_tree(ArtContext *ctx, int32_t *child, float *node_lo, float *node_hi);
 /* the 4-wide collapse of that tree as the walks read it (new functionality: the reference's acceleration structures are opaque, vk_blas_builder.rs:88-170):
  * n_nodes records of 64 B (8-bit quantised child boxes: the per-ray walks) and of 128 B (float child boxes, children sorted along one axis: the packet
- * walks); node 0 is the root, child >= 0: node index, < 0: ~leaf position, 0x7FFFFFFF: absent.  Either pointer may be NULL; *n_nodes is always set. */
+ * walks); node 0 is the root, child >= 0: node index, < 0: ~leaf position, INT32_MIN: absent (bit i of the records' valid masks clear).  Either pointer may be NULL; *n_nodes is always set. */
 int32_t art_get_wide_nodes(ArtContext *ctx, void *quantised, void *floats, size_t capacity_nodes, uint32_t *n_nodes);
 
 /* ---- GLB ingest: the step right before the path (model_reader/gltf_model_reader.rs), host only ------------------ */

@@ -339,7 +339,8 @@ def test_wide_collapse_on_the_device_equals_the_host_loop(R, get_scene, name, de
     assert np.array_equal(qd, qh) and np.array_equal(fd, fh)
     T = dev.stats()["num_triangles"]
     child = fd[:, 24:28].view(np.int32)
-    valid = child != 0x7FFFFFFF
+    valid = child != -2**31                                                       # an absent child refers to INT32_MIN, the walks' "pop" value
+    assert np.array_equal(valid, ((fd[:, 28][:, None] >> np.arange(4)) & 1).astype(bool))  # ... and the valid bits say the same
     assert np.array_equal(child, qd[:, 12:16].view(np.int32))
     leaves = np.sort(~child[valid & (child < 0)])
     assert np.array_equal(leaves, np.arange(T))                                  # every leaf exactly once
@@ -757,6 +758,57 @@ def test_api_state_and_argument_errors(R, get_scene):
     cfg = _lib.ArtConfig(device=99, width=8, height=8)
     ctx = C.c_void_p()
     assert _lib.load().art_create(C.byref(cfg), C.byref(ctx)) == _lib.ART_E_INVALID
+    r.close()
+
+
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "staged", "per-ray"])
+def test_non_finite_cameras_are_errors_and_non_finite_rays_are_misses(R, orc, get_scene, form):
+    """A camera looking along the up axis has no side vector (look_at_rh's cross product is zero): an error, like a NaN anywhere in a raw block.
+    A finite block can still make non-finite rays (a projection inverse of zeros normalises the zero vector): such a ray accepts no triangle in
+    the oracle (every Moeller-Trumbore comparison with NaN is false) and passes every box (fminf / fmaxf drop a NaN operand) -- the walks switch
+    its lane off and the frame is the oracle's: all misses.  (Until round 3 the 4-wide packet walk followed the reference of an absent child.)"""
+    from araytracingjourney_amd import _lib
+    import ctypes as C
+    import math
+    sc = get_scene("cornell")
+    w = h = 64
+    fif, tuning = FORMS[form]
+    r = R.renderer_for_scene(sc, (w, h), keep_debug=True, frames_in_flight=fif, tuning=tuning)
+    for d in ((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), (0.0, 0.0, 0.0)):
+        blk = _lib.ArtCamera()
+        rc = r._L.art_camera_from_params((C.c_float * 3)(0, 0, 0), (C.c_float * 3)(*d), 1.0, math.pi / 2, 0.1, 1000.0, C.byref(blk))
+        assert rc == _lib.ART_E_INVALID, d
+    good = r.camera_mut().update_host_buffer()
+    bad = _lib.ArtCamera.from_buffer_copy(bytes(good))
+    bad.view_inv[5] = float("nan")
+    assert r._L.art_set_camera(r._ctx, C.byref(bad)) == _lib.ART_E_INVALID
+    bad = _lib.ArtCamera.from_buffer_copy(bytes(good))
+    bad.camera_pos[1] = float("inf")
+    assert r._L.art_set_camera(r._ctx, C.byref(bad)) == _lib.ART_E_INVALID
+    r.render_frame()
+    assert r.stats()["hit_pixels"] > 1000                                        # the good camera sees the box
+    zero = _lib.ArtCamera.from_buffer_copy(bytes(good))
+    for i in range(16):
+        zero.proj_inv[i] = 0.0                                                   # finite, and every ray direction is normalize(0) = NaN
+    assert r._L.art_set_camera(r._ctx, C.byref(zero)) == 0
+    arr, n = r.lights_mut().copy_lights_shader_data()
+    assert r._L.art_set_lights(r._ctx, arr, n) == 0
+    r.trace(); r.sync()
+    S, L, nl = oracle_for(orc, sc)
+    ref = S.render(orc.OrcCamera.from_buffer_copy(bytes(zero)), L, nl, w, h, threads=2, debug=True)
+    assert ref["stats"]["hit_pixels"] == 0 and (ref["hit_id"] == -1).all()
+    _, ids = r.read_hits()
+    assert np.array_equal(ids, ref["hit_id"])
+    st = r.stats()
+    assert st["hit_pixels"] == 0 and st["shadow_rays"] == 0
+    assert np.array_equal(r.read_color(), ref["color"]) and np.array_equal(r.read_depth(), ref["depth"]) and np.array_equal(r.read_normal(), ref["normal"])
+    # ray queries: NaN / infinite origins, directions and ranges are misses, in both per-ray walks
+    rays = random_rays(64, 3)
+    rays[0::4, 4] = np.nan; rays[1::4, 1] = np.inf; rays[2::4, 7] = np.nan
+    tuv, qids = r.query_closest(rays)
+    rtuv, rids, _, _ = S.trace_closest(rays)
+    assert np.array_equal(qids, rids) and (qids[0::4] == -1).all() and (qids[1::4] == -1).all() and (qids[2::4] == -1).all() and (qids[3::4, 0] >= 0).any()
+    assert np.array_equal(r.query_any(rays), S.trace_any(rays)[0])
     r.close()
 
 
