@@ -47,7 +47,8 @@ class ArtStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("hit_pixels", C.c_uint64), ("ao_rays", C.c_uint64),
                 ("num_triangles", C.c_uint32), ("num_primitives", C.c_uint32), ("num_nodes", C.c_uint32), ("frame_launches", C.c_uint32),
                 ("build_ms", C.c_float), ("frame_ms", C.c_float), ("trace_primary_ms", C.c_float), ("shade_ms", C.c_float),
-                ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float), ("ao_ms", C.c_float), ("split_blocks", C.c_uint32)]
+                ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float), ("ao_ms", C.c_float), ("split_blocks", C.c_uint32),
+                ("refit_ms", C.c_float), ("refit_cost_ratio", C.c_float), ("refits", C.c_uint32), ("rebuilds", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
@@ -62,7 +63,7 @@ class ArtGlbCopyInfo(C.Structure):
 class ArtTuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("frame_form", "tree_builder", "frame_waves", "packet_wide", "primary_walk", "shadow_walk", "ao_walk", "block_order", "fixed_waves",
                                           "split_fixed_steps", "split_min_steps")] + [("split_alpha", C.c_float)] + \
-               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder")]
+               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder", "as_versions")] + [("refit_rebuild_ratio", C.c_float)]
 
 
 class ArtLayout(C.Structure):
@@ -96,6 +97,7 @@ SYMBOLS = {
     "art_scene_add_primitive": (_I32, [_P, _P, _U32, _P, _U32, _U32, _P, _U32, _U32, _P, _P]),
     "art_scene_clear": (_I32, [_P]),
     "art_scene_set_primitive_enabled": (_I32, [_P, _U32, _I32]),
+    "art_scene_set_model_matrix": (_I32, [_P, _U32, _U32, _P]),
     "art_scene_build": (_I32, [_P]),
     "art_set_camera": (_I32, [_P, _P]),
     "art_camera_from_params": (_I32, [_P, _P, _F, _F, _F, _F, _P]),

@@ -65,6 +65,7 @@ struct FrameSlot {
     hipEvent_t done = nullptr;       // recorded after the slot's last frame
     hipGraphExec_t graph = nullptr;  // the frame's launch sequence captured once (graph mode); dropped whenever an input changes
     void *wait_event = nullptr;      // external event the slot's next frame must wait for (art_wait_external_event)
+    uint32_t as_version = 0;         // which version of the acceleration structure the slot's latest frame read (art_trace_ao and the read-backs follow it)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
         d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_pix.release(); d_wave_cost.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
@@ -104,6 +105,22 @@ struct WavePlan {
     }
 };
 
+// One version of what a frame reads of the acceleration structure.  A static scene has none (the build's arrays are read directly); the first
+// art_scene_set_model_matrix makes a small ring of them: a refit writes the NEXT version while frames in flight still read the older ones, like the
+// reference's per-frame TLAS (one VkTlasBuilder per FrameData, renderer.rs:300-318, :637-651).  Version 0 is the build's own arrays.
+constexpr uint32_t kMaxAsVersions = 8;
+struct AsVersion {
+    DevTri *tris = nullptr; DevNodeW *widef = nullptr; DevNode4 *wide = nullptr; DevPrim *prims = nullptr;
+    bool owned = false;                  // version 0 aliases c->bvh.* and c->d_prims
+    DevPrim *h_prims = nullptr;          // pinned staging copy of the primitive table (the upload is a fully asynchronous copy on the frame's stream)
+    uint64_t used[kMaxFrameSlots] = {};  // frame number + 1 of the newest launch on each ring slot that read this version (0: none)
+    bool aux[kMaxFrameSlots] = {};       // art_trace_ao / art_present ran behind that frame on the slot's stream
+    hipEvent_t ready = nullptr; bool ready_known = true; uint32_t ready_slot = 0; // the refit that wrote it: recorded on ring slot ready_slot's stream
+    hipEvent_t t0 = nullptr, t1 = nullptr; bool timed = false;                     // that refit's device time
+    double *d_cost = nullptr, *h_cost = nullptr; hipEvent_t cost_ev = nullptr; bool cost_pending = false; // its surface-area cost, on its way to the host
+    uint64_t epoch = 0;                  // which refit wrote it (0: the build)
+};
+
 struct ArtContext {
     ArtConfig cfg{};
     int device = 0;
@@ -130,6 +147,11 @@ struct ArtContext {
     std::vector<uint32_t> h_first_tri; // first global triangle id of every primitive slot (ascending): gid -> (primitive, triangle) on the host
     Lbvh bvh{};
     uint32_t T = 0;
+    // moving models (art_scene_set_model_matrix): versions of the structure, the primitive table as the next refit will upload it
+    std::vector<AsVersion> as; uint32_t as_cur = 0; bool xform_dirty = false;
+    std::vector<DevPrim> h_dev_prims;          // host copy of d_prims (build order), matrices kept current
+    uint64_t as_epoch = 0, binary_epoch = 0;   // refits so far; the refit the binary trees / node records reflect
+    double as_cost0 = 0.0; float refit_cost_ratio = 1.0f; uint32_t refits = 0, rebuilds = 0; float last_refit_ms = 0.f;
     ArtCamera camera{};
     uint32_t B = 1, read_b = 0;       // frames per launch of the fused frame (art_set_frames_per_launch); which of them the read / device-pointer calls refer to
     ArtCamera cam_more[kMaxBatch - 1] = {}; // cameras of frames 1.. of a launch (frame 0: camera)
@@ -221,6 +243,135 @@ int32_t ensure_wide(ArtContext *c, bool needed) {
 
 int32_t sync_all(ArtContext *c) {
     for (uint32_t k = 0; k < c->F; k++) HIPC(hipStreamSynchronize(c->stream_of(k)));
+    return ART_OK;
+}
+
+// ---- versions of the acceleration structure (moving models) ------------------------------------------------------------------------------
+struct AsPtrs { const DevTri *tris; const DevNodeW *widef; const DevNode4 *wide; const DevPrim *prims; };
+AsPtrs as_ptrs(const ArtContext *c, uint32_t v) {
+    if (c->as.empty()) return AsPtrs{c->bvh.tris, c->bvh.widef, c->bvh.wide, c->d_prims.p};
+    const AsVersion &V = c->as[v];
+    return AsPtrs{V.tris, V.widef, V.wide, V.prims};
+}
+uint64_t as_epoch_of(const ArtContext *c, uint32_t v) { return c->as.empty() ? 0 : c->as[v].epoch; }
+// everything that reads them has finished (the caller synchronised)
+void as_release(ArtContext *c) {
+    for (AsVersion &V : c->as) {
+        if (V.owned) { (void)hipFree(V.tris); (void)hipFree(V.widef); (void)hipFree(V.wide); (void)hipFree(V.prims); }
+        if (V.h_prims) (void)hipHostFree(V.h_prims);
+        if (V.h_cost) (void)hipHostFree(V.h_cost);
+        (void)hipFree(V.d_cost);
+        for (hipEvent_t e : {V.ready, V.t0, V.t1, V.cost_ev}) if (e) (void)hipEventDestroy(e);
+    }
+    c->as.clear(); c->as_cur = 0;
+}
+// the first move of a built scene: the ring of versions (ArtTuning.as_versions, default 3 like the reference's frames in flight, renderer.rs:135), every one a copy of
+// the build's arrays -- the topology (child references, valid masks, sort axes) is never written again -- and the cost of the tree as built
+int32_t as_create(ArtContext *c) {
+    int32_t r = ensure_wide(c, true); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    const uint32_t K = c->tuning.as_versions ? std::min(c->tuning.as_versions, kMaxAsVersions) : 3u;
+    const size_t np = c->h_dev_prims.size(), T = c->T, NW = c->bvh.n_wide;
+    c->as.assign(K, AsVersion{});
+    auto body = [&]() -> int32_t {
+        for (uint32_t v = 0; v < K; v++) {
+            AsVersion &V = c->as[v];
+            if (v == 0) { V.tris = c->bvh.tris; V.widef = c->bvh.widef; V.wide = c->bvh.wide; V.prims = c->d_prims.p; }
+            else {
+                V.owned = true;
+                HIPC(hipMalloc(&V.tris, T * sizeof(DevTri))); HIPC(hipMalloc(&V.widef, NW * sizeof(DevNodeW))); HIPC(hipMalloc(&V.wide, NW * sizeof(DevNode4))); HIPC(hipMalloc(&V.prims, np * sizeof(DevPrim)));
+                HIPC(hipMemcpy(V.tris, c->bvh.tris, T * sizeof(DevTri), hipMemcpyDeviceToDevice)); HIPC(hipMemcpy(V.widef, c->bvh.widef, NW * sizeof(DevNodeW), hipMemcpyDeviceToDevice));
+                HIPC(hipMemcpy(V.wide, c->bvh.wide, NW * sizeof(DevNode4), hipMemcpyDeviceToDevice)); HIPC(hipMemcpy(V.prims, c->d_prims.p, np * sizeof(DevPrim), hipMemcpyDeviceToDevice));
+            }
+            HIPC(hipHostMalloc((void **)&V.h_prims, np * sizeof(DevPrim), hipHostMallocDefault)); HIPC(hipHostMalloc((void **)&V.h_cost, 16, hipHostMallocDefault)); HIPC(hipMalloc(&V.d_cost, 16));
+            HIPC(hipEventCreateWithFlags(&V.ready, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&V.cost_ev, hipEventDisableTiming));
+            HIPC(hipEventCreate(&V.t0)); HIPC(hipEventCreate(&V.t1));
+        }
+        AsVersion &V0 = c->as[0];
+        launch_wide_cost(c->bvh.n_wide, V0.widef, V0.d_cost, c->main_stream());
+        HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(c->main_stream()));
+        double h[2] = {0, 0};
+        HIPC(hipMemcpy(h, V0.d_cost, 16, hipMemcpyDeviceToHost));
+        c->as_cost0 = h[1] > 0.0 ? h[0] / h[1] : 0.0; c->refit_cost_ratio = 1.0f;
+        HIPC(hipDeviceSynchronize()); // (the copies above ran on the null stream; the frame streams are non-blocking)
+        return ART_OK;
+    };
+    r = body();
+    if (r) as_release(c);
+    return r;
+}
+// the surface-area cost of the latest refit travels to the host behind it; once it has arrived it is what ArtStats.refit_cost_ratio and the rebuild rule go by
+void harvest_cost(ArtContext *c) {
+    if (c->as.empty()) return;
+    AsVersion &L = c->as[c->as_cur];
+    if (!L.cost_pending || hipEventQuery(L.cost_ev) != hipSuccess) return;
+    L.cost_pending = false;
+    if (L.h_cost[1] > 0.0 && c->as_cost0 > 0.0) c->refit_cost_ratio = (float)((L.h_cost[0] / L.h_cost[1]) / c->as_cost0);
+}
+// A model moved since the last launch: bring the NEXT version of the structure up to date on stream s, the stream of ring slot k whose frame is about to be
+// launched -- the frame is ordered behind the refit by the stream, frames on other streams by V.ready (art_trace).  Frames still reading the version about to be
+// written are waited for on the host, like the reference's per-frame fence (renderer.rs:451-466).
+int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
+    if (!c->xform_dirty) return ART_OK;
+    int32_t r;
+    if (c->as.empty()) { r = as_create(c); if (r) return r; }
+    {   // the cost of the latest refit, if it has arrived: past the threshold the tree is built again for where the models are now
+        harvest_cost(c);
+        const float thr = c->tuning.refit_rebuild_ratio > 0.0f ? c->tuning.refit_rebuild_ratio : (c->tuning.refit_rebuild_ratio < 0.0f ? INFINITY : 2.0f);
+        if (c->refit_cost_ratio > thr) {
+            if (g_build_log & 1u) std::fprintf(stderr, "[art] refit cost %.2f x the build's: building again\n", c->refit_cost_ratio);
+            r = art_scene_build(c); // (synchronises, uploads the primitives with their current matrices, drops the versions)
+            if (r == ART_OK) c->rebuilds++;
+            return r;
+        }
+    }
+    const uint32_t K = (uint32_t)c->as.size(), next = (c->as_cur + 1) % K;
+    AsVersion &V = c->as[next];
+    for (uint32_t j = 0; j < c->F; j++) {
+        if (j != k) { // (ring slot k's earlier work is ordered before the refit by its stream)
+            if (V.aux[j]) HIPC(hipStreamSynchronize(c->stream_of(j)));
+            else if (V.used[j]) {
+                const uint64_t f = V.used[j] - 1;
+                if (c->frame_no - f <= (uint64_t)ArtContext::kRing) HIPC(hipEventSynchronize(c->ev[f % ArtContext::kRing][4])); else HIPC(hipStreamSynchronize(c->stream_of(j)));
+            }
+        }
+        V.used[j] = 0; V.aux[j] = false;
+    }
+    if (V.cost_pending) { HIPC(hipEventSynchronize(V.cost_ev)); V.cost_pending = false; }
+    if (c->graph_mode) drop_graphs(c); // a captured frame holds the old version's pointers
+    const size_t np = c->h_dev_prims.size();
+    std::memcpy(V.h_prims, c->h_dev_prims.data(), np * sizeof(DevPrim));
+    HIPC(hipEventRecord(V.t0, s));
+    HIPC(hipMemcpyAsync(V.prims, V.h_prims, np * sizeof(DevPrim), hipMemcpyHostToDevice, s));
+    launch_retri(c->T, c->bvh.shade_tris, V.prims, V.tris, s);
+    launch_wide_refit(c->bvh.wide_levels, V.tris, V.wide, V.widef, s);
+    HIPC(hipEventRecord(V.t1, s)); V.timed = true;
+    launch_wide_cost(c->bvh.n_wide, V.widef, V.d_cost, s);
+    HIPC(hipMemcpyAsync(V.h_cost, V.d_cost, 16, hipMemcpyDeviceToHost, s));
+    HIPC(hipEventRecord(V.cost_ev, s)); V.cost_pending = true;
+    HIPC(hipEventRecord(V.ready, s)); V.ready_known = false; V.ready_slot = k;
+    HIPC(hipGetLastError());
+    c->as_cur = next; V.epoch = ++c->as_epoch; c->xform_dirty = false; c->refits++;
+    return ART_OK;
+}
+// for the calls that read the structure outside a frame (queries, the parity surface): nothing in flight, the pending move applied
+int32_t refresh_now(ArtContext *c) {
+    int32_t r = sync_all(c); if (r) return r;
+    if (!c->xform_dirty) return ART_OK;
+    r = scene_refresh(c, 0, c->stream_of(0)); if (r) return r;
+    HIPC(hipStreamSynchronize(c->stream_of(0)));
+    if (!c->as.empty()) c->as[c->as_cur].ready_known = true;
+    return ART_OK;
+}
+// the binary trees and the 64-byte node records follow the versions on demand only (the non-default walks and the parity surface read them): they are
+// not versioned, so this waits for everything in flight
+int32_t ensure_binary(ArtContext *c, bool needed) {
+    if (!needed || c->binary_epoch == as_epoch_of(c, c->as_cur)) return ART_OK;
+    int32_t r = sync_all(c); if (r) return r;
+    hipError_t e = binary_refit(c->bvh, c->T, as_ptrs(c, c->as_cur).tris, c->main_stream());
+    if (e != hipSuccess) return hipfail(e, "binary_refit");
+    c->binary_epoch = as_epoch_of(c, c->as_cur);
+    drop_graphs(c);
     return ART_OK;
 }
 
@@ -556,6 +707,7 @@ int32_t art_destroy(ArtContext *c) {
     (void)hipSetDevice(c->device);
     for (uint32_t k = 0; k < c->F; k++) if (c->stream_of(k)) (void)hipStreamSynchronize(c->stream_of(k));
     drop_graphs(c);
+    as_release(c);
     lbvh_free(c->bvh);
     c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release(); c->d_ao_tab.release();
     c->d_tile_list.release(); c->d_tile_xy.release(); c->d_tile_slot.release(); c->d_block_order.release(); c->plan.release();
@@ -577,6 +729,7 @@ int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     auto walk_ok = [](uint32_t k) { return k == 0 || k == 2 || k == 4 || k == 8; };
     if (t->frame_form > 2 || t->tree_builder > 1 || (t->frame_waves != 0 && (t->frame_waves < 6 || t->frame_waves > 8)) || !walk_ok(t->primary_walk) || !walk_ok(t->shadow_walk) || !walk_ok(t->ao_walk))
         return fail(ART_E_INVALID, "art_set_tuning: frame_form 0..2, tree_builder 0..1, frame_waves 0|6|7|8, walks 0|2|4|8");
+    if (t->as_versions > kMaxAsVersions || !(t->refit_rebuild_ratio == t->refit_rebuild_ratio)) return fail(ART_E_INVALID, "art_set_tuning: as_versions 0..8, refit_rebuild_ratio a number");
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
     drop_graphs(c);
@@ -615,6 +768,7 @@ int32_t art_scene_add_primitive(ArtContext *c, const ArtVertex *verts, uint32_t 
     if (n_indices == 0 || n_indices % 3 != 0) return fail(ART_E_INVALID, "art_scene_add_primitive: index count must be a positive multiple of 3");
     if (n_verts == 0 || tw == 0 || th == 0) return fail(ART_E_INVALID, "art_scene_add_primitive: empty vertices or texture");
     if (idx_bytes == 2 && n_verts > 65536) return fail(ART_E_INVALID, "art_scene_add_primitive: u16 indices cannot address the vertex count");
+    for (int i = 0; i < 12; i++) if (!std::isfinite(model3x4[i])) return fail(ART_E_INVALID, "art_scene_add_primitive: non-finite model matrix");
     for (uint32_t i = 0; i < n_indices; i++) {
         uint32_t v = idx_bytes == 2 ? ((const uint16_t *)indices)[i] : ((const uint32_t *)indices)[i];
         if (v >= n_verts) return fail(ART_E_INVALID, "art_scene_add_primitive: index out of range");
@@ -646,11 +800,29 @@ int32_t art_scene_set_primitive_enabled(ArtContext *c, uint32_t id, int32_t enab
     return ART_OK;
 }
 
+int32_t art_scene_set_model_matrix(ArtContext *c, uint32_t first, uint32_t n, const float model3x4[12]) {
+    if (!c || !model3x4) return fail(ART_E_INVALID, "art_scene_set_model_matrix: null argument");
+    if (n == 0 || first >= c->prims.size() || n > c->prims.size() - first) return fail(ART_E_INVALID, "art_scene_set_model_matrix: no such primitives");
+    for (int i = 0; i < 12; i++) if (!std::isfinite(model3x4[i])) return fail(ART_E_INVALID, "art_scene_set_model_matrix: non-finite matrix");
+    float w2o[12];
+    affine_inverse(model3x4, w2o);
+    for (uint32_t id = first; id < first + n; id++) {
+        HostPrim &p = c->prims[id];
+        if (std::memcmp(p.o2w, model3x4, 48) == 0) continue;     // where it already is
+        std::memcpy(p.o2w, model3x4, 48); std::memcpy(p.w2o, w2o, 48);
+        if (!c->built || id >= c->h_dev_prims.size()) continue;  // takes effect with the build
+        std::memcpy(c->h_dev_prims[id].o2w, model3x4, 48); std::memcpy(c->h_dev_prims[id].w2o, w2o, 48);
+        if (p.enabled) c->xform_dirty = true;                    // instanced: the next art_trace (or query) refits first
+    }
+    return ART_OK;
+}
+
 int32_t art_scene_build(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "art_scene_build: null context");
     if (c->prims.empty()) return fail(ART_E_STATE, "art_scene_build: no primitives");
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
+    as_release(c); c->xform_dirty = false; c->as_epoch = 0; c->binary_epoch = 0; c->refit_cost_ratio = 1.0f; // the versions were copies of the tree that goes away
     lbvh_free(c->bvh); c->built = false; drop_graphs(c);
     // Only enabled primitives are uploaded and instanced (get_acceleration_structure_instance returns None unless the model is in
     // the Device state, vk_model.rs:360-372).  Ids keep their meaning: a disabled primitive stays in the table with zero triangles.
@@ -696,6 +868,7 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(c->d_first_tri.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
     c->h_first_tri = first;
+    c->h_dev_prims = dp;
     c->T = T;
     BuildInputs in{c->d_prims.p, (uint32_t)dp.size(), c->d_first_tri.p, T, c->cfg.morton_bits};
     hipEvent_t e0, e1;
@@ -846,12 +1019,13 @@ int32_t art_resize(ArtContext *c, uint32_t w, uint32_t h) {
     return ART_OK;
 }
 
-static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S) {
+static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S, uint32_t version) {
     FrameArgs a{};
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p; a.fold_counters = c->kind_primary == 8 && c->kind_shadow == 8 && c->n_local != 0;
-    a.nodes = c->bvh.nodes; a.wide = c->bvh.wide; a.widef = c->bvh.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = c->bvh.tris; a.shade_tris = c->bvh.shade_tris; a.prims = c->d_prims.p; a.tex_pool = c->d_tex.p;
+    const AsPtrs as = as_ptrs(c, version); // the version of the acceleration structure this launch reads
+    a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
     a.n_lights = (uint32_t)c->lights.size();
     if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
     for (uint32_t i = 0; i < a.n_lights; i++) directional_constants(a.lights[i]);
@@ -873,13 +1047,25 @@ int32_t art_trace(ArtContext *c) {
     if (c->W == 0 || c->H == 0) return fail(ART_E_STATE, "art_trace: zero extent (art_resize)");
     int32_t r = use_device(c); if (r) return r;
     if (!c->frame_ready) { r = sync_all(c); if (r) return r; r = setup_frame(c); if (r) return r; }
-    r = ensure_wide(c, c->kind_primary == 4 || c->kind_shadow == 4 || c->packet_wide); if (r) return r;
     const uint32_t k = (uint32_t)(c->frame_no % c->F);
     FrameSlot &S = c->slot[k];
     hipStream_t s = c->stream_of(k);
     if (S.wait_event) { HIPC(hipStreamWaitEvent(s, (hipEvent_t)S.wait_event, 0)); S.wait_event = nullptr; }
+    if (c->xform_dirty) { r = scene_refresh(c, k, s); if (r) return r; } // a model moved: the refit this frame is ordered behind (past the cost threshold: a rebuild)
+    r = ensure_wide(c, c->kind_primary == 4 || c->kind_shadow == 4 || c->packet_wide); if (r) return r;
+    r = ensure_binary(c, !c->packet_wide || c->kind_primary == 2 || c->kind_shadow == 2); if (r) return r;
     if (c->plan.enabled) { r = plan_poll(c); if (r) return r; }
-    FrameArgs a = make_frame_args(c, S);
+    const uint32_t ver = c->as_cur;
+    if (!c->as.empty()) {
+        AsVersion &V = c->as[ver];
+        if (!V.ready_known) { // the refit that wrote this version may still run on another ring slot's stream
+            if (hipEventQuery(V.ready) == hipSuccess) V.ready_known = true;
+            else if (V.ready_slot != k) HIPC(hipStreamWaitEvent(s, V.ready, 0));
+        }
+        V.used[k] = c->frame_no + 1; V.aux[k] = false;
+    }
+    S.as_version = ver;
+    FrameArgs a = make_frame_args(c, S, ver);
     if (c->tiled()) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
     if (c->B > 1 && (!fused || c->frame_waves < 8)) return fail(ART_E_STATE, "art_trace: several frames per launch need the default fused frame");
@@ -972,7 +1158,9 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     }
     uint32_t lut[65] = {0};
     for (uint32_t k = 0; k <= spp; k++) lut[k] = (uint32_t)(std::pow(1.0 - (double)k / (double)spp, 2.2) * 255.0 + 0.5); // XE_GTAO_DEFAULT_FINAL_VALUE_POWER (vk_xe_gtao.rs:22)
-    FrameArgs a = make_frame_args(c, S);
+    r = ensure_binary(c, c->kind_ao == 2 || (c->kind_ao == 8 && !c->packet_wide)); if (r) return r;
+    FrameArgs a = make_frame_args(c, S, S.as_version); // the structure the frame itself was traced in
+    if (!c->as.empty()) c->as[S.as_version].aux[c->last] = true;
     HIPC(hipMemsetAsync(S.d_counters.p + 64 + 16 * 32, 0, 8 * 32 * 4, s)); // the AO launch's work cursors
     HIPC(hipEventRecord(S.ao_ev[0], s));
     if (a.n_local) launch_ao(a, spp, radius, S.d_occl.p, S.d_ao_pix.p, c->d_ao_tab.p, c->ao_entry, S.d_ao.p, lut, s);
@@ -1251,7 +1439,7 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
             FrameSlot &S = c->slot[c->last];
             HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, c->stream_of(c->last)));
             if (c->n_local) { // of the frame the read calls refer to
-                FrameArgs fa = make_frame_args(c, S);
+                FrameArgs fa = make_frame_args(c, S, S.as_version);
                 fa.pix_bits += (size_t)c->read_b * c->n_local; fa.depth += (size_t)c->read_b * c->W * c->H;
                 launch_frame_stats(fa, S.d_counters.p, c->stream_of(c->last)); HIPC(hipGetLastError());
             }
@@ -1270,6 +1458,8 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         c->stats.frame_launches = (c->fused && c->kind_primary == 8 && c->kind_shadow == 8) ? 1u : 4u;
         c->stats.split_blocks = 0;
         for (uint8_t lv : c->plan.level) c->stats.split_blocks += lv != 0;
+        harvest_cost(c);
+        if (!c->as.empty() && c->as[c->as_cur].timed) { float rms = 0; if (hipEventElapsedTime(&rms, c->as[c->as_cur].t0, c->as[c->as_cur].t1) == hipSuccess) c->last_refit_ms = rms; }
         c->stats.ao_rays = (uint64_t)c->ao_spp * cnt[1];
         if (c->ao_spp) { float ams = 0; if (hipEventElapsedTime(&ams, c->slot[c->last].ao_ev[0], c->slot[c->last].ao_ev[1]) == hipSuccess) c->stats.ao_ms = ams; }
         float ms = 0;
@@ -1285,6 +1475,7 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
             }
         }
     }
+    c->stats.refit_ms = c->last_refit_ms; c->stats.refit_cost_ratio = c->refit_cost_ratio; c->stats.refits = c->refits; c->stats.rebuilds = c->rebuilds;
     *out = c->stats;
     return ART_OK;
 }
@@ -1346,10 +1537,11 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     std::vector<float4> h(n);
     std::vector<DevTri> tris(c->T);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && (sync_all(c) != ART_OK || ensure_wide(c, true) != ART_OK)) e = hipErrorUnknown;
+    const int qkind = c->kind_primary == 8 ? 2 : c->kind_primary;
+    if (e == hipSuccess && (refresh_now(c) != ART_OK || ensure_wide(c, true) != ART_OK || ensure_binary(c, qkind == 2) != ART_OK)) e = hipErrorUnknown; // (a pending move is applied first)
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
-    if (e == hipSuccess) { launch_query_closest(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.tris, c->kind_primary == 8 ? 2 : c->kind_primary}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) { const AsPtrs as = as_ptrs(c, c->as_cur); launch_query_closest(BvhView{c->bvh.nodes, as.wide, as.tris, qkind}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);
@@ -1375,10 +1567,11 @@ int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit
     if (e != hipSuccess) { (void)hipFree(d_r); return hipfail(e, "hipMalloc"); }
     std::vector<uint32_t> h(n);
     e = hipMemcpy(d_r, rays, (size_t)n * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess && (sync_all(c) != ART_OK || ensure_wide(c, true) != ART_OK)) e = hipErrorUnknown;
+    const int qkind = c->kind_shadow == 8 ? 4 : c->kind_shadow;
+    if (e == hipSuccess && (refresh_now(c) != ART_OK || ensure_wide(c, true) != ART_OK || ensure_binary(c, qkind == 2) != ART_OK)) e = hipErrorUnknown;
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
-    if (e == hipSuccess) { launch_query_any(BvhView{c->bvh.nodes, c->bvh.wide, c->bvh.tris, c->kind_shadow == 8 ? 4 : c->kind_shadow}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) { const AsPtrs as = as_ptrs(c, c->as_cur); launch_query_any(BvhView{c->bvh.nodes, as.wide, as.tris, qkind}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_r); (void)hipFree(d_h);
@@ -1391,7 +1584,8 @@ int32_t art_get_lbvh(ArtContext *c, uint32_t *leaf_gid, uint64_t *keys, int32_t 
     if (!c) return fail(ART_E_INVALID, "art_get_lbvh: null context");
     if (!c->built) return fail(ART_E_STATE, "art_get_lbvh: scene not built");
     int32_t r = use_device(c); if (r) return r;
-    r = sync_all(c); if (r) return r;
+    r = refresh_now(c); if (r) return r;       // after a move: the boxes of where the models are now (the keys and the topology are the build's)
+    r = ensure_binary(c, true); if (r) return r;
     size_t T = c->T, NI = T > 1 ? T - 1 : 0;
     if (leaf_gid) HIPC(hipMemcpy(leaf_gid, c->bvh.leaf_gid, T * 4, hipMemcpyDeviceToHost));
     if (keys) HIPC(hipMemcpy(keys, c->bvh.keys, T * 8, hipMemcpyDeviceToHost));
@@ -1408,7 +1602,8 @@ int32_t art_get_traversal_tree(ArtContext *c, int32_t *child, float *node_lo, fl
     if (!c) return fail(ART_E_INVALID, "art_get_traversal_tree: null context");
     if (!c->built) return fail(ART_E_STATE, "art_get_traversal_tree: scene not built");
     int32_t r = use_device(c); if (r) return r;
-    r = sync_all(c); if (r) return r;
+    r = refresh_now(c); if (r) return r;
+    r = ensure_binary(c, true); if (r) return r;
     size_t T = c->T, NI = T > 1 ? T - 1 : 0;
     const bool sah = c->bvh.trav_child != nullptr;
     if (child && NI) HIPC(hipMemcpy(child, sah ? c->bvh.trav_child : c->bvh.child, NI * 8, hipMemcpyDeviceToHost));
@@ -1423,12 +1618,13 @@ int32_t art_get_wide_nodes(ArtContext *c, void *quantised, void *floats, size_t 
     if (!c || !n_nodes) return fail(ART_E_INVALID, "art_get_wide_nodes: null argument");
     if (!c->built) return fail(ART_E_STATE, "art_get_wide_nodes: scene not built");
     int32_t r = use_device(c); if (r) return r;
-    r = sync_all(c); if (r) return r;
+    r = refresh_now(c); if (r) return r;
     r = ensure_wide(c, true); if (r) return r;
     *n_nodes = c->bvh.n_wide;
     if ((quantised || floats) && capacity_nodes < c->bvh.n_wide) return fail(ART_E_INVALID, "art_get_wide_nodes: buffers too small");
-    if (quantised) HIPC(hipMemcpy(quantised, c->bvh.wide, (size_t)c->bvh.n_wide * sizeof(DevNode4), hipMemcpyDeviceToHost));
-    if (floats) HIPC(hipMemcpy(floats, c->bvh.widef, (size_t)c->bvh.n_wide * sizeof(DevNodeW), hipMemcpyDeviceToHost));
+    const AsPtrs as = as_ptrs(c, c->as_cur);   // the version the next frame would read
+    if (quantised) HIPC(hipMemcpy(quantised, as.wide, (size_t)c->bvh.n_wide * sizeof(DevNode4), hipMemcpyDeviceToHost));
+    if (floats) HIPC(hipMemcpy(floats, as.widef, (size_t)c->bvh.n_wide * sizeof(DevNodeW), hipMemcpyDeviceToHost));
     return ART_OK;
 }
 

@@ -253,7 +253,9 @@ static hipError_t wide_build_host(Lbvh &l, uint32_t T, hipStream_t s) {
     wide.reserve(NI / 2 + 2);
     if (NI == 0) todo.push_back(~0); // single triangle: a root with one leaf child
     else todo.push_back(0);
+    std::vector<uint32_t> levels; size_t level_end = 0; // breadth-first: the nodes of a level are contiguous
     for (size_t w = 0; w < todo.size(); w++) {
+        if (w == level_end) { levels.push_back((uint32_t)w); level_end = todo.size(); }
         int32_t cand[4]; int nc = 0;
         if (todo[w] < 0) { cand[nc++] = todo[w]; }
         else {
@@ -322,6 +324,7 @@ static hipError_t wide_build_host(Lbvh &l, uint32_t T, hipStream_t s) {
         widef.push_back(dw);
     }
     l.n_wide = (uint32_t)wide.size();
+    levels.push_back(l.n_wide); l.wide_levels = levels;
     HIPQ(hipMalloc(&l.wide, wide.size() * sizeof(DevNode4)));
     HIPQ(hipMemcpy(l.wide, wide.data(), wide.size() * sizeof(DevNode4), hipMemcpyHostToDevice));
     HIPQ(hipMalloc(&l.widef, widef.size() * sizeof(DevNodeW)));
@@ -375,6 +378,37 @@ __global__ __launch_bounds__(256) void k_wide_expand(WideIn in, const int32_t *_
     meta[w] = (uint32_t)nc | (sort_axis << 8);
     n_internal[w] = ni;
 }
+// The quantised record of a 4-wide node from its nc child boxes: origin = the boxes' common corner, one power-of-two scale per axis, 8-bit planes rounded
+// outwards so that origin + q * scale -- as the walks' fma evaluates it -- contains the float box.  Shared by the collapse and by the refit.
+__device__ inline void wide_quantise(const float *const lo[4], const float *const hi[4], int nc, DevNode4 &d) {
+    for (int k = 0; k < 6; k++) d.q[k] = 0;
+    d.spare[0] = d.spare[1] = 0;
+    float org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < nc; i++) for (int k = 0; k < 3; k++) { org[k] = fminf(org[k], lo[i][k]); top[k] = fmaxf(top[k], hi[i][k]); }
+    d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
+    uint32_t ebits[3]; float scale[3];
+    for (int k = 0; k < 3; k++) { // smallest power of two with 255 * scale >= extent (as evaluated by the tracer's fma), at least 2^-100
+        double ext = (double)top[k] - (double)org[k];
+        int e = ext > 0 ? ceil_log2(ext / 255.0) : -100;
+        if (e < -100) e = -100;
+        for (;;) { scale[k] = ldexpf(1.0f, e); if (fmaf(255.0f, scale[k], org[k]) >= top[k]) break; e++; }
+        ebits[k] = (uint32_t)(e + 127);
+    }
+    uint32_t mask = 0;
+    for (int i = 0; i < nc; i++) {
+        mask |= 1u << i;
+        for (int k = 0; k < 3; k++) {
+            int ql = (int)floor(((double)lo[i][k] - (double)org[k]) / (double)scale[k]);
+            int qh = (int)ceil(((double)hi[i][k] - (double)org[k]) / (double)scale[k]);
+            ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+            while (ql > 0 && fmaf((float)ql, scale[k], org[k]) > lo[i][k]) ql--;
+            while (qh < 255 && fmaf((float)qh, scale[k], org[k]) < hi[i][k]) qh++;
+            d.q[k] |= (uint32_t)ql << (8 * i);
+            d.q[3 + k] |= (uint32_t)qh << (8 * i);
+        }
+    }
+    d.exps = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (mask << 24);
+}
 // pass 2: the two node records of every wide node of the level; its internal children become the next level's wide nodes
 __global__ __launch_bounds__(256) void k_wide_emit(WideIn in, uint32_t n, uint32_t first /*wide index of this level's first node*/, const int32_t *__restrict__ cand_in,
                                                    const uint32_t *__restrict__ meta, const uint32_t *__restrict__ offs, DevNode4 *__restrict__ wide,
@@ -385,40 +419,19 @@ __global__ __launch_bounds__(256) void k_wide_emit(WideIn in, uint32_t n, uint32
     int32_t cand[4];
     for (int i = 0; i < 4; i++) cand[i] = cand_in[4 * (size_t)w + i];
     DevNode4 d; DevNodeW dw;
-    for (int k = 0; k < 6; k++) d.q[k] = 0;
-    d.spare[0] = d.spare[1] = 0; dw.pad[1] = dw.pad[2] = 0;
-    float org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = 0; i < nc; i++) { const float *lo, *hi; wide_box(in, cand[i], lo, hi); for (int k = 0; k < 3; k++) { org[k] = fminf(org[k], lo[k]); top[k] = fmaxf(top[k], hi[k]); } }
-    d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
-    uint32_t ebits[3]; float scale[3];
-    for (int k = 0; k < 3; k++) { // smallest power of two with 255 * scale >= extent (as evaluated by the tracer's fma), at least 2^-100
-        double ext = (double)top[k] - (double)org[k];
-        int e = ext > 0 ? ceil_log2(ext / 255.0) : -100;
-        if (e < -100) e = -100;
-        for (;;) { scale[k] = ldexpf(1.0f, e); if (fmaf(255.0f, scale[k], org[k]) >= top[k]) break; e++; }
-        ebits[k] = (uint32_t)(e + 127);
-    }
-    uint32_t mask = 0, next = first + n + offs[w]; // this node's internal children follow those of the nodes before it
+    dw.pad[1] = dw.pad[2] = 0;
+    const float *lo[4] = {nullptr, nullptr, nullptr, nullptr}, *hi[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < nc; i++) wide_box(in, cand[i], lo[i], hi[i]);
+    wide_quantise(lo, hi, nc, d);
+    uint32_t next = first + n + offs[w]; // this node's internal children follow those of the nodes before it
     for (int i = 0; i < 4; i++) {
         if (i >= nc) { d.child[i] = kAbsentChild; dw.child[i] = kAbsentChild; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; }
-        mask |= 1u << i;
-        const float *lo, *hi; wide_box(in, cand[i], lo, hi);
-        for (int k = 0; k < 3; k++) {
-            int ql = (int)floor(((double)lo[k] - (double)org[k]) / (double)scale[k]);
-            int qh = (int)ceil(((double)hi[k] - (double)org[k]) / (double)scale[k]);
-            ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
-            while (ql > 0 && fmaf((float)ql, scale[k], org[k]) > lo[k]) ql--;
-            while (qh < 255 && fmaf((float)qh, scale[k], org[k]) < hi[k]) qh++;
-            d.q[k] |= (uint32_t)ql << (8 * i);
-            d.q[3 + k] |= (uint32_t)qh << (8 * i);
-            dw.box[i][k] = lo[k]; dw.box[i][3 + k] = hi[k];
-        }
+        for (int k = 0; k < 3; k++) { dw.box[i][k] = lo[i][k]; dw.box[i][3 + k] = hi[i][k]; }
         if (cand[i] < 0) d.child[i] = cand[i];
         else { d.child[i] = (int32_t)next; next_front[next - (first + n)] = cand[i]; next++; }
         dw.child[i] = d.child[i];
     }
-    d.exps = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16) | (mask << 24);
-    dw.valid = mask; dw.pad[0] = sort_axis;
+    dw.valid = d.exps >> 24; dw.pad[0] = sort_axis;
     wide[first + w] = d;
     widef[first + w] = dw;
 }
@@ -431,6 +444,7 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
     WideIn in{l.trav_child ? l.trav_child : l.child, l.trav_child ? l.trav_lo : l.node_lo, l.trav_child ? l.trav_hi : l.node_hi, l.leaf_lo, l.leaf_hi};
     int32_t *front[2] = {nullptr, nullptr}, *cand = nullptr; uint32_t *meta = nullptr, *cnt = nullptr, *offs = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
     DevNode4 *wide = nullptr; DevNodeW *widef = nullptr;
+    std::vector<uint32_t> levels; // first node of every level (breadth-first numbering: a level is contiguous), then n_wide
     auto body = [&]() -> hipError_t {
         HIPQ(hipMalloc(&front[0], (size_t)cap * 4)); HIPQ(hipMalloc(&front[1], (size_t)cap * 4)); HIPQ(hipMalloc(&cand, (size_t)cap * 16));
         HIPQ(hipMalloc(&meta, (size_t)cap * 4)); HIPQ(hipMalloc(&cnt, ((size_t)cap + 1) * 4)); HIPQ(hipMalloc(&offs, ((size_t)cap + 1) * 4));
@@ -451,10 +465,12 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
             uint32_t n_next = 0;
             HIPQ(hipMemcpyAsync(&n_next, offs + n, 4, hipMemcpyDeviceToHost, s));
             HIPQ(hipStreamSynchronize(s));
+            levels.push_back(first);
             first += n; n = n_next; cur ^= 1;
         }
         HIPQ(hipGetLastError());
         l.n_wide = first;
+        levels.push_back(first); l.wide_levels = levels;
         return hipSuccess;
     };
     hipError_t e = body();
@@ -468,6 +484,152 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
         if (e != hipSuccess) { hipFree(l.wide); hipFree(l.widef); l.wide = nullptr; l.widef = nullptr; l.n_wide = 0; }
     }
     hipFree(wide); hipFree(widef);
+    return e;
+}
+
+// ---- refit: a model moved (VkModel::set_model_matrix, vk_model.rs:461-466; the reference rebuilds its TLAS every frame for this, renderer.rs:637-651) ------
+// The topology stays, the world-space triangles of the version and every box above them are made again.  Results cannot depend on it: accept() is per
+// triangle and every node box is an exact min / max union of the triangle boxes below it -- the frames are those of a fresh build.
+
+// the version's triangle records from the object-space shading records (the vertices k_leaves gathered) and the version's object->world matrices: the very
+// operations of k_soup (transform) and k_leaves (edges, box), so a refit with unchanged matrices writes the bits that are there
+__global__ __launch_bounds__(256) void k_retri(uint32_t T, const DevShadeTri *__restrict__ shade, const DevPrim *__restrict__ prims, DevTri *__restrict__ tris) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= T) return;
+    const float4 *sq = reinterpret_cast<const float4 *>(shade + p);
+    const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s8 = sq[8];
+    const float *m = prims[__float_as_uint(s8.z)].o2w;
+    const float3 w0 = xform_point(m, s0.x, s0.y, s0.z), w1 = xform_point(m, s0.w, s1.x, s1.y), w2 = xform_point(m, s1.z, s1.w, s2.x);
+    const float a[3] = {w0.x, w0.y, w0.z}, b[3] = {w1.x, w1.y, w1.z}, c[3] = {w2.x, w2.y, w2.z};
+    DevTri t;
+    for (int k = 0; k < 3; k++) {
+        t.f[k] = a[k]; t.f[3 + k] = b[k] - a[k]; t.f[6 + k] = c[k] - a[k];
+        t.f[9 + k] = fminf(fminf(a[k], b[k]), c[k]); t.f[12 + k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+    }
+    t.f[15] = tris[p].f[15]; // the global triangle id never changes
+    tris[p] = t;
+}
+
+// one node of the 4-wide tree from its children: a leaf child's box is its triangle's, an internal child's the union of that node's own child boxes
+__device__ __forceinline__ void wide_refit_node(uint32_t w, const DevTri *__restrict__ tris, DevNode4 *wide, DevNodeW *widef) {
+    DevNodeW dw = widef[w];
+    const int nc = __popc(dw.valid & 15u); // the valid children are slots 0 .. nc-1
+    float lo[4][3], hi[4][3];
+    for (int i = 0; i < 4; i++) {
+        if (i >= nc) continue;
+        const int32_t ch = dw.child[i];
+        if (ch < 0) { const DevTri &t = tris[~ch]; for (int k = 0; k < 3; k++) { lo[i][k] = t.f[9 + k]; hi[i][k] = t.f[12 + k]; } }
+        else {
+            const DevNodeW &cw = widef[ch];
+            const uint32_t cv = cw.valid;
+            for (int k = 0; k < 3; k++) { lo[i][k] = INFINITY; hi[i][k] = -INFINITY; }
+            for (int j = 0; j < 4; j++) if ((cv >> j) & 1u) for (int k = 0; k < 3; k++) { lo[i][k] = fminf(lo[i][k], cw.box[j][k]); hi[i][k] = fmaxf(hi[i][k], cw.box[j][3 + k]); }
+        }
+        for (int k = 0; k < 3; k++) { dw.box[i][k] = lo[i][k]; dw.box[i][3 + k] = hi[i][k]; }
+    }
+    const float *plo[4] = {lo[0], lo[1], lo[2], lo[3]}, *phi[4] = {hi[0], hi[1], hi[2], hi[3]};
+    DevNode4 d;
+    wide_quantise(plo, phi, nc, d);
+    for (int i = 0; i < 4; i++) d.child[i] = dw.child[i];
+    widef[w] = dw;
+    wide[w] = d;
+}
+__global__ __launch_bounds__(256) void k_wide_refit(uint32_t first, uint32_t n, const DevTri *__restrict__ tris, DevNode4 *wide, DevNodeW *widef) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wide_refit_node(first + i, tris, wide, widef);
+}
+// the top of the tree: levels of at most 1024 nodes each, bottom-up in ONE workgroup (a launch per level would cost more than the levels)
+constexpr int kTopLevels = 16;
+struct TopLevels { uint32_t first[kTopLevels + 1]; int n; }; // level i = nodes [first[i], first[i + 1])
+__global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevTri *__restrict__ tris, DevNode4 *wide, DevNodeW *widef) {
+    for (int lv = L.n - 1; lv >= 0; lv--) {
+        const uint32_t n = L.first[lv + 1] - L.first[lv];
+        if (threadIdx.x < n) wide_refit_node(L.first[lv] + threadIdx.x, tris, wide, widef);
+        __threadfence_block();
+        __syncthreads(); // the level above reads these records
+    }
+}
+// Surface-area cost of the 4-wide tree: cost[0] += sum over all nodes of the half-areas of their child boxes, cost[1] = half-area of the root's union --
+// cost[0] / cost[1] is the expected number of child boxes a random ray through the scene crosses, what a refit can degrade and a rebuild restores.
+__global__ __launch_bounds__(256) void k_wide_cost(uint32_t n_wide, const DevNodeW *__restrict__ widef, double *cost) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    double a = 0.0;
+    if (w < n_wide) {
+        const DevNodeW &d = widef[w];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int j = 0; j < 4; j++) if ((d.valid >> j) & 1u) {
+            double dx = (double)d.box[j][3] - d.box[j][0], dy = (double)d.box[j][4] - d.box[j][1], dz = (double)d.box[j][5] - d.box[j][2];
+            a += dx * dy + dy * dz + dz * dx;
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], d.box[j][k]); hi[k] = fmaxf(hi[k], d.box[j][3 + k]); }
+        }
+        if (w == 0) { double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2]; cost[1] = dx * dy + dy * dz + dz * dx; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+    if ((threadIdx.x & 63u) == 0 && a != 0.0) atomicAdd(&cost[0], a);
+}
+
+void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, DevTri *tris, hipStream_t s) {
+    k_retri<<<(T + 255) / 256, 256, 0, s>>>(T, shade, prims, tris);
+}
+void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, hipStream_t s) {
+    const int n_levels = (int)levels.size() - 1;
+    if (n_levels <= 0) return;
+    int top = 0; // levels [0, top) go into the one-workgroup launch
+    while (top < n_levels && top < kTopLevels && levels[top + 1] - levels[top] <= 1024u) top++;
+    for (int lv = n_levels - 1; lv >= top; lv--) {
+        const uint32_t n = levels[lv + 1] - levels[lv];
+        k_wide_refit<<<(n + 255) / 256, 256, 0, s>>>(levels[lv], n, tris, wide, widef);
+    }
+    if (top) {
+        TopLevels L{}; L.n = top;
+        for (int i = 0; i <= top; i++) L.first[i] = levels[i];
+        k_wide_refit_top<<<1, 1024, 0, s>>>(L, tris, wide, widef);
+    }
+}
+void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, double *cost, hipStream_t s) {
+    (void)hipMemsetAsync(cost, 0, 16, s);
+    k_wide_cost<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, cost);
+}
+
+// The binary trees (the canonical LBVH of art_get_lbvh, the traversal tree of the per-ray / binary walks) after a refit: leaf boxes from the triangle records,
+// node boxes bottom-up with the build's own kernel, the 64-byte node records again.  Only the non-default forms and the parity surface read them, so this runs
+// on demand and under full synchronisation (art_api.hip).
+__global__ __launch_bounds__(256) void k_leaf_boxes(uint32_t T, const DevTri *__restrict__ tris, float *__restrict__ leaf_lo, float *__restrict__ leaf_hi) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= T) return;
+    for (int k = 0; k < 3; k++) { leaf_lo[3 * (size_t)p + k] = tris[p].f[9 + k]; leaf_hi[3 * (size_t)p + k] = tris[p].f[12 + k]; }
+}
+__global__ __launch_bounds__(256) void k_parents(uint32_t NI, const int32_t *__restrict__ child, int32_t *__restrict__ parent_int, int32_t *__restrict__ parent_leaf) {
+    uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= NI) return;
+    if (n == 0) parent_int[0] = -1;
+    for (int c = 0; c < 2; c++) { int32_t ch = child[2 * (size_t)n + c]; if (ch < 0) parent_leaf[~ch] = (int32_t)n; else parent_int[ch] = (int32_t)n; }
+}
+hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s) {
+    const uint32_t NI = T > 1 ? T - 1 : 0, B = 256, GT = (T + B - 1) / B;
+    k_leaf_boxes<<<GT, B, 0, s>>>(T, tris, l.leaf_lo, l.leaf_hi);
+    int32_t *parent_int = nullptr, *parent_leaf = nullptr; uint32_t *arrive = nullptr;
+    auto body = [&]() -> hipError_t {
+        if (NI) {
+            HIPQ(hipMalloc(&parent_int, (size_t)NI * 4)); HIPQ(hipMalloc(&parent_leaf, (size_t)T * 4)); HIPQ(hipMalloc(&arrive, (size_t)NI * 4));
+            for (int tree = 0; tree < 2; tree++) {
+                const int32_t *child = tree == 0 ? l.child : l.trav_child;
+                float *nlo = tree == 0 ? l.node_lo : l.trav_lo, *nhi = tree == 0 ? l.node_hi : l.trav_hi;
+                if (!child) continue;
+                HIPQ(hipMemsetAsync(arrive, 0, (size_t)NI * 4, s));
+                k_parents<<<(NI + B - 1) / B, B, 0, s>>>(NI, child, parent_int, parent_leaf);
+                k_refit<<<GT, B, 0, s>>>(T, child, parent_int, parent_leaf, l.leaf_lo, l.leaf_hi, nlo, nhi, arrive);
+            }
+        }
+        const uint32_t NN = NI ? NI : 1;
+        if (l.trav_child) k_emit_nodes<<<(NN + B - 1) / B, B, 0, s>>>(T, l.trav_child, l.trav_lo, l.trav_hi, l.leaf_lo, l.leaf_hi, l.nodes);
+        else k_emit_nodes<<<(NN + B - 1) / B, B, 0, s>>>(T, l.child, l.node_lo, l.node_hi, l.leaf_lo, l.leaf_hi, l.nodes);
+        HIPQ(hipGetLastError());
+        HIPQ(hipStreamSynchronize(s));
+        return hipSuccess;
+    };
+    hipError_t e = body();
+    hipFree(parent_int); hipFree(parent_leaf); hipFree(arrive);
     return e;
 }
 

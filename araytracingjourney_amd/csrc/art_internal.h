@@ -83,6 +83,7 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevNode4 *wide;         // [n_wide] collapsed + quantised traversal structure
     DevNodeW *widef;        // [n_wide] the same topology with float boxes (packet walk)
     uint32_t n_wide;
+    std::vector<uint32_t> wide_levels; // host: first wide node of every level of the collapse (breadth-first numbering), then n_wide -- the refit goes through them bottom-up
     DevShadeTri *shade_tris; // [T] leaf order
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
@@ -99,6 +100,13 @@ hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out);
 // the binned SAH of sah_build, level by level on the device (art_sahdev.hip)
 hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s);
 void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s);
+// refit after a model moved (art_build.hip): the triangle records of a version of the acceleration structure from the shading records and that version's
+// primitive table; its 4-wide nodes bottom-up, level by level (l.wide_levels); the tree's surface-area cost (2 doubles: sum of child half-areas, root half-area);
+// the binary trees and node records from a version's triangles (on demand, synchronises)
+void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, DevTri *tris, hipStream_t s);
+void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, hipStream_t s);
+void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, double *cost, hipStream_t s);
+hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s);
 void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks); // art_trace.hip: persistent tracer presets (0 = default)
 extern uint32_t g_build_log;   // art_api.hip: art_set_tuning log bits (1 build phases, 2 wave plan) -- stderr, off by default
 void lbvh_free(Lbvh &l);

@@ -124,6 +124,15 @@ struct Sphere {
 enum class ModelState { Storage, Host, Device };
 struct Model { // VkModel: only Device models are instanced in the acceleration structure (renderer.rs:640-651)
     std::vector<uint32_t> primitive_ids; Sphere model_bounding_sphere; ModelState state = ModelState::Host; bool needs_cb_submit = false, instanced = true;
+    ArtContext *ctx = nullptr; Matrix3x4 model_matrix{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    // VkModel::set_model_matrix (vk_model.rs:461-466): the instance's object -> world matrix; the sphere is transformed as the reference transforms it (the
+    // current sphere by the new matrix).  The reference rebuilds its TLAS every frame for this (renderer.rs:637-651); libart refits in front of the next frame.
+    void set_model_matrix(const Matrix3x4 &m) {
+        model_matrix = m;
+        model_bounding_sphere = model_bounding_sphere.transform(m);
+        if (ctx && !primitive_ids.empty()) check(art_scene_set_model_matrix(ctx, primitive_ids.front(), (uint32_t)primitive_ids.size(), m.data())); // a model's ids are consecutive (art_scene_add_glb)
+    }
+    const Matrix3x4 &get_transform_model_matrix() const { return model_matrix; } // vk_model.rs:358-363
     void update_model_status(const Vector3 &camera_pos) { // vk_model.rs:334-345
         float d = model_bounding_sphere.get_distance_from_point(camera_pos);
         ModelState want = d <= 10.0f ? ModelState::Device : (d <= 20.0f ? ModelState::Host : ModelState::Storage);
@@ -149,7 +158,7 @@ public:
         GltfModelReader r = GltfModelReader::open(file_path, true, GltfModelReader::B8G8R8A8_UNORM);
         uint32_t first = 0, n = 0;
         check_glb(art_scene_add_glb(ctx_, r.handle(), model_matrix.data(), &first, &n));
-        Model m;
+        Model m; m.ctx = ctx_; m.model_matrix = model_matrix;
         for (uint32_t i = 0; i < n; i++) m.primitive_ids.push_back(first + i);
         auto cs = r.get_primitives_bounding_sphere();                      // vk_model.rs:501, then set_model_matrix (:461-466)
         Sphere sp; sp.center = cs.first; sp.radius = cs.second;

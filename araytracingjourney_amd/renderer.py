@@ -188,9 +188,11 @@ class Model:
     """VkModel's residency state machine (vk_model.rs:280-345, states :27-275): Storage <-> Host <-> Device by the distance between the
     camera and the model's bounding sphere.  Only Device models are instanced in the acceleration structure (renderer.rs:640-651)."""
 
-    def __init__(self, primitive_ids, sphere, reload=None):
+    def __init__(self, primitive_ids, sphere, reload=None, renderer=None, model_matrix=None):
         self.primitive_ids = list(primitive_ids)
         self.model_bounding_sphere = sphere
+        self._renderer = renderer               # the libart context that instances the primitives
+        self.model_matrix = None if model_matrix is None else np.array(model_matrix, np.float32).reshape(3, 4)
         self.state = HOST                       # VkModel::new goes Storage -> Host (vk_model.rs:324-329)
         self.needs_cb_submit = False            # a transition to or from Device changes what the next build must contain
         self._reload = reload                   # Storage -> Host: how to read the model again (GLB path), None for in-memory models
@@ -202,6 +204,25 @@ class Model:
         if (want == DEVICE) != (self.state == DEVICE):
             self.needs_cb_submit = True
         self.state = want
+
+    def set_model_matrix(self, matrix):
+        """VkModel::set_model_matrix (vk_model.rs:461-466): the row-major 3x4 object -> world matrix of the model's instance; the bounding sphere
+        is transformed as the reference transforms it (the CURRENT sphere by the new matrix, :463-465).  The reference rebuilds its TLAS every frame
+        for this (renderer.rs:637-651); libart refits its structure on the device in front of the next frame (art_scene_set_model_matrix)."""
+        m = np.ascontiguousarray(matrix, dtype=np.float32).reshape(3, 4)
+        self.model_matrix = m.copy()
+        self.model_bounding_sphere = self.model_bounding_sphere.transform(m)
+        if self._renderer is not None and self.primitive_ids:
+            ids = sorted(self.primitive_ids)
+            runs, start = [], ids[0]                # consecutive ids travel as one call
+            for a, b in zip(ids, ids[1:] + [None]):
+                if b is None or b != a + 1:
+                    runs.append((start, a - start + 1)); start = b
+            for first, n in runs:
+                check(self._renderer._L.art_scene_set_model_matrix(self._renderer._ctx, first, n, _ptr(m)))
+
+    def get_transform_model_matrix(self):           # vk_model.rs:358-363
+        return None if self.model_matrix is None else self.model_matrix.copy()
 
     def needs_command_buffer_submission(self):
         return self.needs_cb_submit
@@ -265,7 +286,7 @@ class Renderer:
         c = 0.5 * (lo + hi)
         rad = max(float(np.linalg.norm(np.asarray(p.verts)[:, :3] - c, axis=1).max()) for p in primitives)
         mm = model_matrix if model_matrix is not None else primitives[0].model
-        self._models.append(Model(ids, Sphere(c, rad).transform(mm)))
+        self._models.append(Model(ids, Sphere(c, rad).transform(mm), renderer=self, model_matrix=mm))
         return ids
 
     def add_model_glb(self, reader, model_matrix):
@@ -277,7 +298,7 @@ class Renderer:
             raise _lib.ArtError(r, self._L.art_glb_last_error().decode("utf-8", "replace"))
         ids = list(range(first.value, first.value + n.value))
         c, rad = reader.get_primitives_bounding_sphere()   # vk_model.rs:501, then set_model_matrix (:461-466)
-        self._models.append(Model(ids, Sphere(c, rad).transform(model_matrix)))
+        self._models.append(Model(ids, Sphere(c, rad).transform(model_matrix), renderer=self, model_matrix=model_matrix))
         return ids
 
     def models_mut(self):
@@ -385,6 +406,12 @@ class Renderer:
     def device_color(self):
         p, n = C.c_void_p(), C.c_size_t()
         check(self._L.art_device_color(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def _dev(self, which):
+        """(device pointer, bytes) of the latest frame's depth / normal output (art_device_depth / art_device_normal)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        check(getattr(self._L, "art_device_" + which)(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
     def device_color_tiles(self):

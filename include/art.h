@@ -101,6 +101,9 @@ typedef struct ArtStats {
     float trace_primary_ms, shade_ms, trace_shadow_ms, accumulate_ms;
     float ao_ms;                /* last art_trace_ao (ray generation + any-hit + resolve) */
     uint32_t split_blocks;      /* fused frame: 8x8 pixel blocks the current wave plan deals to 4 or 16 waves instead of one (see ART_FLAG_FIXED_WAVES) */
+    float refit_ms;             /* last refit after art_scene_set_model_matrix, device time (triangle records + every box above them) */
+    float refit_cost_ratio;     /* surface-area cost of the refitted tree over the cost of the tree as built (the latest refit whose figure has arrived); 1 = as built */
+    uint32_t refits, rebuilds;  /* refits since art_create; builds art_trace started by itself because refit_cost_ratio passed ArtTuning.refit_rebuild_ratio */
 } ArtStats;
 
 typedef struct ArtContext ArtContext;
@@ -153,6 +156,15 @@ int32_t art_scene_clear(ArtContext *ctx);
 /* residency (vk_model.rs:334-345, renderer.rs:637-651): only models in the Device state are instanced in the TLAS.  A disabled
  * primitive keeps its id and its host copy but is neither uploaded nor traced; takes effect at the next art_scene_build. */
 int32_t art_scene_set_primitive_enabled(ArtContext *ctx, uint32_t primitive_id, int32_t enabled);
+/* VkModel::set_model_matrix (vk_model.rs:461-466) -> get_transform_model_matrix (:358-363) -> the instance record of the per-frame TLAS
+ * (VkTlasBuilder::recreate_tlas every frame, renderer.rs:637-651, vk_tlas_builder.rs:38-233): primitives first_primitive .. first_primitive + n_primitives - 1
+ * (one model's, art_scene_add_glb returns the range) get a new row-major object->world 3x4.  On a built scene nothing is built again: the NEXT art_trace
+ * (or query) first REFITS on the device -- the world-space triangle records and every node box above them, the topology kept -- on that frame's own stream,
+ * into the next of a small ring of versions of the structure (ArtTuning.as_versions, default 3), so frames in flight keep the scene they were launched
+ * with and nothing waits unless every version is still being read (the reference's per-frame fence, renderer.rs:451-466).  Frames are those of a fresh
+ * build, bit for bit (hits are structure-independent).  When the refitted tree's surface-area cost passes ArtTuning.refit_rebuild_ratio (default 2) times
+ * the built tree's, art_trace builds again instead (ArtStats.rebuilds).  Every rank of an art_mgpu job must make the same calls. */
+int32_t art_scene_set_model_matrix(ArtContext *ctx, uint32_t first_primitive, uint32_t n_primitives, const float model3x4[12]);
 /* VkBlasBuilder::build_blas_from_geometry (vk_blas_builder.rs:88-170) + VkTlasBuilder::recreate_tlas
  * (vk_tlas_builder.rs:38-233): device LBVH over the world-space triangle soup. */
 int32_t art_scene_build(ArtContext *ctx);
@@ -346,6 +358,8 @@ typedef struct ArtTuning {
     uint32_t hw_queues;         /* hardware queues the HOST gave the process (GPU_MAX_HW_QUEUES; 0 = HIP's default of 4): the wave plan counts min(frames in flight, this) launches in flight */
     uint32_t log;               /* to stderr: 1 build phase times, 2 wave-plan decisions, 4 every wave-plan poll */
     uint32_t wide_builder;      /* the 4-wide collapse of the binary tree: 0 level by level on the device | 1 one host thread (the form the device one is tested against) */
+    uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..8 (0 = 3): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
+    float refit_rebuild_ratio;  /* art_trace rebuilds instead of refitting once ArtStats.refit_cost_ratio exceeds this (0 = 2.0; negative: never) */
 } ArtTuning;
 int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
 /* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */

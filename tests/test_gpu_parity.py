@@ -917,6 +917,169 @@ def test_lights_change_every_frame_while_sixteen_frames_are_in_flight(R, orc, ge
     r.close()
 
 
+def _pose(base, i):
+    """frame i's object -> world matrix of the moving model: its base matrix, rotated about y and z and carried along a small loop (float32 3x4, row-major)"""
+    import math
+    a, b = 0.21 * i, 0.13 * i
+    ry = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1]])
+    rz = np.array([[math.cos(b), -math.sin(b), 0, 0], [math.sin(b), math.cos(b), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    t = np.eye(4); t[:3, 3] = (0.25 * math.sin(0.4 * i), 0.05 * i, 0.2 * math.cos(0.3 * i) - 0.2)
+    m = t @ ry @ rz @ np.vstack([np.asarray(base, np.float64).reshape(3, 4), [0, 0, 0, 1]])
+    return np.ascontiguousarray(m[:3], np.float32)
+
+
+def _moving_scene(R, scenes, sc, movers, extent, lights, **kw):
+    """the scene as two models: the primitives in `movers` (one model that will move) and the rest"""
+    r = R.Renderer(extent, **kw)
+    static = [p for j, p in enumerate(sc.primitives) if j not in movers]
+    moving = [sc.primitives[j] for j in movers]
+    r.add_model(static)
+    r.add_model(moving)
+    cam = r.camera_mut()
+    cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
+    for d in lights:
+        r.lights_mut().push_dict(d)
+    r.prepare_first_frame()
+    return r, static, moving
+
+
+def _oracle_of_moved(orc, scenes, static, moving, m):
+    P = type(moving[0])
+    return orc.Scene(static + [P(p.verts, p.indices, p.tex, m) for p in moving], morton_bits=30)   # built from scratch where the model is now
+
+
+@pytest.mark.parametrize("versions", [3, 1, 8])
+def test_a_model_moves_every_frame_with_sixteen_frames_in_flight(R, orc, get_scene, scenes, versions):
+    """Row a3 (VkModel::set_model_matrix vk_model.rs:461-466 + the per-frame TLAS of renderer.rs:637-651): one model is moved and rotated before every
+    frame, 16 frames are launched back to back without a host sync, and EVERY frame is the oracle's frame of a scene built from scratch where the model
+    is in that frame -- depth and normal bit for bit (the geometry outputs), radiance within 1e-4.  libart refits (triangle records and every box above
+    them, topology kept) into a ring of `versions` copies of the structure: frames in flight keep the scene they were launched with."""
+    from helpers import device_to_host
+    sc = get_scene("sponza_like", 0.12)
+    w, h, F = 320, 180, 16
+    lights = scenes.sponza_lights(4)
+    movers = [len(sc.primitives) - 1, len(sc.primitives) - 2]          # two primitives of one model (displaced spheres)
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, frames_in_flight=F, tuning={"as_versions": versions, "refit_rebuild_ratio": -1.0})
+    model = r.models_mut()[1]
+    base = moving[0].model
+    r.render_frame()                                                    # buffers allocated, wave plan sampled
+    ptrs, poses = [], []
+    for i in range(F):
+        m = _pose(base, i + 1)
+        model.set_model_matrix(m)
+        poses.append(m)
+        r.upload_state(); r.trace()
+        ptrs.append((r.device_color(), r._dev("depth"), r._dev("normal")))
+    r.sync()
+    st = r.stats()
+    assert st["refits"] == F and st["rebuilds"] == 0 and st["refit_ms"] > 0
+    cam = oracle_camera(orc, sc, w, h)
+    L = orc.make_lights(lights)
+    shown = 0
+    for i in range(F):
+        ref = _oracle_of_moved(orc, scenes, static, moving, poses[i]).render(cam, L, len(lights), w, h, threads=8, debug=True)
+        (pc, nc), (pd, nd), (pn, nn) = ptrs[i]
+        color = device_to_host(pc, nc).view(np.float32).reshape(h, w, 4)
+        depth = device_to_host(pd, nd).view(np.float32).reshape(h, w)
+        normal = device_to_host(pn, nn).view(np.float32).reshape(h, w, 4)
+        assert np.array_equal(depth.view(np.uint32), ref["depth"].view(np.uint32)), f"frame {i}: depth"
+        assert np.array_equal(normal.view(np.uint32), ref["normal"].view(np.uint32)), f"frame {i}: normal"
+        assert_radiance_close(color, ref["color"], what=f"frame {i}")
+        shown += int((ref["hit_id"][..., 0] >= len(static)).sum())
+    assert shown > 2000                                                  # the model that moves is in view
+    r.close()
+
+
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "staged", "per-ray"])
+def test_a_moved_model_in_every_form_of_the_frame(R, orc, get_scene, scenes, form):
+    """after art_scene_set_model_matrix every form of the frame -- the binary node records and the per-ray walks follow the refit on demand -- gives the oracle's
+    frame of the moved scene: hit ids, t, u, v and shadow bits bit for bit; so do ray queries, ray-traced AO, and the trees read back through the parity
+    surface are trees of exact boxes over the moved triangles"""
+    sc = get_scene("sponza_like", 0.12)
+    w, h = 240, 136
+    lights = scenes.sponza_lights(4)
+    fif, tuning = FORMS[form]
+    movers = [len(sc.primitives) - 1]
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, keep_debug=True, frames_in_flight=fif, tuning=dict(tuning, refit_rebuild_ratio=-1.0))
+    model = r.models_mut()[1]
+    cam = oracle_camera(orc, sc, w, h)
+    L = orc.make_lights(lights)
+    r.render_frame()
+    for i in (3, 7):
+        m = _pose(moving[0].model, i)
+        model.set_model_matrix(m)
+        r.render_frame()
+        S = _oracle_of_moved(orc, scenes, static, moving, m)
+        ref = S.render(cam, L, len(lights), w, h, threads=8, debug=True)
+        tuv, ids = r.read_hits()
+        assert np.array_equal(ids, ref["hit_id"]), f"{int((ids != ref['hit_id']).any(-1).sum())} hit ids differ"
+        assert np.array_equal(tuv.view(np.uint32)[..., :3], ref["hit_tuv"].view(np.uint32)[..., :3])
+        assert np.array_equal(r.read_shadow_bits(), ref["shadow_bits"])
+        st = r.stats()
+        assert st["shadow_rays"] == ref["stats"]["shadow_rays"] and st["hit_pixels"] == ref["stats"]["hit_pixels"]
+        assert_radiance_close(r.read_color(), ref["color"])
+        assert np.array_equal(r.read_depth().view(np.uint32), ref["depth"].view(np.uint32))
+        r.trace_ao(8)                                                    # AO in the structure the frame was traced in
+        want_ao, _ = orc.render_ao(S, cam, ref["depth"], ref["normal"], 8, 0.2 * 1.457, threads=8)
+        assert np.array_equal(r.read_ao(), want_ao)
+    model.set_model_matrix(_pose(moving[0].model, 11))                   # no frame in between: the queries refit first
+    S = _oracle_of_moved(orc, scenes, static, moving, model.model_matrix)
+    rays = random_rays(20000, 11)
+    tuv, ids = r.query_closest(rays)
+    rtuv, rids, _, _ = S.trace_closest(rays)
+    assert np.array_equal(ids, rids) and np.array_equal(tuv.view(np.uint32)[:, :3], rtuv.view(np.uint32)[:, :3])
+    short = rays.copy(); short[:, 7] = 1.5
+    assert np.array_equal(r.query_any(short), S.trace_any(short)[0])
+    # the parity surface after a move: leaf boxes = the moved triangles' boxes, every node box the exact union of its children's
+    lb, tr = r.get_lbvh(), r.get_traversal_tree()
+    ref_lb = S.lbvh()
+    by_gid = np.empty_like(ref_lb["leaf_lo"]); by_gid[ref_lb["leaf_gid"]] = ref_lb["leaf_lo"]
+    assert np.array_equal(lb["leaf_lo"].view(np.uint32), by_gid[lb["leaf_gid"]].view(np.uint32))   # same world-space triangles as a fresh build (leaf order: the original build's)
+    for tree, child in ((lb, lb["child"]), (tr, tr["child"])):
+        def box(ref, lo_or_hi):
+            return np.where((ref < 0)[:, None], lb["leaf_" + lo_or_hi][np.where(ref < 0, ~ref, 0)], tree["node_" + lo_or_hi][np.where(ref >= 0, ref, 0)])
+        assert np.array_equal(tree["node_lo"], np.minimum(box(child[:, 0], "lo"), box(child[:, 1], "lo")))
+        assert np.array_equal(tree["node_hi"], np.maximum(box(child[:, 0], "hi"), box(child[:, 1], "hi")))
+    r.close()
+
+
+def test_refit_writes_the_bits_of_the_build_and_rebuilds_past_the_cost_threshold(R, orc, get_scene, scenes):
+    """a model moved away and back: the refitted triangle records and 4-wide nodes are, bit for bit, the arrays of the build (the refit repeats the build's
+    arithmetic); a move that inflates the tree past ArtTuning.refit_rebuild_ratio makes art_trace build again -- and the frame is still the oracle's"""
+    sc = get_scene("sponza_like", 0.12)
+    w, h = 160, 90
+    lights = scenes.sponza_lights(1)
+    movers = [len(sc.primitives) - 1]
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, tuning={"refit_rebuild_ratio": 1.05})
+    model = r.models_mut()[1]
+    q0, f0 = r.get_wide_nodes()
+    r.render_frame()
+    c0 = r.read_color()
+    model.set_model_matrix(moving[0].model)                              # where it already is: nothing to do
+    r.render_frame()
+    assert r.stats()["refits"] == 0
+    model.set_model_matrix(_pose(moving[0].model, 2)); r.render_frame()
+    q1, f1 = r.get_wide_nodes()
+    assert not np.array_equal(f0, f1) and np.array_equal(f0[:, 24:], f1[:, 24:])        # boxes moved, the topology did not
+    model.set_model_matrix(moving[0].model); r.render_frame()
+    st = r.stats()
+    assert st["refits"] == 2 and st["rebuilds"] == 0 and abs(st["refit_cost_ratio"] - 1.0) < 0.2
+    q2, f2 = r.get_wide_nodes()
+    assert np.array_equal(q0, q2) and np.array_equal(f0, f2)
+    assert np.array_equal(r.read_color().view(np.uint32), c0.view(np.uint32))
+    far = np.array(moving[0].model, np.float32).reshape(3, 4).copy(); far[1, 3] += 6.0   # six units up: every box above it inflates
+    model.set_model_matrix(far); r.render_frame(); r.sync()
+    assert r.stats()["refit_cost_ratio"] > 1.05                          # measured on that refit ...
+    model.set_model_matrix(_pose(far, 1)); r.render_frame()              # ... so the next move builds instead
+    st = r.stats()
+    assert st["rebuilds"] == 1 and st["refit_cost_ratio"] == 1.0
+    S = _oracle_of_moved(orc, scenes, static, moving, model.model_matrix)
+    ref = S.render(oracle_camera(orc, sc, w, h), orc.make_lights(lights), 1, w, h, threads=8)
+    assert_radiance_close(r.read_color(), ref["color"])
+    assert np.array_equal(r.read_depth().view(np.uint32), ref["depth"].view(np.uint32))
+    r.close()
+
+
 def test_packing_and_tonemap_match_oracle(R, orc, get_scene):
     """art_present: the reference's storage formats (bit-exact integer packing) and tonemap.comp.glsl's output (BGRA8, <= 1 LSB)"""
     sc = get_scene("sponza_like", 0.12)
