@@ -292,7 +292,7 @@ int32_t as_create(ArtContext *c) {
         HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(c->main_stream()));
         double h[2] = {0, 0};
         HIPC(hipMemcpy(h, V0.d_cost, 16, hipMemcpyDeviceToHost));
-        c->as_cost0 = h[1] > 0.0 ? h[0] / h[1] : 0.0; c->refit_cost_ratio = 1.0f;
+        c->as_cost0 = h[0]; c->refit_cost_ratio = 1.0f;
         HIPC(hipDeviceSynchronize()); // (the copies above ran on the null stream; the frame streams are non-blocking)
         return ART_OK;
     };
@@ -306,7 +306,7 @@ void harvest_cost(ArtContext *c) {
     AsVersion &L = c->as[c->as_cur];
     if (!L.cost_pending || hipEventQuery(L.cost_ev) != hipSuccess) return;
     L.cost_pending = false;
-    if (L.h_cost[1] > 0.0 && c->as_cost0 > 0.0) c->refit_cost_ratio = (float)((L.h_cost[0] / L.h_cost[1]) / c->as_cost0);
+    if (c->as_cost0 > 0.0) c->refit_cost_ratio = (float)(L.h_cost[0] / c->as_cost0);
 }
 // A model moved since the last launch: bring the NEXT version of the structure up to date on stream s, the stream of ring slot k whose frame is about to be
 // launched -- the frame is ordered behind the refit by the stream, frames on other streams by V.ready (art_trace).  Frames still reading the version about to be
@@ -1461,7 +1461,7 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         harvest_cost(c);
         if (!c->as.empty() && c->as[c->as_cur].timed) { float rms = 0; if (hipEventElapsedTime(&rms, c->as[c->as_cur].t0, c->as[c->as_cur].t1) == hipSuccess) c->last_refit_ms = rms; }
         c->stats.ao_rays = (uint64_t)c->ao_spp * cnt[1];
-        if (c->ao_spp) { float ams = 0; if (hipEventElapsedTime(&ams, c->slot[c->last].ao_ev[0], c->slot[c->last].ao_ev[1]) == hipSuccess) c->stats.ao_ms = ams; }
+        if (c->ao_spp && c->slot[c->last].ao_valid) { float ams = 0; if (hipEventElapsedTime(&ams, c->slot[c->last].ao_ev[0], c->slot[c->last].ao_ev[1]) == hipSuccess) c->stats.ao_ms = ams; } // (only a slot whose latest frame had its AO pass has recorded these events: asking others leaves an error behind for the next hipGetLastError)
         float ms = 0;
         if (c->frame_no) {
             hipEvent_t *ev = c->ev[(c->frame_no - 1) % ArtContext::kRing];

@@ -549,8 +549,10 @@ __global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevT
         __syncthreads(); // the level above reads these records
     }
 }
-// Surface-area cost of the 4-wide tree: cost[0] += sum over all nodes of the half-areas of their child boxes, cost[1] = half-area of the root's union --
-// cost[0] / cost[1] is the expected number of child boxes a random ray through the scene crosses, what a refit can degrade and a rebuild restores.
+// Surface-area cost of the 4-wide tree: cost[0] += sum over all nodes of the half-areas of their child boxes (the measure of the rays that cross each box: what a
+// walk pays for), cost[1] = half-area of the root's union.  A refit can only keep or grow it against the same rays; a rebuild restores it.  The rule compares the
+// plain sums: dividing by the root's area would reward a model that flies off (the root grows faster than the sum) although the rays of a camera among the rest
+// of the scene cross more boxes than before.
 __global__ __launch_bounds__(256) void k_wide_cost(uint32_t n_wide, const DevNodeW *__restrict__ widef, double *cost) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     double a = 0.0;

@@ -56,6 +56,8 @@ def parse():
                                                  "block_order, split_alpha ...); the default -- none -- is the product")
     ap.add_argument("--camera-path", type=int, default=8, help="N = 1 extra leg: the camera moves every frame along a closed path of this many poses (0 = skip); ray counts of every pose "
                                                                "are checked against the oracle's committed ones")
+    ap.add_argument("--moving-model", type=int, default=8, help="N = 1 extra leg: one model of the scene (its last primitive) is moved and rotated before every frame along a closed path of this many "
+                                                                "poses (art_scene_set_model_matrix: a device refit in front of each frame, VkModel::set_model_matrix + the reference's per-frame TLAS); 0 = skip")
     ap.add_argument("--gather-launches", type=int, default=-1, help="N>1: ring slots (launches) per exchange; 0 = the whole ring (the slots are contiguous, so a group travels as one message "
                     "per peer); default: a quarter of the timed launches, at most the ring -- a run of a few launches then still overlaps its exchanges with its tracing "
                     "instead of paying one exchange of everything behind the last frame")
@@ -318,6 +320,51 @@ def main():
         r._camera = renderer.Camera(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
         r.upload_state()
 
+    # ---- a moving model: art_scene_set_model_matrix before every frame (row a3: the reference rebuilds its TLAS every frame so that models can move) --------
+    moving_model = None
+    if extras and not args.ao and not glb and args.moving_model > 0 and len(sc.primitives) > 1:
+        import math
+        mv = renderer.Renderer((W, H), device=local_rank, frames_in_flight=F, tuning=tuning)
+        mv.add_model(sc.primitives[:-1])
+        mv.add_model(sc.primitives[-1:])
+        cam = mv.camera_mut()
+        cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
+        for d in lights:
+            mv.lights_mut().push_dict(d)
+        mv.prepare_first_frame()
+        mv.upload_state()
+        base = np.vstack([np.asarray(sc.primitives[-1].model, np.float64).reshape(3, 4), [0, 0, 0, 1]])
+        poses = []
+        for i in range(args.moving_model):   # a closed loop: rotation about y, a small orbit
+            a = 2 * math.pi * i / args.moving_model
+            ry = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1]])
+            t = np.eye(4); t[:3, 3] = (0.15 * math.cos(a) - 0.15, 0.05 * math.sin(2 * a), 0.15 * math.sin(a))
+            poses.append(np.ascontiguousarray((t @ ry @ base)[:3], np.float32))
+        model = mv.models_mut()[1]
+        rays_pose, refit_alone = [], []
+        for m in poses:                       # every pose once alone: its ray count, and the refit's device time with nothing else on the GPU
+            model.set_model_matrix(m)
+            mv.trace(); mv.sync()
+            ps = mv.stats()
+            rays_pose.append(ps["primary_rays"] + ps["shadow_rays"]); refit_alone.append(ps["refit_ms"])
+
+        def moved(n):
+            for i in range(n):
+                model.set_model_matrix(poses[i % len(poses)])
+                mv.trace()
+        moved(2 * F); mv.sync()
+        m0 = time.perf_counter()
+        moved(args.steps); mv.sync()
+        mwall = time.perf_counter() - m0
+        ms_ = mv.stats()
+        refit_alone.sort()
+        moving_model = dict(poses=len(poses), value=sum(rays_pose[i % len(poses)] for i in range(args.steps)) / mwall / 1e6, unit="Mray/s", ms_per_step=mwall * 1e3 / args.steps,
+                            refit_ms=refit_alone[len(refit_alone) // 2], refit_ms_max=refit_alone[-1], refits=ms_["refits"], rebuilds=ms_["rebuilds"], refit_cost_ratio=ms_["refit_cost_ratio"],
+                            moving_triangles=sc.primitives[-1].n_tris, build_ms=ms_["build_ms"],
+                            protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, rotated and carried round a loop), fenced on both sides like `value`; "
+                                     "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses")
+        mv.close()
+
     # ---- outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit ---------------------------
     frame_ok = None
     if world > 1 and (rank == 0 or spread):          # every rank that assembles frames checks the newest one it holds
@@ -435,7 +482,7 @@ def main():
                                      f"{counts['launches_per_gather'] * B} frames per exchange") + f", {F * B} frames in flight"},
         "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
         "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
-        "camera_path": campath,
+        "camera_path": campath, "moving_model": moving_model, "refit_ms": moving_model["refit_ms"] if moving_model else None,
         "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": settle_launches * B,
         "tuning": tuning, "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
         "roofline": roof, "cpu_baseline": cpu,

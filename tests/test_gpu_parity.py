@@ -1050,7 +1050,7 @@ def test_refit_writes_the_bits_of_the_build_and_rebuilds_past_the_cost_threshold
     w, h = 160, 90
     lights = scenes.sponza_lights(1)
     movers = [len(sc.primitives) - 1]
-    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, tuning={"refit_rebuild_ratio": 1.05})
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, tuning={"refit_rebuild_ratio": -1.0})
     model = r.models_mut()[1]
     q0, f0 = r.get_wide_nodes()
     r.render_frame()
@@ -1067,6 +1067,10 @@ def test_refit_writes_the_bits_of_the_build_and_rebuilds_past_the_cost_threshold
     q2, f2 = r.get_wide_nodes()
     assert np.array_equal(q0, q2) and np.array_equal(f0, f2)
     assert np.array_equal(r.read_color().view(np.uint32), c0.view(np.uint32))
+    r.close()
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, tuning={"refit_rebuild_ratio": 1.05})
+    model = r.models_mut()[1]
+    r.render_frame()
     far = np.array(moving[0].model, np.float32).reshape(3, 4).copy(); far[1, 3] += 6.0   # six units up: every box above it inflates
     model.set_model_matrix(far); r.render_frame(); r.sync()
     assert r.stats()["refit_cost_ratio"] > 1.05                          # measured on that refit ...
