@@ -265,12 +265,13 @@ void as_release(ArtContext *c) {
     }
     c->as.clear(); c->as_cur = 0;
 }
-// the first move of a built scene: the ring of versions (ArtTuning.as_versions, default 3 like the reference's frames in flight, renderer.rs:135), every one a copy of
+// the first move of a built scene: the ring of versions (ArtTuning.as_versions; default 4: one more than the reference's frames in flight, renderer.rs:135 -- measured on
+// config 2 with a model of 164 k triangles moving every frame, 16 ring slots: 0.70 / 0.38 / 0.28 / 0.25 / 0.26 ms per frame with 1 / 2 / 3 / 4 / 8 versions), every one a copy of
 // the build's arrays -- the topology (child references, valid masks, sort axes) is never written again -- and the cost of the tree as built
 int32_t as_create(ArtContext *c) {
     int32_t r = ensure_wide(c, true); if (r) return r;
     r = sync_all(c); if (r) return r;
-    const uint32_t K = c->tuning.as_versions ? std::min(c->tuning.as_versions, kMaxAsVersions) : 3u;
+    const uint32_t K = c->tuning.as_versions ? std::min(c->tuning.as_versions, kMaxAsVersions) : 4u;
     const size_t np = c->h_dev_prims.size(), T = c->T, NW = c->bvh.n_wide;
     c->as.assign(K, AsVersion{});
     auto body = [&]() -> int32_t {
@@ -288,7 +289,7 @@ int32_t as_create(ArtContext *c) {
             HIPC(hipEventCreate(&V.t0)); HIPC(hipEventCreate(&V.t1));
         }
         AsVersion &V0 = c->as[0];
-        launch_wide_cost(c->bvh.n_wide, V0.widef, V0.d_cost, c->main_stream());
+        launch_wide_cost(c->bvh.n_wide, V0.widef, nullptr, V0.d_cost, c->main_stream());
         HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(c->main_stream()));
         double h[2] = {0, 0};
         HIPC(hipMemcpy(h, V0.d_cost, 16, hipMemcpyDeviceToHost));
@@ -344,9 +345,8 @@ int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
     HIPC(hipEventRecord(V.t0, s));
     HIPC(hipMemcpyAsync(V.prims, V.h_prims, np * sizeof(DevPrim), hipMemcpyHostToDevice, s));
     launch_retri(c->T, c->bvh.shade_tris, V.prims, V.tris, s);
-    launch_wide_refit(c->bvh.wide_levels, V.tris, V.wide, V.widef, s);
+    launch_wide_refit(c->bvh.wide_levels, V.tris, V.wide, V.widef, V.d_cost, s);
     HIPC(hipEventRecord(V.t1, s)); V.timed = true;
-    launch_wide_cost(c->bvh.n_wide, V.widef, V.d_cost, s);
     HIPC(hipMemcpyAsync(V.h_cost, V.d_cost, 16, hipMemcpyDeviceToHost, s));
     HIPC(hipEventRecord(V.cost_ev, s)); V.cost_pending = true;
     HIPC(hipEventRecord(V.ready, s)); V.ready_known = false; V.ready_slot = k;

@@ -510,87 +510,101 @@ __global__ __launch_bounds__(256) void k_retri(uint32_t T, const DevShadeTri *__
     tris[p] = t;
 }
 
-// one node of the 4-wide tree from its children: a leaf child's box is its triangle's, an internal child's the union of that node's own child boxes
-__device__ __forceinline__ void wide_refit_node(uint32_t w, const DevTri *__restrict__ tris, DevNode4 *wide, DevNodeW *widef) {
-    DevNodeW dw = widef[w];
-    const int nc = __popc(dw.valid & 15u); // the valid children are slots 0 .. nc-1
-    float lo[4][3], hi[4][3];
-    for (int i = 0; i < 4; i++) {
-        if (i >= nc) continue;
-        const int32_t ch = dw.child[i];
-        if (ch < 0) { const DevTri &t = tris[~ch]; for (int k = 0; k < 3; k++) { lo[i][k] = t.f[9 + k]; hi[i][k] = t.f[12 + k]; } }
-        else {
-            const DevNodeW &cw = widef[ch];
-            const uint32_t cv = cw.valid;
-            for (int k = 0; k < 3; k++) { lo[i][k] = INFINITY; hi[i][k] = -INFINITY; }
-            for (int j = 0; j < 4; j++) if ((cv >> j) & 1u) for (int k = 0; k < 3; k++) { lo[i][k] = fminf(lo[i][k], cw.box[j][k]); hi[i][k] = fmaxf(hi[i][k], cw.box[j][3 + k]); }
-        }
-        for (int k = 0; k < 3; k++) { dw.box[i][k] = lo[i][k]; dw.box[i][3 + k] = hi[i][k]; }
+// One child box of one node of the 4-wide tree: a leaf child's box is its triangle's, an internal child's the union of that node's own child boxes (float min / max
+// are exact, so whatever the order the union is the box a build would find).  Four neighbouring lanes share a node; the pass is loads and min / max only -- the
+// quantised records are made afterwards, for all nodes at once (k_wide_requant): their double-precision arithmetic does not belong on the bottom-up critical path.
+__device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const DevTri *__restrict__ tris, DevNodeW *widef) {
+    const int32_t ch = widef[w].child[i];
+    if (ch == kAbsentChild) return;
+    float lo[3], hi[3];
+    if (ch < 0) {
+        const float4 *tq = reinterpret_cast<const float4 *>(tris + (uint32_t)~ch);
+        const float4 c = tq[2], d = tq[3];                  // f[8..11] | f[12..15]: e2.z lo.xyz | hi.xyz gid
+        lo[0] = c.y; lo[1] = c.z; lo[2] = c.w; hi[0] = d.x; hi[1] = d.y; hi[2] = d.z;
+    } else {
+        const float4 *q = reinterpret_cast<const float4 *>(widef + ch);
+        const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
+        const uint32_t cv = widef[ch].valid;
+        const float b[4][6] = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y}, {a1.z, a1.w, a2.x, a2.y, a2.z, a2.w}, {a3.x, a3.y, a3.z, a3.w, a4.x, a4.y}, {a4.z, a4.w, a5.x, a5.y, a5.z, a5.w}};
+        for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+        for (int j = 0; j < 4; j++) if ((cv >> j) & 1u) for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[j][k]); hi[k] = fmaxf(hi[k], b[j][3 + k]); }
     }
-    const float *plo[4] = {lo[0], lo[1], lo[2], lo[3]}, *phi[4] = {hi[0], hi[1], hi[2], hi[3]};
-    DevNode4 d;
-    wide_quantise(plo, phi, nc, d);
-    for (int i = 0; i < 4; i++) d.child[i] = dw.child[i];
-    widef[w] = dw;
-    wide[w] = d;
+    float *o = widef[w].box[i];
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
 }
-__global__ __launch_bounds__(256) void k_wide_refit(uint32_t first, uint32_t n, const DevTri *__restrict__ tris, DevNode4 *wide, DevNodeW *widef) {
+__global__ __launch_bounds__(256) void k_wide_refit(uint32_t first, uint32_t n, const DevTri *__restrict__ tris, DevNodeW *widef) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) wide_refit_node(first + i, tris, wide, widef);
+    if (i < 4u * n) wide_union_child(first + (i >> 2), i & 3u, tris, widef);
 }
 // the top of the tree: levels of at most 1024 nodes each, bottom-up in ONE workgroup (a launch per level would cost more than the levels)
 constexpr int kTopLevels = 16;
 struct TopLevels { uint32_t first[kTopLevels + 1]; int n; }; // level i = nodes [first[i], first[i + 1])
-__global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevTri *__restrict__ tris, DevNode4 *wide, DevNodeW *widef) {
+__global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevTri *__restrict__ tris, DevNodeW *widef) {
     for (int lv = L.n - 1; lv >= 0; lv--) {
         const uint32_t n = L.first[lv + 1] - L.first[lv];
-        if (threadIdx.x < n) wide_refit_node(L.first[lv] + threadIdx.x, tris, wide, widef);
+        for (uint32_t i = threadIdx.x; i < 4u * n; i += 1024u) wide_union_child(L.first[lv] + (i >> 2), i & 3u, tris, widef);
         __threadfence_block();
         __syncthreads(); // the level above reads these records
     }
 }
-// Surface-area cost of the 4-wide tree: cost[0] += sum over all nodes of the half-areas of their child boxes (the measure of the rays that cross each box: what a
-// walk pays for), cost[1] = half-area of the root's union.  A refit can only keep or grow it against the same rays; a rebuild restores it.  The rule compares the
-// plain sums: dividing by the root's area would reward a model that flies off (the root grows faster than the sum) although the rays of a camera among the rest
-// of the scene cross more boxes than before.
-__global__ __launch_bounds__(256) void k_wide_cost(uint32_t n_wide, const DevNodeW *__restrict__ widef, double *cost) {
+// after the boxes: every node's quantised record (the per-ray walks', DevNode4) from its float one, and the tree's surface-area cost while the boxes are at hand:
+// cost[0] += the half-areas of all child boxes (the measure of the rays that cross each box: what a walk pays for), cost[1] = half-area of the root's union.  A refit
+// can only keep or grow the sum against the same rays; a rebuild restores it.  The rule compares the plain sums: dividing by the root's area would reward a model
+// that flies off (the root grows faster than the sum) although the rays of a camera among the rest of the scene cross more boxes than before.
+__global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const DevNodeW *__restrict__ widef, DevNode4 *__restrict__ wide, double *cost) {
+    __shared__ double s_part[4];
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     double a = 0.0;
     if (w < n_wide) {
-        const DevNodeW &d = widef[w];
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int j = 0; j < 4; j++) if ((d.valid >> j) & 1u) {
-            double dx = (double)d.box[j][3] - d.box[j][0], dy = (double)d.box[j][4] - d.box[j][1], dz = (double)d.box[j][5] - d.box[j][2];
-            a += dx * dy + dy * dz + dz * dx;
-            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], d.box[j][k]); hi[k] = fmaxf(hi[k], d.box[j][3 + k]); }
+        const float4 *q = reinterpret_cast<const float4 *>(widef + w);
+        const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
+        const int4 ch = *reinterpret_cast<const int4 *>(&widef[w].child[0]);
+        const float lo[4][3] = {{a0.x, a0.y, a0.z}, {a1.z, a1.w, a2.x}, {a3.x, a3.y, a3.z}, {a4.z, a4.w, a5.x}}, hi[4][3] = {{a0.w, a1.x, a1.y}, {a2.y, a2.z, a2.w}, {a3.w, a4.x, a4.y}, {a5.y, a5.z, a5.w}};
+        const int nc = (ch.x != kAbsentChild) + (ch.y != kAbsentChild) + (ch.z != kAbsentChild) + (ch.w != kAbsentChild); // the valid children are slots 0 .. nc-1
+        if (wide) {
+            const float *plo[4] = {lo[0], lo[1], lo[2], lo[3]}, *phi[4] = {hi[0], hi[1], hi[2], hi[3]};
+            DevNode4 d;
+            wide_quantise(plo, phi, nc, d);
+            d.child[0] = ch.x; d.child[1] = ch.y; d.child[2] = ch.z; d.child[3] = ch.w;
+            wide[w] = d;
         }
-        if (w == 0) { double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2]; cost[1] = dx * dy + dy * dz + dz * dx; }
+        float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int j = 0; j < nc; j++) {
+            double dx = (double)hi[j][0] - lo[j][0], dy = (double)hi[j][1] - lo[j][1], dz = (double)hi[j][2] - lo[j][2];
+            a += dx * dy + dy * dz + dz * dx;
+            for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], lo[j][k]); rhi[k] = fmaxf(rhi[k], hi[j][k]); }
+        }
+        if (w == 0) { double dx = (double)rhi[0] - rlo[0], dy = (double)rhi[1] - rlo[1], dz = (double)rhi[2] - rlo[2]; cost[1] = dx * dy + dy * dz + dz * dx; }
     }
     for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
-    if ((threadIdx.x & 63u) == 0 && a != 0.0) atomicAdd(&cost[0], a);
+    if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]); if (t != 0.0) atomicAdd(&cost[0], t); }
 }
 
 void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, DevTri *tris, hipStream_t s) {
     k_retri<<<(T + 255) / 256, 256, 0, s>>>(T, shade, prims, tris);
 }
-void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, hipStream_t s) {
+void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, double *cost, hipStream_t s) {
     const int n_levels = (int)levels.size() - 1;
     if (n_levels <= 0) return;
     int top = 0; // levels [0, top) go into the one-workgroup launch
     while (top < n_levels && top < kTopLevels && levels[top + 1] - levels[top] <= 1024u) top++;
     for (int lv = n_levels - 1; lv >= top; lv--) {
         const uint32_t n = levels[lv + 1] - levels[lv];
-        k_wide_refit<<<(n + 255) / 256, 256, 0, s>>>(levels[lv], n, tris, wide, widef);
+        k_wide_refit<<<(4 * n + 255) / 256, 256, 0, s>>>(levels[lv], n, tris, widef);
     }
     if (top) {
         TopLevels L{}; L.n = top;
         for (int i = 0; i <= top; i++) L.first[i] = levels[i];
-        k_wide_refit_top<<<1, 1024, 0, s>>>(L, tris, wide, widef);
+        k_wide_refit_top<<<1, 1024, 0, s>>>(L, tris, widef);
     }
+    launch_wide_cost((uint32_t)levels.back(), widef, wide, cost, s);
 }
-void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, double *cost, hipStream_t s) {
+// the quantised records (wide; null: leave them) and the cost (2 doubles) of the float records
+void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide, double *cost, hipStream_t s) {
     (void)hipMemsetAsync(cost, 0, 16, s);
-    k_wide_cost<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, cost);
+    k_wide_requant<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, wide, cost);
 }
 
 // The binary trees (the canonical LBVH of art_get_lbvh, the traversal tree of the per-ray / binary walks) after a refit: leaf boxes from the triangle records,

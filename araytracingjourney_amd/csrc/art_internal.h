@@ -104,8 +104,8 @@ void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s);
 // primitive table; its 4-wide nodes bottom-up, level by level (l.wide_levels); the tree's surface-area cost (2 doubles: sum of child half-areas, root half-area);
 // the binary trees and node records from a version's triangles (on demand, synchronises)
 void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, DevTri *tris, hipStream_t s);
-void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, hipStream_t s);
-void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, double *cost, hipStream_t s);
+void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, double *cost, hipStream_t s); // boxes bottom-up, then the quantised records + cost
+void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide /*null: cost only*/, double *cost, hipStream_t s);
 hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s);
 void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks); // art_trace.hip: persistent tracer presets (0 = default)
 extern uint32_t g_build_log;   // art_api.hip: art_set_tuning log bits (1 build phases, 2 wave plan) -- stderr, off by default

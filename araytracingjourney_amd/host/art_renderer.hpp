@@ -124,12 +124,13 @@ struct Sphere {
 enum class ModelState { Storage, Host, Device };
 struct Model { // VkModel: only Device models are instanced in the acceleration structure (renderer.rs:640-651)
     std::vector<uint32_t> primitive_ids; Sphere model_bounding_sphere; ModelState state = ModelState::Host; bool needs_cb_submit = false, instanced = true;
-    ArtContext *ctx = nullptr; Matrix3x4 model_matrix{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    // VkModel::set_model_matrix (vk_model.rs:461-466): the instance's object -> world matrix; the sphere is transformed as the reference transforms it (the
-    // current sphere by the new matrix).  The reference rebuilds its TLAS every frame for this (renderer.rs:637-651); libart refits in front of the next frame.
+    ArtContext *ctx = nullptr; Matrix3x4 model_matrix{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0}; Sphere object_sphere; // the reader's sphere, before any model matrix
+    // VkModel::set_model_matrix (vk_model.rs:461-466): the instance's object -> world matrix and the sphere that goes with it.  Fixed against the reference, which
+    // transforms the sphere it HOLDS (already transformed) by the new matrix (:463-465) and so compounds the matrices of a model that moves every frame; the same for
+    // the one call main.rs makes.  The reference rebuilds its TLAS every frame for this (renderer.rs:637-651); libart refits in front of the next frame.
     void set_model_matrix(const Matrix3x4 &m) {
         model_matrix = m;
-        model_bounding_sphere = model_bounding_sphere.transform(m);
+        model_bounding_sphere = object_sphere.transform(m);
         if (ctx && !primitive_ids.empty()) check(art_scene_set_model_matrix(ctx, primitive_ids.front(), (uint32_t)primitive_ids.size(), m.data())); // a model's ids are consecutive (art_scene_add_glb)
     }
     const Matrix3x4 &get_transform_model_matrix() const { return model_matrix; } // vk_model.rs:358-363
@@ -162,6 +163,7 @@ public:
         for (uint32_t i = 0; i < n; i++) m.primitive_ids.push_back(first + i);
         auto cs = r.get_primitives_bounding_sphere();                      // vk_model.rs:501, then set_model_matrix (:461-466)
         Sphere sp; sp.center = cs.first; sp.radius = cs.second;
+        m.object_sphere = sp;
         m.model_bounding_sphere = sp.transform(model_matrix);
         models_.push_back(m);
     }

@@ -188,9 +188,10 @@ class Model:
     """VkModel's residency state machine (vk_model.rs:280-345, states :27-275): Storage <-> Host <-> Device by the distance between the
     camera and the model's bounding sphere.  Only Device models are instanced in the acceleration structure (renderer.rs:640-651)."""
 
-    def __init__(self, primitive_ids, sphere, reload=None, renderer=None, model_matrix=None):
+    def __init__(self, primitive_ids, sphere, reload=None, renderer=None, model_matrix=None, object_sphere=None):
         self.primitive_ids = list(primitive_ids)
         self.model_bounding_sphere = sphere
+        self._object_sphere = object_sphere     # the reader's sphere, before any model matrix (set_model_matrix transforms THIS one)
         self._renderer = renderer               # the libart context that instances the primitives
         self.model_matrix = None if model_matrix is None else np.array(model_matrix, np.float32).reshape(3, 4)
         self.state = HOST                       # VkModel::new goes Storage -> Host (vk_model.rs:324-329)
@@ -206,12 +207,14 @@ class Model:
         self.state = want
 
     def set_model_matrix(self, matrix):
-        """VkModel::set_model_matrix (vk_model.rs:461-466): the row-major 3x4 object -> world matrix of the model's instance; the bounding sphere
-        is transformed as the reference transforms it (the CURRENT sphere by the new matrix, :463-465).  The reference rebuilds its TLAS every frame
-        for this (renderer.rs:637-651); libart refits its structure on the device in front of the next frame (art_scene_set_model_matrix)."""
+        """VkModel::set_model_matrix (vk_model.rs:461-466): the row-major 3x4 object -> world matrix of the model's instance, and the bounding sphere
+        that goes with it.  Fixed against the reference: it transforms the sphere it HOLDS -- already transformed by the previous matrix -- by the new one
+        (:463-465), so a model that is moved every frame compounds its matrices (a scale of 2 doubles the radius per call); here the reader's
+        object-space sphere is transformed, which is the same for the one call the reference's main.rs makes.  The reference rebuilds its TLAS every
+        frame for a moved model (renderer.rs:637-651); libart refits its structure on the device in front of the next frame (art_scene_set_model_matrix)."""
         m = np.ascontiguousarray(matrix, dtype=np.float32).reshape(3, 4)
         self.model_matrix = m.copy()
-        self.model_bounding_sphere = self.model_bounding_sphere.transform(m)
+        self.model_bounding_sphere = (self._object_sphere if self._object_sphere is not None else self.model_bounding_sphere).transform(m)
         if self._renderer is not None and self.primitive_ids:
             ids = sorted(self.primitive_ids)
             runs, start = [], ids[0]                # consecutive ids travel as one call
@@ -286,7 +289,7 @@ class Renderer:
         c = 0.5 * (lo + hi)
         rad = max(float(np.linalg.norm(np.asarray(p.verts)[:, :3] - c, axis=1).max()) for p in primitives)
         mm = model_matrix if model_matrix is not None else primitives[0].model
-        self._models.append(Model(ids, Sphere(c, rad).transform(mm), renderer=self, model_matrix=mm))
+        self._models.append(Model(ids, Sphere(c, rad).transform(mm), renderer=self, model_matrix=mm, object_sphere=Sphere(c, rad)))
         return ids
 
     def add_model_glb(self, reader, model_matrix):
@@ -298,7 +301,7 @@ class Renderer:
             raise _lib.ArtError(r, self._L.art_glb_last_error().decode("utf-8", "replace"))
         ids = list(range(first.value, first.value + n.value))
         c, rad = reader.get_primitives_bounding_sphere()   # vk_model.rs:501, then set_model_matrix (:461-466)
-        self._models.append(Model(ids, Sphere(c, rad).transform(model_matrix), renderer=self, model_matrix=model_matrix))
+        self._models.append(Model(ids, Sphere(c, rad).transform(model_matrix), renderer=self, model_matrix=model_matrix, object_sphere=Sphere(c, rad)))
         return ids
 
     def models_mut(self):

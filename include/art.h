@@ -160,7 +160,7 @@ int32_t art_scene_set_primitive_enabled(ArtContext *ctx, uint32_t primitive_id, 
  * (VkTlasBuilder::recreate_tlas every frame, renderer.rs:637-651, vk_tlas_builder.rs:38-233): primitives first_primitive .. first_primitive + n_primitives - 1
  * (one model's, art_scene_add_glb returns the range) get a new row-major object->world 3x4.  On a built scene nothing is built again: the NEXT art_trace
  * (or query) first REFITS on the device -- the world-space triangle records and every node box above them, the topology kept -- on that frame's own stream,
- * into the next of a small ring of versions of the structure (ArtTuning.as_versions, default 3), so frames in flight keep the scene they were launched
+ * into the next of a small ring of versions of the structure (ArtTuning.as_versions, default 4), so frames in flight keep the scene they were launched
  * with and nothing waits unless every version is still being read (the reference's per-frame fence, renderer.rs:451-466).  Frames are those of a fresh
  * build, bit for bit (hits are structure-independent).  When the refitted tree's surface-area cost passes ArtTuning.refit_rebuild_ratio (default 2) times
  * the built tree's, art_trace builds again instead (ArtStats.rebuilds).  Every rank of an art_mgpu job must make the same calls. */
@@ -358,7 +358,7 @@ typedef struct ArtTuning {
     uint32_t hw_queues;         /* hardware queues the HOST gave the process (GPU_MAX_HW_QUEUES; 0 = HIP's default of 4): the wave plan counts min(frames in flight, this) launches in flight */
     uint32_t log;               /* to stderr: 1 build phase times, 2 wave-plan decisions, 4 every wave-plan poll */
     uint32_t wide_builder;      /* the 4-wide collapse of the binary tree: 0 level by level on the device | 1 one host thread (the form the device one is tested against) */
-    uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..8 (0 = 3): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
+    uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..8 (0 = 4): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
     float refit_rebuild_ratio;  /* art_trace rebuilds instead of refitting once ArtStats.refit_cost_ratio exceeds this (0 = 2.0; negative: never) */
 } ArtTuning;
 int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
