@@ -40,7 +40,7 @@ class ArtCamera(C.Structure):
 
 class ArtConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("morton_bits", C.c_uint32),
-                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("frames_in_flight", C.c_uint32)]
+                ("shard_rank", C.c_uint32), ("shard_count", C.c_uint32), ("flags", C.c_uint32), ("frames_in_flight", C.c_uint32), ("root_relief", C.c_uint32)]
 
 
 class ArtStats(C.Structure):
@@ -86,7 +86,7 @@ class ArtMgpuConfig(C.Structure):
 
 assert C.sizeof(ArtVertex) == 48 and C.sizeof(ArtLight) == 80 and C.sizeof(ArtCamera) == 268
 
-# every symbol include/art.h declares: (name, restype, argtypes)
+# every symbol include/art.h declares -- the boundary: (name, restype, argtypes)
 _P, _U32, _I32, _F, _SZ = C.c_void_p, C.c_uint32, C.c_int32, C.c_float, C.c_size_t
 SYMBOLS = {
     "art_last_error": (C.c_char_p, []),
@@ -121,32 +121,17 @@ SYMBOLS = {
     "art_device_color": (_I32, [_P, _P, _P]),
     "art_device_depth": (_I32, [_P, _P, _P]),
     "art_device_normal": (_I32, [_P, _P, _P]),
-    "art_set_root_relief": (_I32, [_U32]),
-    "art_shard_layout": (_I32, [_U32, _U32, _U32, _U32, _P, _U32, _P, _P]),
+    "art_shard_layout": (_I32, [_U32, _U32, _U32, _U32, _U32, _P, _U32, _P, _P]),
     "art_shard_tile_count": (_I32, [_P, _P, _P]),
     "art_device_color_tiles": (_I32, [_P, _P, _P]),
-    "art_bind_color_tiles": (_I32, [_P, _U32, _P, _SZ]),
-    "art_bind_color_tiles_pair": (_I32, [_P, _U32, _P, _P, _SZ]),
-    "art_bind_color_tiles_ring": (_I32, [_P, _U32, _P, _U32, _SZ]),
-    "art_set_graph_mode": (_I32, [_P, _I32]),
     "art_set_frames_per_launch": (_I32, [_P, _U32]),
     "art_set_camera_batch": (_I32, [_P, _P, _U32]),
     "art_set_read_frame": (_I32, [_P, _U32]),
     "art_frames_in_flight": (_I32, [_P, _P, _P]),
-    "art_stream_wait_frame": (_I32, [_P, _P]),
     "art_frames_done": (_I32, [_P, C.c_uint64, _U32, _P, _P]),
-    "art_wait_external_event": (_I32, [_P, _P]),
-    "art_trace_for_stream": (_I32, [_P, _P, _P]),
-    "art_collect_timings": (_I32, [_P, _P, _P]),
-    "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
     "art_untile_gathered": (_I32, [_P, _P, _U32, _P, _P]),
-    "art_untile_gathered_strided": (_I32, [_P, _P, _U32, _U32, _P, _P]),
-    "art_untile_gathered_frames": (_I32, [_P, _P, _U32, _U32, _U32, _P, _P]),
     "art_get_stats": (_I32, [_P, _P]),
     "art_get_layout": (_I32, [_P, _P]),
-    "art_set_tuning": (_I32, [_P, _P]),
-    "art_timestamp_mark": (_I32, [_P, _U32]),
-    "art_timestamp_elapsed": (_I32, [_P, _P]),
     "art_mgpu_shard": (_I32, [_U32, _U32, _U32, _P, _P]),
     "art_mgpu_unique_id": (_I32, [_P]),
     "art_mgpu_create": (_I32, [_P, _P, _P, _P]),
@@ -156,13 +141,6 @@ SYMBOLS = {
     "art_mgpu_read_frame": (_I32, [_P, _P, _SZ]),
     "art_mgpu_counts": (_I32, [_P, _P, _P, _P]),
     "art_mgpu_destroy": (_I32, [_P]),
-    "art_read_hits": (_I32, [_P, _P, _P, _SZ]),
-    "art_read_shadow_bits": (_I32, [_P, _P, _SZ]),
-    "art_query_closest": (_I32, [_P, _P, _U32, _P, _P]),
-    "art_query_any": (_I32, [_P, _P, _U32, _P]),
-    "art_get_lbvh": (_I32, [_P] + [_P] * 7),
-    "art_get_traversal_tree": (_I32, [_P, _P, _P, _P]),
-    "art_get_wide_nodes": (_I32, [_P, _P, _P, _SZ, _P]),
     "art_glb_last_error": (C.c_char_p, []),
     "art_glb_open": (_I32, [C.c_char_p, _I32, _I32, _P]),
     "art_glb_close": (_I32, [_P]),
@@ -171,6 +149,31 @@ SYMBOLS = {
     "art_glb_bounding_sphere": (_I32, [_P, _P, _P]),
     "art_glb_permute_pixels": (_I32, [_P, _SZ, _U32, _P, _U32, _U32, _P, _SZ]),
     "art_scene_add_glb": (_I32, [_P, _P, _P, _P, _P]),
+}
+# include/art_parity.h: the parity / rehearsal / measurement surface (same library, not part of the boundary)
+PARITY_SYMBOLS = {
+    "art_bind_color_tiles": (_I32, [_P, _U32, _P, _SZ]),
+    "art_bind_color_tiles_pair": (_I32, [_P, _U32, _P, _P, _SZ]),
+    "art_bind_color_tiles_ring": (_I32, [_P, _U32, _P, _U32, _SZ]),
+    "art_set_graph_mode": (_I32, [_P, _I32]),
+    "art_stream_wait_frame": (_I32, [_P, _P]),
+    "art_wait_external_event": (_I32, [_P, _P]),
+    "art_trace_for_stream": (_I32, [_P, _P, _P]),
+    "art_collect_timings": (_I32, [_P, _P, _P]),
+    "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
+    "art_untile_gathered_strided": (_I32, [_P, _P, _U32, _U32, _P, _P]),
+    "art_untile_gathered_frames": (_I32, [_P, _P, _U32, _U32, _U32, _P, _P]),
+    "art_set_tuning": (_I32, [_P, _P]),
+    "art_timestamp_mark": (_I32, [_P, _U32]),
+    "art_timestamp_elapsed": (_I32, [_P, _P]),
+    "art_read_hits": (_I32, [_P, _P, _P, _SZ]),
+    "art_read_shadow_bits": (_I32, [_P, _P, _SZ]),
+    "art_query_closest": (_I32, [_P, _P, _U32, _P, _P]),
+    "art_query_any": (_I32, [_P, _P, _U32, _P]),
+    "art_get_lbvh": (_I32, [_P] + [_P] * 7),
+    "art_get_traversal_tree": (_I32, [_P, _P, _P, _P]),
+    "art_get_wide_nodes": (_I32, [_P, _P, _P, _SZ, _P]),
+    "art_mgpu_pending": (_I32, [_P, _P, _P]),
 }
 
 _lib = None
@@ -184,7 +187,7 @@ def load():
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C araytracingjourney_amd/csrc` (libart has no CPU fallback)")
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(PARITY_SYMBOLS.items()):
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

@@ -512,7 +512,7 @@ int32_t setup_frame(ArtContext *c) {
     uint32_t count = c->cfg.shard_count > 1 ? c->cfg.shard_count : 1, rank = count > 1 ? c->cfg.shard_rank : 0;
     c->tile_list.clear();
     std::vector<uint32_t> per(count, 0), slot_of((size_t)c->tiles_x * c->tiles_y);
-    const std::vector<uint8_t> owner_of = shard_owner_table(c->tiles_x, c->tiles_y, count);
+    const std::vector<uint8_t> owner_of = shard_owner_table(c->tiles_x, c->tiles_y, count, c->cfg.root_relief);
     for (uint32_t ty = 0; ty < c->tiles_y; ty++)
         for (uint32_t tx = 0; tx < c->tiles_x; tx++) {
             uint32_t o = owner_of[(size_t)ty * c->tiles_x + tx];
@@ -677,6 +677,7 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     if (cfg->shard_count > 1 && cfg->shard_rank >= cfg->shard_count) return fail(ART_E_INVALID, "art_create: shard_rank >= shard_count");
     if (cfg->shard_count > 255) return fail(ART_E_INVALID, "art_create: at most 255 shards");
     if (cfg->frames_in_flight > kMaxFrames) return fail(ART_E_INVALID, "art_create: at most 24 frames in flight");
+    if (cfg->root_relief > 255) return fail(ART_E_INVALID, "art_create: root_relief 0..255");
     ArtContext *c = new (std::nothrow) ArtContext();
     if (!c) return fail(ART_E_NOMEM, "art_create: out of memory");
     c->cfg = *cfg;
@@ -1241,19 +1242,15 @@ int32_t art_device_color(ArtContext *c, void **p, size_t *b) { int32_t r = dev_p
 int32_t art_device_depth(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_depth"); if (r) return r; *p = c->slot[c->last].d_depth.p + (size_t)c->read_b * c->W * c->H; if (b) *b = (size_t)c->W * c->H * 4; return ART_OK; }
 int32_t art_device_normal(ArtContext *c, void **p, size_t *b) { int32_t r = dev_ptr(c, nullptr, 0, p, b, "art_device_normal"); if (r) return r; *p = c->slot[c->last].d_normal.p + (size_t)c->read_b * c->W * c->H; if (b) *b = (size_t)c->W * c->H * 16; return ART_OK; }
 
-int32_t art_set_root_relief(uint32_t per_256) {
-    if (per_256 > 255) return fail(ART_E_INVALID, "art_set_root_relief: 0..255");
-    shard_root_relief() = per_256;
-    return ART_OK;
-}
-int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t *tiles, uint32_t cap, uint32_t *owned, uint32_t *padded) {
+int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t root_relief, uint32_t *tiles, uint32_t cap, uint32_t *owned, uint32_t *padded) {
     if (width == 0 || height == 0) return fail(ART_E_INVALID, "art_shard_layout: zero extent");
+    if (root_relief > 255) return fail(ART_E_INVALID, "art_shard_layout: root_relief 0..255");
     uint32_t count = shard_count > 1 ? shard_count : 1;
     if (shard_rank >= count) return fail(ART_E_INVALID, "art_shard_layout: shard_rank >= shard_count");
     uint32_t tx_n = (width + kTile - 1) / kTile, ty_n = (height + kTile - 1) / kTile, mine = 0;
     if (count > 255) return fail(ART_E_INVALID, "art_shard_layout: at most 255 shards");
     std::vector<uint32_t> per(count, 0);
-    const std::vector<uint8_t> owner_of = shard_owner_table(tx_n, ty_n, count);
+    const std::vector<uint8_t> owner_of = shard_owner_table(tx_n, ty_n, count, root_relief);
     for (uint32_t ty = 0; ty < ty_n; ty++)
         for (uint32_t tx = 0; tx < tx_n; tx++) {
             uint32_t o = owner_of[(size_t)ty * tx_n + tx];

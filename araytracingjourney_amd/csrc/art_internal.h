@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <utility>
 #include "../../include/art.h"
+#include "../../include/art_parity.h"
 
 namespace art {
 
@@ -213,13 +214,11 @@ void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t s
 // every group hands its tiles to the shards in a fresh pseudo-random order: each shard holds one tile of every neighbourhood (its work
 // follows the frame's cost everywhere) and no lattice can beat against the scene's regularities -- the diagonal interleave
 // (tx + 5 ty) mod count left the slowest of 8 shards 18 % above the mean on config 2 (profiles/README.md r1k).  Shares differ by <= 1 tile.
-// Root relief (art_set_root_relief): shard 0 composites besides tracing, so in `relief / 256` of the groups its tile goes to one of the other
-// shards instead (each of them in turn).  Process-wide: every rank of a job must use the same value before it creates its contexts.
-inline uint32_t &shard_root_relief() { static uint32_t per_256 = 0; return per_256; }
-inline std::vector<uint8_t> shard_owner_table(uint32_t tiles_x, uint32_t tiles_y, uint32_t count) {
+// Root relief (ArtConfig.root_relief): shard 0 composites besides tracing, so in `relief / 256` of the groups its tile goes to one of the other
+// shards instead (each of them in turn).  Every rank of a job must create its context with the same value.
+inline std::vector<uint8_t> shard_owner_table(uint32_t tiles_x, uint32_t tiles_y, uint32_t count, uint32_t relief) {
     std::vector<uint8_t> owner((size_t)tiles_x * tiles_y, 0);
     if (count <= 1) return owner;
-    const uint32_t relief = shard_root_relief();
     uint32_t relieved = 0;
     auto spread = [](uint32_t v) { v &= 0xFFFFu; v = (v | (v << 8)) & 0x00FF00FFu; v = (v | (v << 4)) & 0x0F0F0F0Fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u; return v; };
     std::vector<std::pair<uint32_t, uint32_t>> order; // (Morton key, tile)

@@ -91,6 +91,7 @@ struct ArtMgpu {
     uint32_t pend_k0 = 0, pend_n = 0;
     uint32_t newest = 0; bool have_frame = false;      // where in `frames` the most recent frame sits
     void *comm = nullptr;
+    int32_t failed = ART_OK; std::string failed_msg;   // an exchange failed: its group's frames are lost and the ranks are out of step -- every later call reports it
 };
 
 namespace {
@@ -145,6 +146,7 @@ int32_t run_exchange(ArtMgpu *m, const Group &g) {
         int rc = rccl().Gather(send, m->root ? m->gathered : nullptr, bytes, kNcclUint8, 0, m->comm, m->xs);
         if (rc != 0) return mg_fail(ART_E_HIP, std::string("ncclGather: ") + rccl().GetErrorString(rc));
     } else {
+        if (m->root) MGH(hipStreamSynchronize(m->xs)); // the un-tile of the previous group may still read `gathered`, and a hook need not order its writes behind xs (a blocking copy on the null stream does not)
         int32_t rc = m->cfg.exchange(m->cfg.exchange_user, send, bytes, m->root ? m->gathered : nullptr, 0u, m->xs);
         if (rc != 0) return mg_fail(ART_E_HIP, "art_mgpu: the host exchange function failed (" + std::to_string(rc) + ")");
     }
@@ -161,8 +163,11 @@ int32_t run_exchange(ArtMgpu *m, const Group &g) {
     return ART_OK;
 }
 
+int32_t sticky(ArtMgpu *m) { return m->failed ? mg_fail(m->failed, "art_mgpu: an earlier exchange failed (" + m->failed_msg + "); destroy this object") : ART_OK; }
+
 // submit, in order, every queued group whose frames the host can see finished; force: wait for them
 int32_t poll(ArtMgpu *m, bool force) {
+    MGA(sticky(m));
     while (!m->fifo.empty()) {
         const Group g = m->fifo.front();
         if (m->renders) {
@@ -176,7 +181,12 @@ int32_t poll(ArtMgpu *m, bool force) {
             }
         }
         m->fifo.pop_front();
-        MGA(run_exchange(m, g));
+        const int32_t r = run_exchange(m, g);
+        if (r != ART_OK) { // the group is gone and its slots will never be sent: free them, and latch the error -- a later trace must not wait for them, a flush not report success
+            for (uint32_t k = g.k0; k < g.k0 + g.n; k++) m->state[g.buf][k] = kFree;
+            m->failed = r; m->failed_msg = art_last_error();
+            return r;
+        }
     }
     return ART_OK;
 }
@@ -284,15 +294,19 @@ int32_t art_mgpu_create(ArtContext *ctx, const ArtMgpuConfig *cfg, const uint8_t
     // Ring slot, tile buffer and group boundaries follow the context's launch count, and every rank must cut its groups alike (a group is one
     // collective): whatever the caller traced before, the count starts again from zero here, on every rank.
     r = ring_rewind(ctx);
-    if (r) return bail(r);
+    if (r) { for (uint32_t k = 0; k < m->F; k++) (void)art_bind_color_tiles(ctx, k, nullptr, 0); return bail(r); }   // (bail() frees the buffers the slots were just bound to)
     *out = m;
     return ART_OK;
 }
 
 int32_t art_mgpu_trace(ArtMgpu *m) {
     if (!m) return mg_fail(ART_E_INVALID, "art_mgpu_trace: null argument");
+    MGA(sticky(m));
     const uint32_t k = (uint32_t)(m->traced % m->F), buf = (uint32_t)((m->traced / m->F) % m->NBUF);   // the ring slot and the tile buffer this launch takes (art_trace: tiles_for)
-    while (m->state[buf][k] == kQueued) MGA(poll(m, false));      // its previous contents have not even been sent: NBUF trips behind, rare
+    while (m->state[buf][k] == kQueued) {                         // its previous contents have not even been sent: NBUF trips behind, rare
+        if (m->fifo.empty()) return mg_fail(ART_E_STATE, "art_mgpu_trace: a tile buffer is queued for an exchange no group holds");   // (cannot happen; never spin on it)
+        MGA(poll(m, false));
+    }
     if (m->state[buf][k] == kSent) {
         // Gate on the HOST: the event is NBUF trips old and has almost always fired.  (A cross-stream wait queued in front of the launch would
         // cost the frames in flight their L2 contents: 115 instead of 55 us per frame on a 1/8 share, profiles/README.md r1n.)
@@ -314,6 +328,7 @@ int32_t art_mgpu_trace(ArtMgpu *m) {
 
 int32_t art_mgpu_flush(ArtMgpu *m) {
     if (!m) return mg_fail(ART_E_INVALID, "art_mgpu_flush: null argument");
+    MGA(sticky(m));
     MGA(close_group(m, true));
     MGH(hipStreamSynchronize(m->xs));
     return ART_OK;
@@ -343,6 +358,13 @@ int32_t art_mgpu_counts(ArtMgpu *m, uint64_t *launches_traced, uint64_t *gathers
     if (launches_traced) *launches_traced = m->traced;
     if (gathers) *gathers = m->gathers;
     if (launches_per_gather) *launches_per_gather = m->GB;
+    return ART_OK;
+}
+
+int32_t art_mgpu_pending(ArtMgpu *m, uint32_t *groups_queued, uint32_t *launches_open) {
+    if (!m) return mg_fail(ART_E_INVALID, "art_mgpu_pending: null argument");
+    if (groups_queued) *groups_queued = (uint32_t)m->fifo.size();
+    if (launches_open) *launches_open = m->pend_n;
     return ART_OK;
 }
 

@@ -237,12 +237,12 @@ class Model:
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
-    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, device_tree=False, fixed_waves=False, tile_output=False, tuning=None):
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, device_tree=False, fixed_waves=False, tile_output=False, tuning=None, root_relief=0):
         self._L = _lib.load()
         w, h = extent
         cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
                         flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0) | (_lib.ART_FLAG_PACKED_TILES if packed_tiles else 0) | (_lib.ART_FLAG_DEVICE_TREE if device_tree else 0) | (_lib.ART_FLAG_FIXED_WAVES if fixed_waves else 0) | (_lib.ART_FLAG_TILE_OUTPUT if tile_output else 0),
-                        frames_in_flight=frames_in_flight)
+                        frames_in_flight=frames_in_flight, root_relief=root_relief)
         self._ctx = C.c_void_p()
         check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))
         # The host tells the library how many hardware queues it asked HIP for (libart itself reads no environment variable); `tuning` picks one of the
@@ -631,6 +631,21 @@ class MultiGpu:
     def flush(self):
         check(self._L.art_mgpu_flush(self._h))
 
+    def pending(self):
+        """(groups of launches whose exchange has not been submitted yet, launches of the group still open): exchanges are submitted lazily, from later
+        launches or the flush"""
+        g, n = C.c_uint32(), C.c_uint32()
+        check(self._L.art_mgpu_pending(self._h, C.byref(g), C.byref(n)))
+        return g.value, n.value
+
+    def assert_quiescent(self, what="a control-plane collective"):
+        """The rule a host with a control plane of its own must keep (a hang of round 2: rank 0 sat in the data gather of a queued group while the others
+        had entered a broadcast of the control plane on the same gloo group): nothing of the data path may be outstanding when the ranks meet anywhere
+        else -- flush() first."""
+        g, n = self.pending()
+        if g or n:
+            raise RuntimeError(f"{what} while {g} group(s) of launches are queued for their exchange and {n} launch(es) wait in an open group: call flush() first")
+
     def counts(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
         check(self._L.art_mgpu_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
@@ -653,11 +668,6 @@ class MultiGpu:
             self.close()
         except Exception:
             pass
-
-
-def set_root_relief(per_256):
-    """process-wide, before contexts are created, the same on every rank: shard 0 gives up per_256 / 256 of its tiles (it also composites)"""
-    check(_lib.load().art_set_root_relief(int(per_256)))
 
 
 def renderer_for_scene(scene, extent, n_lights=None, **kw) -> Renderer:

@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--watchdog-seconds", type=float, default=-1.0, help="if the run has not finished after this long, every rank prints its Python stack and exits 1 (0 = off; default: off "
-                    "for one GPU, 900 for N > 1, whose exchange no machine in reach could rehearse over RCCL): a hung job "
-                    "then ends with a diagnosis instead of holding the GPU until someone kills it")
+                    "for one GPU, 300 for N > 1 -- below the 600 s after which the driver kills a bench run -- whose exchange no machine in reach could rehearse over RCCL): "
+                    "a hung job then ends with a diagnosis instead of holding the GPU until someone kills it")
     ap.add_argument("--settle-seconds", type=float, default=1.0, help="untimed set-up before the warm-up: frames are traced for at least this long (and at least 3 ring depths), so the wave plan "
                     "has settled and the GPU has left its idle clocks; 0 = the 3 ring depths only")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall clock the CPU baseline repeats the frame for (the contract: a bounded sample, ~10-30 s of CPU work)")
@@ -61,8 +61,9 @@ def parse():
     ap.add_argument("--gather-launches", type=int, default=-1, help="N>1: ring slots (launches) per exchange; 0 = the whole ring (the slots are contiguous, so a group travels as one message "
                     "per peer); default: a quarter of the timed launches, at most the ring -- a run of a few launches then still overlaps its exchanges with its tracing "
                     "instead of paying one exchange of everything behind the last frame")
+    ap.add_argument("--one-placement", action="store_true", help="N>1: time only the placement --roots names (default: both, back to back -- `value` is --roots', the other one's rate is reported beside it)")
     ap.add_argument("--roots", default="spread", choices=["spread", "rank0"],
-                    help="N>1: where frames are assembled.  'spread' (default) = frame f on rank f mod N: every group of launches is one grouped ncclSend / ncclRecv (each frame's "
+                    help="N>1: where frames are assembled (the placement `value` is measured with; the other is timed too and reported as value_rank0_root / value_spread_roots).  'spread' (default) = frame f on rank f mod N: every group of launches is one grouped ncclSend / ncclRecv (each frame's "
                          "gather, all at once), every xGMI link carries its share in both directions; 'rank0' = one ncclGather per group to rank 0, which then receives over its own "
                          "links only (2 GPUs: 12.4 MB of RGB32F tiles per 1080p frame over ONE link).  A dedicated compositor implies rank0")
     ap.add_argument("--compositor", default="shared", choices=["dedicated", "shared"],
@@ -91,7 +92,7 @@ def host_cores():
 
 def main():
     args = parse()
-    watchdog = args.watchdog_seconds if args.watchdog_seconds >= 0 else (900.0 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0.0)
+    watchdog = args.watchdog_seconds if args.watchdog_seconds >= 0 else (300.0 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0.0)
     if watchdog > 0:
         import faulthandler
         faulthandler.dump_traceback_later(watchdog, exit=True)
@@ -139,10 +140,9 @@ def main():
     renders = not (dedicated and rank == 0)
     # rank 0 also receives and un-tiles every frame: its share shrinks by 1/32 per GPU (2 GPUs: 6 %, 8 GPUs: 25 % of an equal share), which
     # is what levels its loop with the others' on the rehearsal (profiles/README.md r1n: 35.7 -> 31 us per frame at N = 8)
-    spread = world > 1 and args.roots == "spread" and not dedicated
-    relief = 0 if (world == 1 or dedicated or spread) else min(255, (8 * world if args.root_relief < 0 else args.root_relief))
-    renderer.set_root_relief(relief)
     shard = renderer.mgpu_shard(rank, world, dedicated) if world > 1 else (0, 1)
+
+    tuning = {k: (float(v) if k in ("split_alpha", "refit_rebuild_ratio") else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)} or None
 
     def make_renderer(**kw):
         if glb:   # through the real ingest: art_glb_open + art_scene_add_glb (renderer.rs:346)
@@ -157,90 +157,156 @@ def main():
             return r_
         return renderer.renderer_for_scene(sc, (W, H), **kw)
 
-    tuning = {k: (float(v) if k == "split_alpha" else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)} or None
-    r = make_renderer(device=local_rank, shard=shard, frames_in_flight=F, packed_tiles=packed, tuning=tuning)
-    B = 1                             # frames per launch
-    if (world > 1 or args.frames_per_launch > 1) and not args.ao:
-        B = args.frames_per_launch if args.frames_per_launch > 0 else next(b for b in (4, 2, 1) if args.steps % b == 0)
-        if args.steps % B:
-            raise SystemExit(f"--steps {args.steps} is not a multiple of --frames-per-launch {B}")
-        r.set_frames_per_launch(B)
-    r.upload_state()
+    def run_job(roots):               # one whole job: context (+ the sharded frame behind the C ABI), settle, warm-up, the timed region.  roots: None (one GPU) | "spread" | "rank0"
+        spread = roots == "spread"
+        relief = 0 if (world == 1 or dedicated or spread) else min(255, (8 * world if args.root_relief < 0 else args.root_relief))
+        r = make_renderer(device=local_rank, shard=shard, frames_in_flight=F, packed_tiles=packed, tuning=tuning, root_relief=relief)
+        B = 1                             # frames per launch
+        if (world > 1 or args.frames_per_launch > 1) and not args.ao:
+            B = args.frames_per_launch if args.frames_per_launch > 0 else next(b for b in (4, 2, 1) if args.steps % b == 0)
+            if args.steps % B:
+                raise SystemExit(f"--steps {args.steps} is not a multiple of --frames-per-launch {B}")
+            r.set_frames_per_launch(B)
+        r.upload_state()
 
-    # launches per exchange: explicit, or a quarter of the timed launches (libart rounds it down to a divisor of the ring)
-    gather_launches = args.gather_launches if args.gather_launches >= 0 else max(1, min(F, (args.steps // B) // 4))
-    # ---- N > 1: the sharded frame behind the C ABI -------------------------------------------------------------------------------------
-    mg, transport = None, None
-    if world > 1:
-        if args.backend == "nccl":
-            ids = [renderer.mgpu_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            mg = renderer.MultiGpu(r, rank, world, unique_id=ids[0], dedicated=dedicated, launches_per_gather=gather_launches, spread=spread)
-            transport = "RCCL inside libart (art_mgpu_*): " + ("grouped ncclSend / ncclRecv" if spread else "ncclGather")
-        else:
-            import ctypes as C
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-
-            def gloo_gather(send, nbytes, recv, root, stream):   # the collective of the rehearsal: same call sequence, payload through host memory
-                host = torch.empty(nbytes, dtype=torch.uint8)
-                assert hip.hipMemcpy(host.data_ptr(), send, nbytes, 2) == 0
-                parts = [torch.empty_like(host) for _ in range(world)] if rank == root else None
-                dist.gather(host, parts, dst=root)
-                if rank == root:
-                    for w_, part in enumerate(parts):
-                        assert hip.hipMemcpy(recv + w_ * nbytes, part.data_ptr(), nbytes, 1) == 0
-            mg = renderer.MultiGpu(r, rank, world, dedicated=dedicated, launches_per_gather=gather_launches, exchange=gloo_gather, spread=spread)
-            transport = "host function over gloo (rehearsal)"
-
-    def step():                       # one launch: B frames of this rank's share (+ its part of the exchange)
-        if mg:
-            mg.trace()
-        else:
-            r.trace()
-        if args.ao and renders:
-            r.trace_ao(args.ao)       # per tile from the local G-buffer: no extra exchange
-
-    def fence():
-        if mg:
-            mg.flush()                # every frame traced so far is on the root, un-tiled
-        r.sync()
-        torch.cuda.synchronize()
-        if world > 1:                 # the contract's bracket: barrier + synchronize (one process: the synchronize above is the bracket)
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # ---- settle (untimed set-up, like the scene build): the wave plan has sampled frames and re-planned, every stream has run -----------------
-    # ... and the GPU has left its idle clocks (tools/fenced_timeline.py).  Every rank makes the SAME number of launches (each is part of a gather):
-    # they come in rounds of 3 ring depths, and rank 0's clock decides after each round whether another one follows.
-    settle_launches, t_settle = 0, time.perf_counter()
-    while True:
-        for _ in range(3 * F):
-            step()
-        settle_launches += 3 * F
-        more = [time.perf_counter() - t_settle < args.settle_seconds]
+        # launches per exchange: explicit, or a quarter of the timed launches (libart rounds it down to a divisor of the ring)
+        gather_launches = args.gather_launches if args.gather_launches >= 0 else max(1, min(F, (args.steps // B) // 4))
+        # ---- N > 1: the sharded frame behind the C ABI -------------------------------------------------------------------------------------
+        mg, transport = None, None
         if world > 1:
-            fence()       # every gather of the round is through (they are submitted lazily, from later launches or the flush) before anyone waits on the control plane
-            dist.broadcast_object_list(more, src=0)
-        if not more[0]:
-            break
-    fence()
-    # ---- the contract: W untimed warm-up steps, then EXACTLY K steps between two fences ------------------------------------------------------
-    for _ in range((args.warmup + B - 1) // B):   # a step() is one launch = B frames
-        step()
-    fence()
-    r.collect_timings()  # drop the warm-up frames from the per-stage event sums
-    t0 = time.perf_counter()
-    for _ in range(args.steps // B):
-        step()
-    fence()
-    wall = time.perf_counter() - t0
-    stage, n_timed = r.collect_timings()  # HIP events on the frames' own streams, over the timed frames (last <= 128)
+            if args.backend == "nccl":
+                ids = [renderer.mgpu_unique_id() if rank == 0 else None]   # (a communicator of its own for every placement)
+                dist.broadcast_object_list(ids, src=0)
+                mg = renderer.MultiGpu(r, rank, world, unique_id=ids[0], dedicated=dedicated, launches_per_gather=gather_launches, spread=spread)
+                transport = "RCCL inside libart (art_mgpu_*): " + ("grouped ncclSend / ncclRecv" if spread else "ncclGather")
+            else:
+                import ctypes as C
+                hip = C.CDLL("libamdhip64.so")
+                hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+                def gloo_gather(send, nbytes, recv, root, stream):   # the collective of the rehearsal: same call sequence, payload through host memory
+                    host = torch.empty(nbytes, dtype=torch.uint8)
+                    assert hip.hipMemcpy(host.data_ptr(), send, nbytes, 2) == 0
+                    parts = [torch.empty_like(host) for _ in range(world)] if rank == root else None
+                    dist.gather(host, parts, dst=root)
+                    if rank == root:
+                        for w_, part in enumerate(parts):
+                            assert hip.hipMemcpy(recv + w_ * nbytes, part.data_ptr(), nbytes, 1) == 0
+                mg = renderer.MultiGpu(r, rank, world, dedicated=dedicated, launches_per_gather=gather_launches, exchange=gloo_gather, spread=spread)
+                transport = "host function over gloo (rehearsal)"
+
+        def control_plane(what):          # no collective of the control plane while exchanges of the data path are queued (they are submitted lazily): ranks would meet in different collectives
+            if mg:
+                mg.assert_quiescent(what)
+
+        def step():                       # one launch: B frames of this rank's share (+ its part of the exchange)
+            if mg:
+                mg.trace()
+            else:
+                r.trace()
+            if args.ao and renders:
+                r.trace_ao(args.ao)       # per tile from the local G-buffer: no extra exchange
+
+        def fence():
+            if mg:
+                mg.flush()                # every frame traced so far is on the root, un-tiled
+            r.sync()
+            torch.cuda.synchronize()
+            if world > 1:                 # the contract's bracket: barrier + synchronize (one process: the synchronize above is the bracket)
+                control_plane("the fence's barrier")
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        # ---- settle (untimed set-up, like the scene build): the wave plan has sampled frames and re-planned, every stream has run -----------------
+        # ... and the GPU has left its idle clocks (tools/fenced_timeline.py).  Every rank makes the SAME number of launches (each is part of a gather):
+        # they come in rounds of 3 ring depths, and rank 0's clock decides after each round whether another one follows.
+        settle_launches, t_settle = 0, time.perf_counter()
+        while True:
+            for _ in range(3 * F):
+                step()
+            settle_launches += 3 * F
+            more = [time.perf_counter() - t_settle < args.settle_seconds]
+            if world > 1:
+                fence()       # every gather of the round is through (they are submitted lazily, from later launches or the flush) before anyone waits on the control plane
+                control_plane("the settle round's broadcast")
+                dist.broadcast_object_list(more, src=0)
+            if not more[0]:
+                break
+        fence()
+        # ---- the contract: W untimed warm-up steps, then EXACTLY K steps between two fences ------------------------------------------------------
+        for _ in range((args.warmup + B - 1) // B):   # a step() is one launch = B frames
+            step()
+        fence()
+        r.collect_timings()  # drop the warm-up frames from the per-stage event sums
+        t0 = time.perf_counter()
+        for _ in range(args.steps // B):
+            step()
+        fence()
+        wall = time.perf_counter() - t0
+        stage, n_timed = r.collect_timings()  # HIP events on the frames' own streams, over the timed frames (last <= 128)
+
+        # ---- outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit ---------------------------
+        frame_ok = None
+        if world > 1 and (rank == 0 or spread):          # every rank that assembles frames checks the newest one it holds
+            got = mg.read_frame()
+            whole = make_renderer(device=local_rank)
+            whole.render_frame()
+            if packed:   # the assembled frame is the packed colour image: against the single GPU's (art_present packs it, vk_rt_lightning_shadows.rs:152)
+                whole.present()
+                frame_ok = bool(np.array_equal(got, whole.read_packed()[0]))
+            else:
+                frame_ok = bool(np.array_equal(got.view(np.uint32), whole.read_color().view(np.uint32)))
+            whole.close()
+        if world > 1 and spread:
+            control_plane("the frame check's all_gather")
+            oks = [None] * world
+            dist.all_gather_object(oks, frame_ok)
+            frame_ok = all(oks)
+        counts = mg.counts() if mg else None
+        st = r.stats()
+        if not renders:                   # the compositor traced nothing
+            st = dict(st, primary_rays=0, shadow_rays=0, ao_rays=0, hit_pixels=0)
+        rays_local = st["primary_rays"] + st["shadow_rays"] + st["ao_rays"]
+        if world > 1:
+            t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["frame_ms"]], dtype=torch.float64)
+            tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            wall = float(tmax[0])
+            rays_total, shadow_total = float(tsum[1]), float(tsum[2])
+            stage = dict(stage, frame_ms=float(tmax[3]))
+        else:
+            rays_total, shadow_total = float(rays_local), float(st["shadow_rays"])
+        if mg:
+            mg.close()
+        if world > 1:                     # the next placement's context gets this one's streams back (24 hardware queues in use is a 3x cliff, profiles/README.md r1k)
+            r.close()
+            r = None
+        return dict(r=r, wall=wall, stage=stage, n_timed=n_timed, frame_ok=frame_ok, counts=counts, st=st, rays_total=rays_total, shadow_total=shadow_total, B=B, transport=transport,
+                    relief=relief, spread=spread, settle_launches=settle_launches, step=step, fence=fence, value=rays_total / (wall / args.steps) / 1e6, ms_per_step=wall * 1e3 / args.steps)
+
+    if world > 1:
+        placements = [args.roots] if (dedicated or args.one_placement) else [args.roots, "rank0" if args.roots == "spread" else "spread"]
+        if dedicated:
+            placements = ["rank0"]
+    else:
+        placements = [None]
+    jobs = {}
+    for pl in placements:             # N > 1: both placements of the assembled frames back to back, each a whole job of its own (context, communicator, settle, warm-up, K timed steps)
+        jobs[pl] = run_job(pl)
+    main_job = jobs[placements[0]]
+    r, wall, stage, n_timed, frame_ok, counts, st, rays_total, shadow_total, B, transport, relief, spread, settle_launches, step, fence = (main_job[k] for k in (
+        "r", "wall", "stage", "n_timed", "frame_ok", "counts", "st", "rays_total", "shadow_total", "B", "transport", "relief", "spread", "settle_launches", "step", "fence"))
+    other = None
+    if len(placements) > 1:
+        o = jobs[placements[1]]
+        other = dict(placement=placements[1], value=o["value"], unit="Mray/s", ms_per_step=o["ms_per_step"], gathered_frame_equals_single_gpu_frame=o["frame_ok"], gathers=o["counts"]["gathers"],
+                     frames_per_exchange=o["counts"]["launches_per_gather"] * o["B"], rank0_share_of_an_equal_share=f"{256 - o['relief']}/256")
+    mg = None
 
     extras = world == 1 and not args.plain
     # ---- steady state: the same K frames with the ring kept full on both sides (device timestamps behind the last priming frame and behind frame K) ----
     steady = None
-    if extras and not args.ao:
+    if extras and not args.ao and args.steps >= 4 * F:   # (a run of fewer than four ring depths is all fill and drain: nothing steady to report)
         for _ in range(2 * F):
             r.trace()
         r.timestamp_mark(0)
@@ -278,11 +344,6 @@ def main():
             spans.sort()
             alone["single_frame_context"] = dict(median_ms=spans[30], p10_ms=spans[6], p90_ms=spans[54], frames=60, split_blocks=one.stats()["split_blocks"])
             one.close()
-
-    st = r.stats()
-    if not renders:                   # the compositor traced nothing
-        st = dict(st, primary_rays=0, shadow_rays=0, ao_rays=0, hit_pixels=0)
-    rays_local = st["primary_rays"] + st["shadow_rays"] + st["ao_rays"]
 
     # ---- a moving camera: every frame a different pose (no frame in flight shares its BVH path with its neighbours) --------------------------
     campath = None
@@ -365,36 +426,9 @@ def main():
                                      "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses")
         mv.close()
 
-    # ---- outside the timed region: the gathered frame must equal an unsharded render of the same frame, bit for bit ---------------------------
-    frame_ok = None
-    if world > 1 and (rank == 0 or spread):          # every rank that assembles frames checks the newest one it holds
-        got = mg.read_frame()
-        whole = make_renderer(device=local_rank)
-        whole.render_frame()
-        if packed:   # the assembled frame is the packed colour image: against the single GPU's (art_present packs it, vk_rt_lightning_shadows.rs:152)
-            whole.present()
-            frame_ok = bool(np.array_equal(got, whole.read_packed()[0]))
-        else:
-            frame_ok = bool(np.array_equal(got.view(np.uint32), whole.read_color().view(np.uint32)))
-        whole.close()
-    if spread:
-        oks = [None] * world
-        dist.all_gather_object(oks, frame_ok)
-        frame_ok = all(oks)
-    counts = mg.counts() if mg else None
-    if world > 1:
-        t = torch.tensor([wall, float(rays_local), float(st["shadow_rays"]), stage["frame_ms"]], dtype=torch.float64)
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        wall = float(tmax[0])
-        rays_total, shadow_total = float(tsum[1]), float(tsum[2])
-        stage = dict(stage, frame_ms=float(tmax[3]))
-    else:
-        rays_total, shadow_total = float(rays_local), float(st["shadow_rays"])
     if rank != 0:
-        if mg:
-            mg.close()
-        dist.destroy_process_group()
+        if world > 1:
+            dist.destroy_process_group()
         return
 
     ms_per_step = wall * 1e3 / args.steps
@@ -485,11 +519,10 @@ def main():
         "camera_path": campath, "moving_model": moving_model, "refit_ms": moving_model["refit_ms"] if moving_model else None,
         "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": settle_launches * B,
         "tuning": tuning, "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
+        **({("value_rank0_root" if other["placement"] == "rank0" else "value_spread_roots"): other["value"], "other_placement": other} if other else {}),
         "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(line))
-    if mg:
-        mg.close()
     if world > 1:
         dist.destroy_process_group()
 

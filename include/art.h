@@ -73,6 +73,9 @@ typedef struct ArtConfig {
     uint32_t flags;       /* ART_FLAG_* */
     uint32_t frames_in_flight; /* 0|1 = one; up to 24 (more than ~22 streams stall the command processor): a ring of per-frame streams + buffers like the reference's FrameData
                                   ring (renderer.rs:135, :300-318); art_trace then returns while up to N-1 older frames run */
+    uint32_t root_relief;      /* sharded contexts, 0..255 (default 0 = equal shares), the same on every rank of a job: shard 0 -- the rank that also receives and un-tiles
+                                  every frame when frames are assembled on rank 0 -- gives up its tile in root_relief / 256 of the tile groups to the other shards in turn, so
+                                  that its share + compositing takes as long as the others' shares (art_shard_layout takes the same value) */
 } ArtConfig;
 
 #define ART_FLAG_FAST_BUILD 2u /* traversal nodes keep the LBVH topology (PREFER_FAST_BUILD); default: binned-SAH rebuild = PREFER_FAST_TRACE, vk_model.rs:968 */
@@ -117,10 +120,6 @@ int32_t art_destroy(ArtContext *ctx);
 /* use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream.
  * Only for one frame in flight: a ring owns its streams, see art_stream_wait_frame / art_wait_external_event. */
 int32_t art_set_stream(ArtContext *ctx, void *hip_stream);
-/* graph mode: art_trace replays one captured hipGraph per ring slot (memset + 4 launches) instead of issuing them one by
- * one -- for host-bound runs (small per-GPU frames).  The capture is redone after a camera / light / extent / scene change;
- * per-stage timings are not available in this mode (only the whole frame). */
-int32_t art_set_graph_mode(ArtContext *ctx, int32_t on);
 /* Several frames per launch (1..4; default 1; the fused frame only): every art_trace then traces n frames with ONE launch -- frame b with
  * the camera cams[b] of art_set_camera_batch (art_set_camera sets all n alike) -- and a ring slot holds n frames: every per-slot output,
  * the compact tile buffer included (bind n x the single-frame size: frame b's tiles follow frame b - 1's), is n frames back to back, and
@@ -138,14 +137,6 @@ int32_t art_frames_in_flight(ArtContext *ctx, uint32_t *frames, uint32_t *next_s
  * needs no device-side wait per frame: on a GPU that keeps tracing, every hipStreamWaitEvent packet in the exchange stream took ~40 us to
  * retire, which capped a 1/7 share at 46 us per frame (profiles/README.md r1n). */
 int32_t art_frames_done(ArtContext *ctx, uint64_t first, uint32_t count, int32_t *done, uint64_t *traced);
-/* make an external stream wait (on the device) for the most recently traced frame */
-int32_t art_stream_wait_frame(ArtContext *ctx, void *hip_stream);
-/* make the NEXT art_trace wait (on the device) for an external hipEvent_t, e.g. "the gather that read this slot's tiles
- * three frames ago has finished" */
-/* art_trace + art_stream_wait_frame in one call (the per-frame host path of a sharded run); *slot_used = the ring slot the frame took */
-int32_t art_trace_for_stream(ArtContext *ctx, void *hip_stream, uint32_t *slot_used);
-int32_t art_wait_external_event(ArtContext *ctx, void *hip_event);
-
 /* add_model (renderer.rs:346) -> VkModel::create_blas geometry contract (vk_model.rs:886-943): one call per glTF
  * primitive.  idx_bytes = 2|4 (vk_model.rs:142-150); rgba8 = 3 layers albedo/ORM/normal of tw x th texels
  * (model_reader.rs:14-19); model3x4 = row-major object->world (vk_model.rs:358-363).  Data are copied. */
@@ -228,37 +219,14 @@ int32_t art_device_normal(ArtContext *ctx, void **dev_ptr, size_t *bytes);
  * the constant 1 of imageStore(vec4(rho, 1)) (raytrace.rgen.glsl:197) -- three quarters of the bytes on the links, nothing lost; the un-tile writes
  * the RGBA32F frame. */
 int32_t art_shard_tile_count(ArtContext *ctx, uint32_t *owned, uint32_t *padded);
-/* Process-wide, before any context is created, the same on every rank of a job: shard 0 (the rank that also receives and un-tiles every
- * frame) gives up its tile in per_256 / 256 of the tile groups to the other shards in turn, so that its share + compositing takes as long
- * as the others' shares.  0 (default) = equal shares.  ART_ROOT_RELIEF in the environment sets the initial value. */
-int32_t art_set_root_relief(uint32_t per_256);
-/* host-only (no device needed): the row-major ids of the tiles shard_rank owns for a width x height frame, in the
- * order they sit in its compact buffer; *owned = their number, *padded = the largest count over all shards (the
- * per-rank gather size).  tiles may be NULL to query the counts; cap = capacity of tiles. */
-int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t *tiles,
+/* host-only (no device needed): the row-major ids of the tiles shard_rank owns for a width x height frame cut for shard_count shards with
+ * ArtConfig.root_relief = root_relief, in the order they sit in its compact buffer; *owned = their number, *padded = the largest count
+ * over all shards (the per-rank gather size).  tiles may be NULL to query the counts; cap = capacity of tiles. */
+int32_t art_shard_layout(uint32_t width, uint32_t height, uint32_t shard_count, uint32_t shard_rank, uint32_t root_relief, uint32_t *tiles,
                          uint32_t cap, uint32_t *owned, uint32_t *padded);
 int32_t art_device_color_tiles(ArtContext *ctx, void **dev_ptr, size_t *bytes);
-/* render ring slot `slot`'s compact tiles straight into a caller-owned device buffer (e.g. the tensor handed to the
- * gather); bytes must equal padded * 12 KiB (4 KiB with ART_FLAG_PACKED_TILES) * frames per launch; NULL unbinds */
-int32_t art_bind_color_tiles(ArtContext *ctx, uint32_t slot, void *dev_ptr, size_t bytes);
-/* two buffers per slot: the slot's frames write them alternately (even / odd trips round the ring), so a frame never waits for the
- * exchange that is still reading the slot's previous tiles -- only for the one of two trips ago.  art_device_color_tiles and
- * art_read_color_tiles refer to the buffer the latest frame wrote. */
-int32_t art_bind_color_tiles_pair(ArtContext *ctx, uint32_t slot, void *dev_even, void *dev_odd, size_t bytes);
-/* n (1..8) buffers per slot, written in turn: trip t round the frame ring writes bufs[t % n], so a frame waits only for the exchange of n
- * trips ago.  With two, the host was found waiting at every trip boundary (the whole trip before last must have been exchanged);
- * four leave the slack a jittery exchange needs (profiles/README.md r1n). */
-int32_t art_bind_color_tiles_ring(ArtContext *ctx, uint32_t slot, void *const *bufs, uint32_t n, size_t bytes);
-int32_t art_read_color_tiles(ArtContext *ctx, void *dst, size_t bytes); /* host copy of the same buffer (tests) */
 /* frame_dev NULL = the context's colour buffer; hip_stream NULL = the latest frame's stream */
 int32_t art_untile_gathered(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, void *frame_dev, void *hip_stream);
-/* the same with shard s's tiles at gathered + s * shard_stride_tiles tiles: several frames gathered by ONE collective leave each
- * rank's frames back to back, so consecutive shards of one frame are a whole block of frames apart */
-int32_t art_untile_gathered_strided(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, void *frame_dev, void *hip_stream);
-/* n_frames frames in ONE launch (the exchange of several ring slots by one collective): frame z's tiles start z * padded tiles into
- * every shard's buffer, its image is written at frames_dev + z * width * height elements */
-int32_t art_untile_gathered_frames(ArtContext *ctx, const void *gathered_dev, uint32_t shard_count, uint32_t shard_stride_tiles, uint32_t n_frames, void *frames_dev, void *hip_stream);
-
 /* what a caller that sizes buffers around a context needs to know (the multi-GPU frame below does) */
 typedef struct ArtLayout {
     uint32_t width, height;
@@ -270,12 +238,6 @@ typedef struct ArtLayout {
     uint32_t reserved;
 } ArtLayout;
 int32_t art_get_layout(ArtContext *ctx, ArtLayout *out);
-/* two device timestamps on the frame streams (a measurement aid, e.g. "how long did frames i..j take while the ring stayed full"):
- * art_timestamp_mark(ctx, 0|1) records mark 0 / 1 behind the most recently traced frame on its stream; art_timestamp_elapsed waits for mark 1
- * and returns the time between the two. */
-int32_t art_timestamp_mark(ArtContext *ctx, uint32_t which);
-int32_t art_timestamp_elapsed(ArtContext *ctx, float *ms);
-
 /* ---- the sharded frame as one surface (new functionality, BASELINE.json north_star: "frames shard by screen tile across the 8 GPUs of one node
  * with an RCCL gather of the HDR buffer over xGMI"; the reference renders on one queue of one device, renderer.rs:188) ----------------------------
  * One process per GPU.  Every process creates its context with the shard art_mgpu_shard gives it, loads the same scene, and creates an ArtMgpu
@@ -302,7 +264,9 @@ typedef struct ArtMgpu ArtMgpu;
                                     links only (2 GPUs: a half frame of RGB32F tiles, 12.4 MB at 1080p, per frame over ONE link); spread roots use every link in both
                                     directions.  art_mgpu_device_frame / art_mgpu_read_frame then give, on every rank, the newest frame that fell to it. */
 /* must leave, ordered before anything enqueued on hip_stream afterwards, every rank's `bytes` bytes (rank order) in recv_dev on rank `root`
- * (recv_dev is NULL elsewhere); send_dev is complete when it is called.  Returns 0 or an error the library passes on as ART_E_HIP. */
+ * (recv_dev is NULL elsewhere); send_dev is complete when it is called, and nothing enqueued earlier on hip_stream still reads recv_dev (the library has
+ * waited for the un-tile of the previous group).  Returns 0 or an error the library passes on as ART_E_HIP -- after which the ArtMgpu only reports that
+ * error (frames of the failed group are lost; destroy it). */
 typedef int32_t (*ArtMgpuExchangeFn)(void *user, const void *send_dev, size_t bytes, void *recv_dev, uint32_t root, void *hip_stream);
 typedef struct ArtMgpuConfig {
     uint32_t rank, world;        /* this process; processes (= GPUs) of the job */
@@ -333,54 +297,6 @@ int32_t art_mgpu_counts(ArtMgpu *mg, uint64_t *launches_traced, uint64_t *gather
 int32_t art_mgpu_destroy(ArtMgpu *mg);
 
 int32_t art_get_stats(ArtContext *ctx, ArtStats *out);
-/* device time per stage (HIP events on the context's stream) summed over the frames traced since the previous call
- * (at most the last 128): sums_ms = primary, shade, shadow, accumulate, whole frame */
-int32_t art_collect_timings(ArtContext *ctx, float sums_ms[5], uint32_t *n_frames);
-
-/* ---- parity / debug surface (not part of the reference's API; used by tests through this C ABI) ---- */
-/* Which of the EQUIVALENT forms of the path a context runs.  All-zero = what the product runs; the other values exist so that tests can
- * show that every form gives the same frame bit for bit (tests/test_gpu_parity.py) and so that sweeps need no rebuild.  libart reads
- * nothing from the environment: a host application's environment cannot change which kernels or trees it gets.
- * Synchronises; the scene has to be built again afterwards (art_scene_build). */
-typedef struct ArtTuning {
-    uint32_t frame_form;        /* 0 one fused launch per frame (k_frame) | 1 four staged launches, packet walks | 2 four staged launches, per-ray walks */
-    uint32_t tree_builder;      /* 0 the context's default (binned SAH on the device; ART_FLAG_FAST_BUILD: LBVH topology; ART_FLAG_DEVICE_TREE: PLOC) | 1 binned SAH on the host threads */
-    uint32_t frame_waves;       /* fused frame: occupancy target per SIMD: 0 = 8 | 6 | 7 | 8 */
-    uint32_t packet_wide;       /* packet walks: 0 = default (the 128-byte 4-wide float nodes), 1 = 4-wide, 2 = the 64-byte binary nodes */
-    uint32_t primary_walk, shadow_walk, ao_walk; /* override one ray type's walk: 0 default | 8 packet | 2 per-ray binary | 4 per-ray 4-wide quantised */
-    uint32_t block_order;       /* launch order of the 256-pixel blocks: 0 XCD-aware macro-blocks of 2x2 tiles | 1 identity | n: macro-blocks of n x n tiles */
-    uint32_t fixed_waves;       /* 1: no adaptive wave plan (like ART_FLAG_FIXED_WAVES) */
-    uint32_t split_fixed_steps; /* wave plan: a fixed packet-step target instead of the adaptive one (0: adaptive) */
-    uint32_t split_min_steps;   /* wave plan: lowest target (0 = 150) */
-    float split_alpha;          /* wave plan: fraction of the launch's fair share a wave may take before its block is split (0 = 0.7) */
-    uint32_t ao_entry_off;      /* 1: AO rays start at the root instead of their pixel's entry node */
-    uint32_t trace_chunk, trace_refill, trace_blocks; /* persistent per-ray tracer (process-wide): slots per cursor pop, idle lanes that trigger a refill, resident blocks; 0 = presets */
-    uint32_t hw_queues;         /* hardware queues the HOST gave the process (GPU_MAX_HW_QUEUES; 0 = HIP's default of 4): the wave plan counts min(frames in flight, this) launches in flight */
-    uint32_t log;               /* to stderr: 1 build phase times, 2 wave-plan decisions, 4 every wave-plan poll */
-    uint32_t wide_builder;      /* the 4-wide collapse of the binary tree: 0 level by level on the device | 1 one host thread (the form the device one is tested against) */
-    uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..8 (0 = 4): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
-    float refit_rebuild_ratio;  /* art_trace rebuilds instead of refitting once ArtStats.refit_cost_ratio exceeds this (0 = 2.0; negative: never) */
-} ArtTuning;
-int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
-/* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */
-int32_t art_read_hits(ArtContext *ctx, float *tuv, int32_t *ids, size_t n_pixels);
-/* per pixel: bit i = light i shadowed, bit 16+i = shadow ray for light i traced (i < 16) */
-int32_t art_read_shadow_bits(ArtContext *ctx, uint32_t *bits, size_t n_pixels);
-/* arbitrary ray queries on the built scene.  rays: n x 8 floats (o.xyz, tmin, d.xyz, tmax), host memory. */
-int32_t art_query_closest(ArtContext *ctx, const float *rays, uint32_t n, float *tuv, int32_t *ids);
-int32_t art_query_any(ArtContext *ctx, const float *rays, uint32_t n, uint8_t *hit);
-/* the device-built binary LBVH, in the oracle's canonical form (any pointer may be NULL):
- * leaf_gid[T], keys[T], child[2*(T-1)], node_lo/hi[(T-1)*3], leaf_lo/hi[T*3] */
-int32_t art_get_lbvh(ArtContext *ctx, uint32_t *leaf_gid, uint64_t *keys, int32_t *child, float *node_lo,
-                     float *node_hi, float *leaf_lo, float *leaf_hi);
-/* the topology and node boxes the walks use over those leaves (child[2*(T-1)], node_lo/hi[3*(T-1)]): the binned-SAH tree by
- * default, the canonical tree with ART_FLAG_FAST_BUILD.  Node 0 is the root; child >= 0: internal node, < 0: ~leaf position. */
-int32_t art_get_traversal_tree(ArtContext *ctx, int32_t *child, float *node_lo, float *node_hi);
-/* the 4-wide collapse of that tree as the walks read it (new functionality: the reference's acceleration structures are opaque, vk_blas_builder.rs:88-170):
- * n_nodes records of 64 B (8-bit quantised child boxes: the per-ray walks) and of 128 B (float child boxes, children sorted along one axis: the packet
- * walks); node 0 is the root, child >= 0: node index, < 0: ~leaf position, INT32_MIN: absent (bit i of the records' valid masks clear).  Either pointer may be NULL; *n_nodes is always set. */
-int32_t art_get_wide_nodes(ArtContext *ctx, void *quantised, void *floats, size_t capacity_nodes, uint32_t *n_nodes);
-
 /* ---- GLB ingest: the step right before the path (model_reader/gltf_model_reader.rs), host only ------------------ */
 typedef struct ArtGlb ArtGlb;
 /* MeshAttributeType / TextureType bits (model_reader.rs:5-20) */

@@ -65,8 +65,14 @@ def test_one_rank_job_over_rccl_assembles_the_frame(get_scene, packed, spread):
         cams = [R.Camera((p0[0] + 0.01 * (2 * i + b), p0[1], p0[2] + 0.004 * i), r.camera_mut().dir(), w / h, r.camera_mut().fovy(), 0.1, 1000.0) for b in range(B)]
         r.set_camera_batch(cams)
         mg.trace()
+        if i == 0:                                      # the launch waits in an open group (or its group for its exchange): a control plane must not be entered now
+            assert mg.pending() != (0, 0)
+            with pytest.raises(RuntimeError, match="flush"):
+                mg.assert_quiescent()
         if i in (0, 4, 10):
             mg.flush()
+            assert mg.pending() == (0, 0)
+            mg.assert_quiescent()
             got = mg.read_frame()
             whole._camera = cams[-1]
             whole.render_frame()
@@ -88,6 +94,33 @@ def test_one_rank_job_over_rccl_assembles_the_frame(get_scene, packed, spread):
     mg.close(); r.close(); whole.close()
 
 
+@pytest.mark.gpu
+def test_a_failed_exchange_is_reported_and_latched(get_scene):
+    """a transport that fails (the host hook here; an RCCL error alike) loses its group's frames and leaves the ranks out of step: the call that submitted the
+    exchange returns the error, and so does every later trace and flush -- none reports success for frames that never arrived, none waits for the lost group"""
+    from araytracingjourney_amd import renderer as R, _lib
+    sc = get_scene("cornell")
+    r = R.renderer_for_scene(sc, (96, 64), frames_in_flight=4, tile_output=True)
+    r.upload_state()
+    calls = []
+
+    def link_down(send, nbytes, recv, root, stream):
+        calls.append(nbytes)
+        raise RuntimeError("link down")
+    mg = R.MultiGpu(r, 0, 1, launches_per_gather=2, exchange=link_down)
+    with pytest.raises(_lib.ArtError) as e:
+        for _ in range(12):
+            mg.trace()
+        mg.flush()
+    assert "exchange function failed" in str(e.value) and len(calls) == 1
+    for fn in (mg.trace, mg.flush, mg.trace):
+        with pytest.raises(_lib.ArtError) as e:
+            fn()
+        assert "earlier exchange failed" in str(e.value)
+    assert len(calls) == 1
+    mg.close(); r.close()
+
+
 def _run_job(cmd, env, seconds):
     """the job in a process group of its own: a job that hangs fails its test and is killed with all its ranks, it does not take the run with it"""
     import signal
@@ -104,23 +137,32 @@ def _run_job(cmd, env, seconds):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--gather", "packed"]), (3, ["--gather-launches", "3", "--frames-per-launch", "2"]), (2, ["--ao", "4"]),
-                                         (2, ["--roots", "rank0"]), (2, ["--roots", "rank0", "--gather", "packed"]), (3, ["--compositor", "dedicated"]), (3, ["--roots", "rank0", "--gather-launches", "3", "--frames-per-launch", "2"])],
-                         ids=["spread", "spread-packed-3", "spread-groups-of-3x2", "spread-ao", "rank0", "rank0-packed", "dedicated", "rank0-groups-of-3x2"])
+                                         (2, ["--roots", "rank0"]), (2, ["--roots", "rank0", "--gather", "packed", "--one-placement"]), (3, ["--compositor", "dedicated"]), (3, ["--roots", "rank0", "--gather-launches", "3", "--frames-per-launch", "2"])],
+                         ids=["spread", "spread-packed-3", "spread-groups-of-3x2", "spread-ao", "rank0", "rank0-packed-only", "dedicated", "rank0-groups-of-3x2"])
 def test_sharded_bench_job_of_child_processes_gathers_the_single_gpu_frame(ranks, extra):
     """bench.py as the driver launches it (torch.distributed.run, one process per rank), the ranks sharing the one GPU and the collective
     going through gloo: the C++ loop of art_mgpu_* -- tile-buffer rings, host-gated groups, un-tile -- with real concurrency, for both placements
     of the assembled frames (spread over the ranks: bench.py's default; all on rank 0); every rank that assembles frames checks the newest one
-    it holds against an unsharded render, bit for bit"""
+    it holds against an unsharded render, bit for bit.  One invocation times BOTH placements back to back -- `value` with the one --roots names, the
+    other's rate beside it -- unless --one-placement (or a dedicated compositor, which implies rank 0) says otherwise"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--detail", "0.12",
-           "--width", "640", "--height", "360", "--frames-in-flight", "6", "--settle-seconds", "0.05", "--watchdog-seconds", "150"] + extra
-    out = _run_job(cmd, env, 240)
+           "--width", "640", "--height", "360", "--frames-in-flight", "6", "--settle-seconds", "0.05", "--watchdog-seconds", "200"] + extra
+    out = _run_job(cmd, env, 300)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads(lines[0])
     assert line["gathered_frame_equals_single_gpu_frame"] is True
     assert line["n_gpus"] == ranks and line["gathers"] >= 4 and line["value"] > 0
+    if "--one-placement" in extra or "dedicated" in extra:
+        assert "other_placement" not in line
+    else:
+        first = "rank0" if "rank0" in extra else "spread"
+        other = line["other_placement"]
+        assert other["placement"] == ("spread" if first == "rank0" else "rank0") and other["gathered_frame_equals_single_gpu_frame"] is True and other["gathers"] >= 4
+        assert line["value_spread_roots" if first == "rank0" else "value_rank0_root"] == other["value"] > 0
+        assert ("rank 0 composites too" in line["config"]["parallelism"]) == (first == "rank0")
     assert ("B10G11R11" in line["config"]["parallelism"]) == ("packed" in extra) and ("RGB32F HDR" in line["config"]["parallelism"]) == ("packed" not in extra)
 
 
