@@ -42,7 +42,6 @@ template <class T> struct DevBuf {
 
 } // namespace
 
-uint32_t art::g_build_log = 0;
 void art::set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 
 // one frame in flight: its own stream and per-frame buffers, like the reference's FrameData ring (renderer.rs:135, :300-318)
@@ -320,7 +319,7 @@ int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
         harvest_cost(c);
         const float thr = c->tuning.refit_rebuild_ratio > 0.0f ? c->tuning.refit_rebuild_ratio : (c->tuning.refit_rebuild_ratio < 0.0f ? INFINITY : 2.0f);
         if (c->refit_cost_ratio > thr) {
-            if (g_build_log & 1u) std::fprintf(stderr, "[art] refit cost %.2f x the build's: building again\n", c->refit_cost_ratio);
+            if (c->tuning.log & 1u) std::fprintf(stderr, "[art] refit cost %.2f x the build's: building again\n", c->refit_cost_ratio);
             r = art_scene_build(c); // (synchronises, uploads the primitives with their current matrices, drops the versions)
             if (r == ART_OK) c->rebuilds++;
             return r;
@@ -451,7 +450,7 @@ static int32_t plan_poll(ArtContext *c) {
         next = P.level; // does not fit: a more tolerant target
     }
     const bool changed = next != P.level;
-    const int verbose = (g_build_log & 4u) ? 2 : ((g_build_log & 2u) ? 1 : 0);
+    const int verbose = (c->tuning.log & 4u) ? 2 : ((c->tuning.log & 2u) ? 1 : 0);
     if (verbose > 1) {
         size_t d = 0; uint32_t mx = 0;
         for (size_t b = 0; b < next.size(); b++) { d += next[b] != P.level[b]; mx = std::max(mx, worst[b]); }
@@ -747,8 +746,6 @@ int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     c->macro = t->block_order == 0 ? 2u : (t->block_order == 1 ? 0u : t->block_order);
     c->ao_entry = t->ao_entry_off == 0;
     c->wide_on_host = t->wide_builder == 1;
-    set_trace_tune(t->trace_chunk, t->trace_refill, t->trace_blocks);
-    g_build_log = t->log;
     c->built = false; c->frame_ready = false; c->traced = false;   // the tree and the frame layout are made again with the new choices
     return ART_OK;
 }
@@ -876,6 +873,7 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     HIPC(hipEventRecord(e0, c->main_stream()));
     hipError_t e = lbvh_build(in, c->bvh, c->main_stream());
+    c->bvh.log = c->tuning.log;
     if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "lbvh_build"); }
     if (c->fast_trace) { // PREFER_FAST_TRACE (vk_model.rs:968): the traversal nodes get a SAH-driven topology over the same leaves
         bool done = false;
@@ -1026,7 +1024,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S, uint32_t version) 
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p; a.fold_counters = c->kind_primary == 8 && c->kind_shadow == 8 && c->n_local != 0;
     const AsPtrs as = as_ptrs(c, version); // the version of the acceleration structure this launch reads
-    a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
+    a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.tune = TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
     a.n_lights = (uint32_t)c->lights.size();
     if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
     for (uint32_t i = 0; i < a.n_lights; i++) directional_constants(a.lights[i]);
@@ -1145,9 +1143,10 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     r = ensure_wide(c, c->kind_ao == 4 || (c->kind_ao == 8 && c->packet_wide)); if (r) return r;
     FrameSlot &S = c->slot[c->last];
     hipStream_t s = c->stream_of(c->last);
-    if (S.d_occl.n < (size_t)c->n_local * spp || S.d_ao.n < (size_t)c->W * c->H || S.d_ao_pix.n < 2 * (size_t)c->n_local) {
+    const size_t n_occl = (size_t)c->n_local * (((spp + 3u) >> 2) * 4u); // one byte per slot of the per-ray tracer: groups of four samples (art_trace.hip ao_slot_decode)
+    if (S.d_occl.n < n_occl || S.d_ao.n < (size_t)c->W * c->H || S.d_ao_pix.n < 2 * (size_t)c->n_local) {
         HIPC(hipStreamSynchronize(s));
-        HIPC(S.d_occl.ensure((size_t)c->n_local * spp)); HIPC(S.d_ao.ensure((size_t)c->W * c->H)); HIPC(S.d_ao_pix.ensure(2 * (size_t)c->n_local));
+        HIPC(S.d_occl.ensure(n_occl)); HIPC(S.d_ao.ensure((size_t)c->W * c->H)); HIPC(S.d_ao_pix.ensure(2 * (size_t)c->n_local));
         HIPC(hipMemset(S.d_ao.p, 0, (size_t)c->W * c->H * 4)); HIPC(hipDeviceSynchronize());
     }
     if (c->ao_tab_spp != spp) { // the sample directions in the tangent frame: a function of (sample, position in the 64x64 noise tile) only
@@ -1538,7 +1537,7 @@ int32_t art_query_closest(ArtContext *c, const float *rays, uint32_t n, float *t
     if (e == hipSuccess && (refresh_now(c) != ART_OK || ensure_wide(c, true) != ART_OK || ensure_binary(c, qkind == 2) != ART_OK)) e = hipErrorUnknown; // (a pending move is applied first)
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
-    if (e == hipSuccess) { const AsPtrs as = as_ptrs(c, c->as_cur); launch_query_closest(BvhView{c->bvh.nodes, as.wide, as.tris, qkind}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) { const AsPtrs as = as_ptrs(c, c->as_cur); launch_query_closest(BvhView{c->bvh.nodes, as.wide, as.tris, qkind, TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 16, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tris.data(), c->bvh.tris, (size_t)c->T * sizeof(DevTri), hipMemcpyDeviceToHost);
@@ -1568,7 +1567,7 @@ int32_t art_query_any(ArtContext *c, const float *rays, uint32_t n, uint8_t *hit
     if (e == hipSuccess && (refresh_now(c) != ART_OK || ensure_wide(c, true) != ART_OK || ensure_binary(c, qkind == 2) != ART_OK)) e = hipErrorUnknown;
     if (e == hipSuccess) e = c->slot[0].d_counters.ensure(kCounterWords);
     if (e == hipSuccess) e = hipMemsetAsync(c->slot[0].d_counters.p, 0, kCounterWords * 4, c->main_stream());
-    if (e == hipSuccess) { const AsPtrs as = as_ptrs(c, c->as_cur); launch_query_any(BvhView{c->bvh.nodes, as.wide, as.tris, qkind}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
+    if (e == hipSuccess) { const AsPtrs as = as_ptrs(c, c->as_cur); launch_query_any(BvhView{c->bvh.nodes, as.wide, as.tris, qkind, TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}}, d_r, n, d_h, c->slot[0].d_counters.p + 64 + 512, c->main_stream()); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipStreamSynchronize(c->main_stream());
     if (e == hipSuccess) e = hipMemcpy(h.data(), d_h, (size_t)n * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_r); (void)hipFree(d_h);

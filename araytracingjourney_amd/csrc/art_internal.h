@@ -84,6 +84,7 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevNode4 *wide;         // [n_wide] collapsed + quantised traversal structure
     DevNodeW *widef;        // [n_wide] the same topology with float boxes (packet walk)
     uint32_t n_wide;
+    uint32_t log = 0;                  // host: ArtTuning.log of the context that builds (bit 0: build phase times to stderr)
     std::vector<uint32_t> wide_levels; // host: first wide node of every level of the collapse (breadth-first numbering), then n_wide -- the refit goes through them bottom-up
     DevShadeTri *shade_tris; // [T] leaf order
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
@@ -108,8 +109,7 @@ void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, De
 void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, double *cost, hipStream_t s); // boxes bottom-up, then the quantised records + cost
 void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide /*null: cost only*/, double *cost, hipStream_t s);
 hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s);
-void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks); // art_trace.hip: persistent tracer presets (0 = default)
-extern uint32_t g_build_log;   // art_api.hip: art_set_tuning log bits (1 build phases, 2 wave plan) -- stderr, off by default
+struct TraceTune { uint32_t chunk, refill, blocks, leaf_batch; }; // overrides of the persistent per-ray tracer's presets (ArtTuning.trace_chunk / trace_refill / trace_blocks; 0 = the preset): they travel with every launch
 void lbvh_free(Lbvh &l);
 
 // float32 -> unsigned small float (5 exponent bits, MB mantissa bits), round to nearest even; negatives -> 0, overflow -> +Inf
@@ -152,6 +152,7 @@ struct FrameArgs {
     bool packet_wide;          // packet walks use the 128-byte 4-wide nodes (else the binary nodes)
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
     int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised
+    TraceTune tune;            // host: the context's overrides of the persistent tracer's presets
     // the light records travel BY VALUE with every launch, like the camera block: a frame in flight can never see a later art_set_lights
     // (a device-side table, however it is double-buffered, is overwritten while launches queued 16 frames ago still hold its address)
     ArtLight lights[kMaxLights]; uint32_t n_lights;
@@ -190,7 +191,7 @@ constexpr uint32_t kAoTableEntriesPerSample = 64 * 64;
 void launch_ao_table(uint32_t spp, float4 *tab, hipStream_t s); // tab: spp * kAoTableEntriesPerSample float4
 // pix: 2 * n_local float4 of scratch (per-pixel origin | start node, normal | noise index); tab: launch_ao_table's; entry_search: start the rays below the root
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, float4 *pix, const float4 *tab, bool entry_search, uint32_t *ao, const uint32_t *lut, hipStream_t s);
-struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevTri *tris; int kind; }; // kind: 2 | 4
+struct BvhView { const DevNode *nodes; const DevNode4 *wide; const DevTri *tris; int kind; TraceTune tune; }; // kind: 2 | 4
 void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, float4 *hits, uint32_t *cursors, hipStream_t s);
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s);
 // per-frame counter block (zeroed every frame): [64..] primary cursors, [64+256..] shadow cursors, [64+512..] query cursors,

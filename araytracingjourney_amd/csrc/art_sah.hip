@@ -215,7 +215,7 @@ struct Builder {
 hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s) {
     if (T < 3) return hipSuccess; // one node at most: nothing to choose
     const uint32_t NI = T - 1;
-    const bool log = (g_build_log & 1u) != 0;
+    const bool log = (l.log & 1u) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now();

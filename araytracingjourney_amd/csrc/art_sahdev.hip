@@ -190,7 +190,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     const uint32_t win_cap = max_ranges < kWindow ? max_ranges : kWindow;
     uint32_t *idx[2] = {nullptr, nullptr}, *range_of[2] = {nullptr, nullptr}, *cb = nullptr, *bins = nullptr, *flags = nullptr, *scan = nullptr, *n_next = nullptr;
     Range *ranges[2] = {nullptr, nullptr}; Split *splits = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
-    const bool log = (g_build_log & 1u) != 0;
+    const bool log = (l.log & 1u) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now(); auto t1 = t0, t2 = t0; uint32_t levels = 0, widest = 0;

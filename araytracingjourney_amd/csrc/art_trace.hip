@@ -115,10 +115,10 @@ constexpr int kOvfStack = 80;   // 16 + 80 >= the deepest possible radix tree (6
 constexpr int kBlock = 256;
 constexpr int kFrameBlock = 64;  // the fused frame: one wave per workgroup
 constexpr int kTraceBlock = 64;  // the persistent per-ray tracer: likewise (its waves share nothing either)
-// tunables of the persistent tracer: {chunk, refill, blocks}.  Measured on config 2 (profiles/README.md):
+// tunables of the persistent tracer: {chunk, refill, blocks, leaf_batch}.  Measured on config 2 (profiles/README.md):
 // one frame at a time is bound by the slowest wave's critical path -> small chunks, more waves; several frames in flight
-// are throughput-bound -> fewer cursor atomics, fewer resident waves.  art_set_tuning (trace_chunk / trace_refill / trace_blocks)
-// overrides both presets for sweeps.
+// are throughput-bound -> fewer cursor atomics, fewer resident waves.  A context's ArtTuning (trace_chunk / trace_refill / trace_blocks / trace_leaf_batch)
+// overrides the presets of ITS launches, for sweeps.
 struct Tune { uint32_t chunk, refill, blocks, leaf_batch; };
 // [0] / [1]: primary, shadow and query rays, one frame at a time / several in flight; [2] / [3]: AO rays likewise -- sixteen consecutive slots are one
 // pixel's rays, a refill is cheap (k_ao_pixels + k_ao_table), and the kernel fits 8 waves per SIMD: larger chunks (a wave stays on 64 neighbouring
@@ -127,15 +127,14 @@ struct Tune { uint32_t chunk, refill, blocks, leaf_batch; };
 // round 1); AO launches are throughput-bound, and a triangle test run for every lone lane was a third of their issued instructions at a tenth of the
 // lanes: 2 / 4 / 8 / 12 / 16 lanes -> 14 510 / 14 930 / 15 370 / 15 330 / 15 070 Mray/s on config 5
 static const Tune kPreset[4] = {{64, 12, 1536, 1}, {128, 24, 1024, 1}, {256, 16, 2048, 8}, {1024, 24, 2048, 8}};
-static Tune g_tune[4] = {kPreset[0], kPreset[1], kPreset[2], kPreset[3]};
-static const Tune &tune(bool pipelined, bool ao = false) { return g_tune[(ao ? 2 : 0) + (pipelined ? 1 : 0)]; }
-void set_trace_tune(uint32_t chunk, uint32_t refill, uint32_t blocks) {
-    for (int k = 0; k < 4; k++) {
-        g_tune[k] = kPreset[k];
-        if (chunk >= 64 && chunk <= 65536) g_tune[k].chunk = chunk;
-        if (refill >= 1 && refill <= 64) g_tune[k].refill = refill;
-        if (blocks >= 1 && blocks <= 16384) g_tune[k].blocks = blocks;
-    }
+// the preset for a launch, with the context's overrides (they travel with the launch: nothing process-wide)
+static Tune tune(bool pipelined, bool ao, const TraceTune &o) {
+    Tune t = kPreset[(ao ? 2 : 0) + (pipelined ? 1 : 0)];
+    if (o.chunk >= 64 && o.chunk <= 65536) t.chunk = o.chunk;
+    if (o.refill >= 1 && o.refill <= 64) t.refill = o.refill;
+    if (o.blocks >= 1 && o.blocks <= 16384) t.blocks = o.blocks;
+    if (o.leaf_batch >= 1 && o.leaf_batch <= 64) t.leaf_batch = o.leaf_batch;
+    return t;
 }
 constexpr int kCursorStride = 32; // one 128-byte line per XCD cursor
 
@@ -257,7 +256,9 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
 // test of every enclosing box (monotone slab), so the packet finds exactly the per-ray answer, bit for bit.
 constexpr int kPacketStack = 288; // shared stack of node references per wave: >= 3 pending siblings per level * 95 levels // a shared stack of node references per wave; the radix tree is at most 95 levels deep
 enum { PK_PRIMARY = 0, PK_SHADOW = 1, PK_AO = 2 };
-struct PacketArgs { const uint8_t *dummy; uint32_t spp; float ao_radius; uint8_t *occl; }; // AO extras
+struct PacketArgs { const uint8_t *dummy; uint32_t spp; float ao_radius; uint8_t *occl; const float4 *ao_pix, *ao_tab; }; // AO extras (per-pixel records of k_ao_pixels, sample table of k_ao_table)
+__device__ __forceinline__ bool ao_slot_decode(uint32_t slot, uint32_t spp, uint32_t &p, uint32_t &j);
+__device__ __forceinline__ V3 ao_dir(V3 N, float tx, float ty, float tz);
 
 __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float depth, float4 nm, uint32_t smp, V3 &o, V3 &d);
 
@@ -410,13 +411,13 @@ __device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, 
 // MODE PK_PRIMARY: slot = local pixel (a wave = one 8x8 block), closest hit -> hits[].
 // MODE PK_SHADOW:  slot = light * n_local + local pixel (the dense shadow-ray slots of k_shade: the same 8x8 block, rays towards
 //                  one light), any hit -> the slot's contribution keeps 0.05.  A lane leaves the packet at its first hit.
-// MODE PK_AO:      slot = local pixel * spp + sample (short rays around a few neighbouring points), any hit -> occl[].
+// MODE PK_AO:      the AO launch's slots (ao_slot_decode): a wave = sixteen neighbouring pixels x the four samples of one azimuth quadrant, any hit -> occl[].
 template <int MODE, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
     constexpr bool ANY = MODE != PK_PRIMARY;
     __shared__ int wstack[(kBlock / 64) * kPacketStack];
     int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
-    const uint32_t total = MODE == PK_PRIMARY ? a.n_local : (MODE == PK_SHADOW ? a.n_local * a.n_lights : a.n_local * x.spp);
+    const uint32_t total = MODE == PK_PRIMARY ? a.n_local : (MODE == PK_SHADOW ? a.n_local * a.n_lights : (a.n_local / 16u) * (((x.spp + 3u) >> 2) * 64u));
     // primary / shadow: the launch order of the 256-pixel blocks is XCD-aware (a.block_order); shadow slots are [light][pixel]
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (MODE != PK_AO) {
@@ -440,12 +441,12 @@ __global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
         float4 r1 = on ? ld_nt(&a.shadow_rays[2 * (size_t)slot + 1]) : make_float4(0.f, 0.f, 1.f, 0.f);
         ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), 0.01f, on ? r0.w : 1.0f);
     } else {
-        uint32_t p = slot / x.spp, smp = slot - p * x.spp, px = 0, py = 0;
-        bool in = slot < total && local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, px, py);
-        float depth = in ? a.depth[(size_t)py * a.W + px] : 10000.0f;
-        on = depth < 10000.0f;
-        V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
-        if (on) ao_ray(a.cam, a.W, a.H, px, py, depth, a.normal[(size_t)py * a.W + px], smp, o, d);
+        uint32_t p = 0, smp = 0;   // smp: the sample's rank in the pixel's azimuth order (k_ao_table)
+        const bool real = slot < total && ao_slot_decode(slot, x.spp, p, smp);
+        float4 po = real ? x.ao_pix[2 * (size_t)p] : make_float4(0.f, 0.f, 0.f, __int_as_float((int)0x80000000));
+        on = __float_as_int(po.w) != (int)0x80000000;   // kAoNothingNear: a padding slot, a miss pixel, nothing within the radius
+        V3 o = mk(po.x, po.y, po.z), d = mk(0.f, 0.f, 1.f);
+        if (on) { float4 pn = x.ao_pix[2 * (size_t)p + 1]; float4 t = x.ao_tab[smp * (64u * 64u) + __float_as_uint(pn.w)]; d = ao_dir(mk(pn.x, pn.y, pn.z), t.x, t.y, t.z); }
         ray_init(r, o, d, x.ao_radius * 0.01f, x.ao_radius);
     }
     const bool traced = on;
@@ -533,12 +534,42 @@ __device__ __forceinline__ void ao_ray(const CameraArg &cam, uint32_t W, uint32_
     d = ao_dir(N, tx, ty, tz);
 }
 constexpr uint32_t kAoNoiseTile = 64 * 64; // the sample table has one entry per (sample, Hilbert index in the 64x64 tile)
+// tab[j * 4096 + hil] = the tangent-frame direction of the pixel's j-th sample IN AZIMUTH ORDER (the R2 sequence's second coordinate, ties by sample index): a
+// pixel's occlusion count is a sum over its samples, so their order is free -- and with it the tracer can put the samples of one azimuth quadrant of
+// neighbouring pixels (similar normals, similar frames) into one wave: rays that leave in similar directions make similar walks (ao_slot_decode below).
 __global__ __launch_bounds__(kBlock) void k_ao_table(uint32_t spp, float4 *__restrict__ tab) {
-    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= spp * kAoNoiseTile) return;
-    float tx, ty, tz;
-    ao_sample(i % kAoNoiseTile, i / kAoNoiseTile, tx, ty, tz);
-    tab[i] = make_float4(tx, ty, tz, 0.f);
+    uint32_t hil = blockIdx.x * kBlock + threadIdx.x;
+    if (hil >= kAoNoiseTile) return;
+    float key[64]; uint8_t idx[64];
+    for (uint32_t s = 0; s < spp; s++) {
+        float fi = (float)(hil + 288u * s), v2 = 0.5f + fi * 0.56984029099805327f;   // ao_sample's u2
+        float k = v2 - floorf(v2);
+        uint32_t at = s;
+        while (at > 0 && key[at - 1] > k) { key[at] = key[at - 1]; idx[at] = idx[at - 1]; at--; }   // insertion keeps equal keys in sample order
+        key[at] = k; idx[at] = (uint8_t)s;
+    }
+    for (uint32_t j = 0; j < spp; j++) {
+        float tx, ty, tz;
+        ao_sample(hil, idx[j], tx, ty, tz);
+        tab[(size_t)j * kAoNoiseTile + hil] = make_float4(tx, ty, tz, 0.f);
+    }
+}
+// The AO launch's slots.  Sixteen pixels -- one 4x4 quadrant of an 8x8 block -- own ceil(spp / 4) * 64 consecutive slots laid out
+// [group of four samples in azimuth order][pixel][sample of the group]: the 64 slots a wave takes at a time are sixteen neighbouring pixels x the four samples of
+// one azimuth quadrant.  (Round 2's order, [pixel][sample], put a pixel's whole hemisphere into sixteen neighbouring lanes: 55 % of the lanes of a vector
+// instruction were active; this order: 61 %, 7 % fewer instructions.)  Slots past spp (spp not a multiple of four) are padding: no ray, occlusion byte 0.
+__device__ __forceinline__ uint32_t ao_slots_per16(uint32_t spp) { return ((spp + 3u) >> 2) * 64u; }
+__device__ __forceinline__ bool ao_slot_decode(uint32_t slot, uint32_t spp, uint32_t &p, uint32_t &j) {
+    const uint32_t per16 = ao_slots_per16(spp), b16 = slot / per16, r = slot - b16 * per16;
+    const uint32_t pi = (r >> 2) & 15u, q = b16 & 3u;
+    const uint32_t x = (pi & 3u) + ((q & 1u) << 2), y = (pi >> 2) + ((q >> 1) << 2);
+    p = (b16 >> 2) * 64u + y * 8u + x;    // local pixel: an 8x8 block is 64 consecutive local pixels, lane = y * 8 + x
+    j = (r >> 6) * 4u + (r & 3u);
+    return j < spp;
+}
+__device__ __forceinline__ size_t ao_slot_of(uint32_t p, uint32_t j, uint32_t spp) {
+    const uint32_t lane = p & 63u, x = lane & 7u, y = lane >> 3, q = (x >> 2) | ((y >> 2) << 1), pi = (x & 3u) | ((y & 3u) << 2);
+    return (size_t)((p >> 6) * 4u + q) * ao_slots_per16(spp) + (j >> 2) * 64u + pi * 4u + (j & 3u);
 }
 
 // AO rays are short: the 16 rays of a pixel stay inside a ball of the AO radius around one point.  Descend the 4-wide tree while
@@ -602,7 +633,7 @@ struct TraceArgs {
     const float4 *rays;
     float4 *contrib; uint32_t n_local; uint32_t *shadow_bits;
     uint32_t *any_out;
-    // MODE_AO: rays are generated from the frame's depth + view-space normal outputs (XeGTAO's inputs); slot = local pixel * spp + sample
+    // MODE_AO: rays are generated from the frame's depth + view-space normal outputs (XeGTAO's inputs); slot -> (local pixel, sample): ao_slot_decode
     const float *depth; const float4 *normal; uint32_t spp; float ao_radius; uint8_t *occl;
     const float4 *ao_pix;     // MODE_AO: per local pixel, origin | start node and world normal | Hilbert index (k_ao_pixels)
     const float4 *ao_tab;     // MODE_AO: [sample][Hilbert index] tangent-frame direction (k_ao_table)
@@ -668,10 +699,11 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
                     } else if (MODE == MODE_AO) {
                         // everything but the direction was made once per pixel (k_ao_pixels), the direction's tangent-frame part once per context (k_ao_table):
                         // a refill is three 16-byte loads, a frame from the normal and ray_init -- cheap enough to refill at few idle lanes
-                        uint32_t p = sidx / a.spp, smp = sidx - p * a.spp;
-                        float4 po = a.ao_pix[2 * (size_t)p];
+                        uint32_t p, smp;                               // smp: the sample's rank in the pixel's azimuth order (k_ao_table)
+                        const bool real = ao_slot_decode(sidx, a.spp, p, smp);
+                        float4 po = real ? a.ao_pix[2 * (size_t)p] : make_float4(0.f, 0.f, 0.f, __int_as_float(kAoNothingNear));
                         int entry = __float_as_int(po.w);
-                        if (entry == kAoNothingNear) a.occl[sidx] = 0; // a miss pixel, or no box within the AO radius: unoccluded, nothing to trace
+                        if (entry == kAoNothingNear) a.occl[sidx] = 0; // a padding slot, a miss pixel, or no box within the AO radius: unoccluded, nothing to trace
                         else {
                             float4 pn = a.ao_pix[2 * (size_t)p + 1];
                             float4 t = a.ao_tab[smp * kAoNoiseTile + __float_as_uint(pn.w)];
@@ -1160,8 +1192,8 @@ static inline uint32_t persistent_blocks(uint32_t total, const Tune &t) {
     uint32_t need = (total + kTraceBlock - 1) / kTraceBlock, cap = t.blocks * (kBlock / kTraceBlock);   // the presets count 256-thread blocks
     return need < cap ? (need ? need : 1u) : cap;
 }
-template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipelined, hipStream_t s) {
-    const Tune &t = tune(pipelined, MODE == MODE_AO);
+template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipelined, const TraceTune &o, hipStream_t s) {
+    const Tune t = tune(pipelined, MODE == MODE_AO, o);
     uint32_t nb = persistent_blocks(a.total, t);
     a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = t.leaf_batch;
     if (kind == 4) k_trace<MODE, 4><<<nb, kTraceBlock, 0, s>>>(a);
@@ -1172,7 +1204,7 @@ void launch_primary(const FrameArgs &f, hipStream_t s) {
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
-    launch_trace<MODE_PRIMARY>(a, f.trace_kind[0], f.pipelined, s);
+    launch_trace<MODE_PRIMARY>(a, f.trace_kind[0], f.pipelined, f.tune, s);
 }
 void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 void launch_shadow(const FrameArgs &f, hipStream_t s) {
@@ -1181,7 +1213,7 @@ void launch_shadow(const FrameArgs &f, hipStream_t s) {
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
-    launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, s);
+    launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, f.tune, s);
 }
 template <bool WIDE, bool ONE_LIGHT> static void launch_frame_form(const FrameArgs &a, uint32_t g, bool count, hipStream_t s) {
     if (a.batch > 1) { // several frames per launch
@@ -1212,13 +1244,13 @@ void launch_query_closest(const BvhView &b, const float4 *rays, uint32_t n, floa
     if (!n) return;
     TraceArgs a{};
     a.nodes = b.nodes; a.wide = b.wide; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.hits = hits;
-    launch_trace<MODE_QUERY_CLOSEST>(a, b.kind, false, s);
+    launch_trace<MODE_QUERY_CLOSEST>(a, b.kind, false, b.tune, s);
 }
 void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t *hit, uint32_t *cursors, hipStream_t s) {
     if (!n) return;
     TraceArgs a{};
     a.nodes = b.nodes; a.wide = b.wide; a.tris = b.tris; a.total = n; a.cursors = cursors; a.rays = rays; a.any_out = hit;
-    launch_trace<MODE_QUERY_ANY>(a, b.kind, false, s);
+    launch_trace<MODE_QUERY_ANY>(a, b.kind, false, b.tune, s);
 }
 // AO resolve: occluded count -> uint(pow(visibility, 2.2) * 255 + 0.5) through a host-built table; 255 where nothing was hit
 #ifdef ART_PHASE_PROF
@@ -1230,31 +1262,32 @@ extern "C" int32_t art_debug_phase(uint32_t *out, int32_t reset) { // out[8][2^1
 }
 #endif
 struct AoLut { uint32_t v[65]; };
-__global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_t *__restrict__ occl, uint32_t spp, AoLut lut, uint32_t *__restrict__ ao) {
+__global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_t *__restrict__ occl, uint32_t spp, AoLut lut, uint32_t *__restrict__ ao) { // occl: one byte per slot (ao_slot_of)
     uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= a.n_local) return;
     uint32_t x, y;
     if (!local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y)) return;
     size_t pix = (size_t)y * a.W + x;
     uint32_t k = 0;
-    for (uint32_t s = 0; s < spp; s++) k += occl[(size_t)p * spp + s];
+    for (uint32_t s = 0; s < spp; s++) k += occl[ao_slot_of(p, s, spp)];
     ao[pix] = a.depth[pix] < 10000.0f ? lut.v[k] : 255u;
 }
-void launch_ao_table(uint32_t spp, float4 *tab, hipStream_t s) { k_ao_table<<<blocks_for(spp * kAoNoiseTile), kBlock, 0, s>>>(spp, tab); }
+void launch_ao_table(uint32_t spp, float4 *tab, hipStream_t s) { k_ao_table<<<blocks_for(kAoNoiseTile), kBlock, 0, s>>>(spp, tab); }
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, float4 *pix, const float4 *tab, bool entry_search, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
     AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
-    if (f.trace_kind[2] == 8) { // measured 2x slower than the per-ray walk (incoherent directions): off by default
-        PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl;
-        if (f.packet_wide) k_packet<PK_AO, true><<<blocks_for(f.n_local * spp), kBlock, 0, s>>>(f, x); else k_packet<PK_AO, false><<<blocks_for(f.n_local * spp), kBlock, 0, s>>>(f, x);
+    k_ao_pixels<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, (f.trace_kind[2] == 4 && entry_search) ? f.wide : nullptr, radius, pix); // one point, normal and entry node per pixel for its spp rays
+    const uint32_t n_slots = (f.n_local / 16u) * (((spp + 3u) >> 2) * 64u); // ao_slot_decode
+    if (f.trace_kind[2] == 8) { // the packet walk (sixteen neighbouring pixels x one azimuth quadrant per wave, from the root): measured 2x slower than the per-ray walk, before and after the regrouping -- off by default
+        PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl; x.ao_pix = pix; x.ao_tab = tab;
+        if (f.packet_wide) k_packet<PK_AO, true><<<blocks_for(n_slots), kBlock, 0, s>>>(f, x); else k_packet<PK_AO, false><<<blocks_for(n_slots), kBlock, 0, s>>>(f, x);
         k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
         return;
     }
     TraceArgs a{};
-    a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local * spp; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
+    a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = n_slots; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
-    k_ao_pixels<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, (f.trace_kind[2] == 4 && entry_search) ? f.wide : nullptr, radius, pix); // one point, normal and entry node per pixel for its spp rays
     a.ao_pix = pix; a.ao_tab = tab;
-    launch_trace<MODE_AO>(a, f.trace_kind[2], f.pipelined, s);
+    launch_trace<MODE_AO>(a, f.trace_kind[2], f.pipelined, f.tune, s);
     k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
 void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {

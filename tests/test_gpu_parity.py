@@ -357,7 +357,7 @@ def test_wide_collapse_on_the_device_equals_the_host_loop(R, get_scene, name, de
     dev.close(); host.close()
 
 
-@pytest.mark.parametrize("walk", [0, 2], ids=["default", "binary"])
+@pytest.mark.parametrize("walk", [0, 2, 8], ids=["default", "binary", "packet"])
 @pytest.mark.parametrize("name,detail,size,spp", [("cornell", 1.0, (256, 256), 16), ("sponza_like", 0.12, (480, 270), 16), ("sponza_like", 0.12, (200, 120), 5)])
 def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp, walk):
     """BASELINE config 5's pass: AO rays from the frame's depth + normal outputs; the 0..255 output is an integer: bit-exact"""
