@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libart.so")
+LIB_PATH = os.environ.get("ART_LIB_PATH") or os.path.join(_HERE, "libart.so")   # ART_LIB_PATH: another build of the same sources, for A/B measurements (tools/); libart itself reads no environment
 
 ART_OK, ART_E_INVALID, ART_E_STATE, ART_E_NO_DEVICE, ART_E_HIP, ART_E_NOMEM = 0, -1, -2, -3, -4, -5
 ART_FLAG_KEEP_DEBUG = 1

@@ -238,6 +238,11 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
             h[i] = slab(this->r, lx, ly, lz, hx, hy, hz, this->tbest, te[i]) && ((mask >> i) & 1u);
         }
         float tn = 3.0e38f; int ni = -1; // continue with the nearest hit child, stack the others
+        if (ANY) { // an any-hit ray's answer does not depend on the order of its visits, only how soon a hit ends it: the first hit child in the node's own order (the
+                   // children are sorted along an axis) instead of the nearest saves the selection chain -- config 5 15 650 -> 16 440 Mray/s (profiles/README.md r4)
+#pragma unroll
+            for (int i = 3; i >= 0; i--) if (h[i]) ni = i;
+        } else
 #pragma unroll
         for (int i = 0; i < 4; i++) if (h[i] && te[i] < tn) { tn = te[i]; ni = i; }
         if (ni < 0) return this->pop(lds, ovf);
