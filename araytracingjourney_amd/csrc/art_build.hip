@@ -299,7 +299,7 @@ static hipError_t wide_build_host(Lbvh &l, uint32_t T, hipStream_t s) {
         }
         uint32_t mask = 0;
         for (int i = 0; i < 4; i++) {
-            if (i >= nc) { d.child[i] = kAbsentChild; dw.child[i] = kAbsentChild; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; } continue; } // an absent child: a point box out at 3e38 -- every axis' entry
+            if (i >= nc) { d.child[i] = kAbsentChild; dw.child[i] = kAbsentChild; for (int k = 0; k < 3; k++) { dw.box[i][k] = 3.0e38f; dw.box[i][3 + k] = 3.0e38f; d.q[k] |= 255u << (8 * i); } continue; } // an absent child: its quantised box is INVERTED (lo planes 255, hi planes 0: the per-ray walk's sign-selected slab enters it after it has left it, whatever the direction); its float box a point box out at 3e38 -- every axis' entry
             // and exit distance is +-huge with the SAME sign, so neither the octant-specialised nor the general slab test lets a finite ray in (an INVERTED box passes the general one);
             // its reference is the walks' "pop" value, so a ray that passes every box (NaN: fminf / fmaxf drop a NaN operand) still cannot leave the node array
             mask |= 1u << i;
@@ -395,6 +395,7 @@ __device__ inline void wide_quantise(const float *const lo[4], const float *cons
         ebits[k] = (uint32_t)(e + 127);
     }
     uint32_t mask = 0;
+    for (int i = nc; i < 4; i++) for (int k = 0; k < 3; k++) d.q[k] |= 255u << (8 * i); // an absent child: an inverted box (lo planes 255, hi planes 0), which the per-ray walk's sign-selected slab never enters
     for (int i = 0; i < nc; i++) {
         mask |= 1u << i;
         for (int k = 0; k < 3; k++) {

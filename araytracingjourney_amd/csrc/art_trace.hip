@@ -228,14 +228,24 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
         uint4 a = nq[0], b = nq[1], c = nq[2], d = nq[3];
         float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
         float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
-        uint32_t mask = a.w >> 24;
         int refs[4] = {(int)d.x, (int)d.y, (int)d.z, (int)d.w};
         float te[4]; bool h[4];
+        // The slab with the entry plane of each axis chosen by the lane's direction sign -- ONE select per axis picks the word that holds the four children's near
+        // planes, one the far planes -- instead of min / max of both planes per child: fma is monotone in the plane coordinate, so min(t0, t1) IS the near plane's
+        // t for a box with lo <= hi, bit for bit (the packet walks' octant trick, per lane).  An absent child carries an inverted box (art_build.hip): whatever the
+        // signs it is left before it is entered, so no valid-mask test.  33 -> 22 vector instructions a child; config 5 16 440 -> ... Mray/s (profiles/README.md r4).
+        const Ray &r = this->r;
+        const bool ngx = r.inv.x < 0.0f, ngy = r.inv.y < 0.0f, ngz = r.inv.z < 0.0f;
+        const uint32_t nxw = ngx ? b.w : b.x, fxw = ngx ? b.x : b.w, nyw = ngy ? c.x : b.y, fyw = ngy ? b.y : c.x, nzw = ngz ? c.y : b.z, fzw = ngz ? b.z : c.y;
+        const float lim = this->tbest;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            float lx = fmaf((float)((b.x >> (8 * i)) & 255u), sx, ox), ly = fmaf((float)((b.y >> (8 * i)) & 255u), sy, oy), lz = fmaf((float)((b.z >> (8 * i)) & 255u), sz, oz);
-            float hx = fmaf((float)((b.w >> (8 * i)) & 255u), sx, ox), hy = fmaf((float)((c.x >> (8 * i)) & 255u), sy, oy), hz = fmaf((float)((c.y >> (8 * i)) & 255u), sz, oz);
-            h[i] = slab(this->r, lx, ly, lz, hx, hy, hz, this->tbest, te[i]) && ((mask >> i) & 1u);
+            float tnx = fmaf(fmaf((float)((nxw >> (8 * i)) & 255u), sx, ox), r.inv.x, -r.ood.x), tfx = fmaf(fmaf((float)((fxw >> (8 * i)) & 255u), sx, ox), r.inv.x, -r.ood.x);
+            float tny = fmaf(fmaf((float)((nyw >> (8 * i)) & 255u), sy, oy), r.inv.y, -r.ood.y), tfy = fmaf(fmaf((float)((fyw >> (8 * i)) & 255u), sy, oy), r.inv.y, -r.ood.y);
+            float tnz = fmaf(fmaf((float)((nzw >> (8 * i)) & 255u), sz, oz), r.inv.z, -r.ood.z), tfz = fmaf(fmaf((float)((fzw >> (8 * i)) & 255u), sz, oz), r.inv.z, -r.ood.z);
+            float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);
+            te[i] = tn;
+            h[i] = fmaxf(tn, r.tmin) <= fminf(tf, lim);
         }
         float tn = 3.0e38f; int ni = -1; // continue with the nearest hit child, stack the others
         if (ANY) { // an any-hit ray's answer does not depend on the order of its visits, only how soon a hit ends it: the first hit child in the node's own order (the
@@ -644,6 +654,15 @@ struct TraceArgs {
     const float4 *ao_tab;     // MODE_AO: [sample][Hilbert index] tangent-frame direction (k_ao_table)
 };
 
+#ifdef ART_TRACE_PROF
+// profiling build only (make EXTRA=-DART_TRACE_PROF; tools/trace_prof.py): what the iterations of the persistent tracer's waves are made of, summed over the waves of every launch since
+// the last reset: [0] loop iterations, [1] iterations with a node step, [2] lanes in them, [3] iterations with a triangle step, [4] lanes in them, [5] iterations with a refill, [6] lanes
+// refilled (= rays), [7] lanes with a ray summed over all iterations
+__device__ unsigned long long g_trace_prof[8];
+#define TPROF(i, n) prof_[i] += (n)
+#else
+#define TPROF(i, n)
+#endif
 // Persistent-threads wavefront tracer.  Each wave keeps up to 64 rays in flight; when kRefill or more lanes have
 // finished it compacts the idle lanes with __ballot / mbcnt and hands them the next candidates of its chunk; chunks
 // come from eight per-XCD work cursors (one returning atomic per chunk), so neighbouring rays stay on one XCD's L2.
@@ -664,8 +683,12 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
     bool exhausted = false, active = false;
     typename std::conditional<WIDTH == 4, Trav4<ANY>, Trav<ANY>>::type tr;
     uint32_t slot = 0, traced = 0;
+#ifdef ART_TRACE_PROF
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
         uint64_t idle = __ballot(!active);
+        TPROF(0, 1); TPROF(7, 64 - __popcll(idle));
         uint32_t n_idle = (uint32_t)__popcll(idle);
         if (!exhausted && n_idle >= a.refill) {
             if (cur == end) { // take the next chunk: lane 0 pops, everyone learns the result
@@ -728,6 +751,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
                     }
                     if (active) { slot = sidx; traced++; }
                 }
+                TPROF(5, 1); TPROF(6, __popcll(__ballot(active) & idle));
                 cur += min(n_idle, avail);
             }
             if (__ballot(active) == 0ull) continue; // nothing to trace yet: fetch again (or find the cursors exhausted)
@@ -737,6 +761,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
         }
         // one internal step for every lane standing on a node ...
         bool done = false;
+        { uint64_t nm_ = __ballot(active && tr.cur >= 0); if (nm_) { TPROF(1, 1); TPROF(2, __popcll(nm_)); } }
         if (active && tr.cur >= 0) {
             if constexpr (WIDTH == 4) done = tr.step_internal(a.wide, lds, ovf);
             else done = tr.step_internal(a.nodes, lds, ovf);
@@ -745,6 +770,7 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
         bool on_leaf = active && !done && tr.cur < 0;
         uint64_t lm = __ballot(on_leaf);
         if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_batch || __ballot(active && !done && tr.cur >= 0) == 0ull)) {
+            TPROF(3, 1); TPROF(4, __popcll(lm));
             if (on_leaf) done = tr.step_leaf(a.tris, lds, ovf);
         }
         if (done) {
@@ -761,6 +787,9 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
             }
         }
     }
+#ifdef ART_TRACE_PROF
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_trace_prof[i], prof_[i]);
+#endif
     if (MODE == MODE_SHADOW && a.count) { // rays this wave traced: one atomic per wave
         for (int off = 32; off >= 1; off >>= 1) traced += (uint32_t)__shfl_xor((int)traced, off);
         if (lane == 0 && traced) atomicAdd(a.count + (blockIdx.x % kSlotCount) * kSlotStride, traced);   // one wave per workgroup
@@ -1258,6 +1287,14 @@ void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t
     launch_trace<MODE_QUERY_ANY>(a, b.kind, false, b.tune, s);
 }
 // AO resolve: occluded count -> uint(pow(visibility, 2.2) * 255 + 0.5) through a host-built table; 255 where nothing was hit
+#ifdef ART_TRACE_PROF
+extern "C" int32_t art_debug_trace_prof(unsigned long long *out, int32_t reset) { // out[8]
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace_prof), sizeof(g_trace_prof)) != hipSuccess) return -1;
+    void *dp = nullptr;
+    if (reset && (hipGetSymbolAddress(&dp, HIP_SYMBOL(g_trace_prof)) != hipSuccess || hipMemset(dp, 0, sizeof(g_trace_prof)) != hipSuccess)) return -1;
+    return 0;
+}
+#endif
 #ifdef ART_PHASE_PROF
 extern "C" int32_t art_debug_phase(uint32_t *out, int32_t reset) { // out[8][2^18]
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase)) != hipSuccess) return -1;
