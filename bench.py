@@ -470,23 +470,56 @@ def main():
             f"GPU ray counts differ from the oracle's: {st['shadow_rays']}/{st['hit_pixels']} vs {ost['shadow_rays']}/{ost['hit_pixels']}"
 
     # ---- roofline (tools/roofline.py re-derives every number below from profiles/) -------------------------------------------------------------
+    # Which roof binds a launch is a MEASURED statement: instruction and traffic counts come from a committed rocprofv3 --pmc pass of this very workload
+    # (profiles/current_pmc.json, keyed by workload: PMC counters cannot be read from inside the benchmarked process).  Without one -- another extent,
+    # a .glb, N > 1 -- the line carries the algorithmic fractions only and says bound: null; it never guesses "hbm".
     roof = None
-    if ost is not None and st.get("frame_launches") == 1:
+    workload = workload_name(sc, glb, W, H, lights, shadow_total, args)
+    cur_path = os.path.join(ROOT, "profiles", "current_pmc.json")
+    cur = json.load(open(cur_path)) if os.path.exists(cur_path) else {}
+    entry = (cur.get("workloads") or {}).get(workload) if world == 1 else None
+    pmc = entry["pmc"] if entry else {}
+    if args.ao and world == 1 and st.get("frame_launches") == 1:
+        # config 5: the dominant kernel is the AO launch's persistent tracer.  Its share of the machine's time per step = the step minus the same frames without
+        # their AO pass, timed here the same way (fenced on both sides)
+        for _ in range(2 * F):
+            r.trace()
+        fence()
+        f0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.trace()
+        fence()
+        frame_only_ms = (time.perf_counter() - f0) * 1e3 / args.steps
+        us = max(ms_per_step - frame_only_ms, 1e-3) * 1e3
+        gold_ao = os.path.join(ROOT, "tests", "golden", "c5_sponza_like_2160p_16spp_ao.stats.json")
+        ga = json.load(open(gold_ao)) if (args.scene == "sponza" and (W, H) == (3840, 2160) and args.detail == 1.0 and not glb and args.ao == 16 and os.path.exists(gold_ao)) else None
+        ab = None
+        if ga and ga["ao_rays"] == st["ao_rays"]:
+            ab = dict(contract=(32 + 1) * ga["ao_rays"] + 64 * ga["n_int_ao"] + 48 * ga["n_tri_ao"])   # SURVEY 8(d) per ray on the canonical LBVH: ray + nodes + triangles + the occlusion byte
+        fr = RL.fractions(pmc, us, ab)
+        roof = dict(bound="valu_issue" if "valu_issue_frac" in fr else None, kernel="k_trace<MODE_AO, 4-wide> (the AO launch's persistent per-ray tracer)",
+                    achieved=pmc["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9 if "SQ_INSTS_VALU" in pmc else None, peak=RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES / 1e9, unit="G wave-instructions/s",
+                    frac=fr.get("valu_issue_frac"), traffic=fr.get("hbm_bytes_per_launch"), hbm_frac=fr.get("hbm_frac"), valu_issue_frac=fr.get("valu_issue_frac"), salu_issue_frac=fr.get("salu_issue_frac"),
+                    valu_lane_utilisation=fr.get("valu_lane_utilisation"),
+                    useful_valu_frac=(fr["valu_issue_frac"] * fr["valu_lane_utilisation"]) if ("valu_issue_frac" in fr and "valu_lane_utilisation" in fr) else None,
+                    contract_frac=fr.get("contract_frac"), l2_hit_rate=fr.get("l2_hit_rate"), machine_us_per_launch=us, frame_only_ms_per_step=frame_only_ms, ao_rays_per_launch=st["ao_rays"],
+                    algorithmic_bytes_per_launch=ab, pmc_source=entry["source"] if entry else None, pmc_kernel_source_sha16=entry.get("kernel_source_sha16") if entry else None,
+                    pmc_stale=(entry.get("kernel_source_sha16") != RL.kernel_source_hash()) if entry else None,
+                    note="the AO launch: machine time = this run's ms_per_step minus the same frames without their AO pass; frac = vector wave-instructions of the launch (committed rocprofv3 --pmc "
+                         "pass) x 2 cycles over what 1 024 SIMDs issue in that time; useful_valu_frac = frac x the share of lanes active per vector instruction (incoherent rays: a wave's "
+                         "lanes finish and wait at different times); contract_frac = SURVEY.md 8(d)'s per-ray bytes on the canonical LBVH / 8 TB/s (cache-resident: NOT an achieved bandwidth)")
+    elif ost is not None and st.get("frame_launches") == 1:
         ab = RL.algorithmic_bytes(ost, len(lights))
         us = ms_per_step * 1e3 * world                     # machine time one GPU spends per frame: each rank's launch handles 1/world of the frame's rays
         share = 1.0 / world
         ab_launch = {k: v * share * B for k, v in ab.items()}   # what ONE launch (B frames of a 1/world share) accounts for
-        cur_path = os.path.join(ROOT, "profiles", "current_pmc.json")
-        cur = json.load(open(cur_path)) if os.path.exists(cur_path) else None
-        usable = bool(cur) and world == 1 and cur.get("workload") == workload_name(sc, glb, W, H, lights, shadow_total, args)
-        pmc = cur["pmc"] if usable else {}
         fr = RL.fractions(pmc, us * B, ab_launch)
         kernel_ms = stage["primary_ms"]                    # HIP events on the launch's own stream: one launch's span, overlapped by the others in flight
         binding = max((k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac") if k in fr), key=lambda k: fr[k], default=None)
-        if binding == "hbm_frac" or binding is None:
-            # no instruction counts for this workload (they come from a committed rocprofv3 --pmc pass): the packet-level algorithmic bytes against HBM
-            roof = dict(bound="hbm", kernel="k_frame", achieved=ab_launch.get("packet", ab_launch["contract"]) / (us * B * 1e-6) / 1e9, peak=RL.HBM_PEAK / 1e9, unit="GB/s")
-            roof["frac"] = roof["achieved"] / roof["peak"]
+        if binding is None:
+            roof = dict(bound=None, kernel="k_frame", achieved=None, peak=None, unit=None, frac=None)   # no counters for this workload: nothing measured says which roof binds it
+        elif binding == "hbm_frac":
+            roof = dict(bound="hbm", kernel="k_frame", achieved=fr["hbm_bytes_per_launch"] / (us * B * 1e-6) / 1e9, peak=RL.HBM_PEAK / 1e9, unit="GB/s", frac=fr["hbm_frac"])
         else:
             per_s = {"valu_issue_frac": RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES, "salu_issue_frac": RL.CUS * RL.CLOCK_HZ}[binding]
             n_inst = pmc["SQ_INSTS_VALU" if binding == "valu_issue_frac" else "SQ_INSTS_SALU"]
@@ -497,20 +530,20 @@ def main():
             machine_us_per_launch=us * B, kernel_ms=kernel_ms, launches_overlapping=kernel_ms * 1e3 / (us * B) if us else None, frames_timed=n_timed, frames_in_flight=F * B,
             algorithmic_bytes_per_launch=dict(packet=ab_launch.get("packet"), contract=ab_launch["contract"], packet_traversal=ab_launch.get("packet_traversal_bytes"),
                                               shading=ab_launch.get("shading_bytes"), outputs=ab_launch.get("output_bytes")),
-            pmc_source=cur["source"] if usable else None, pmc_kernel_source_sha16=cur.get("kernel_source_sha16") if usable else None,
-            pmc_stale=(cur.get("kernel_source_sha16") != RL.kernel_source_hash()) if usable else None,
-            note="frac = the binding roof: wave-instructions issued per launch (committed rocprofv3 --pmc pass of this workload) over what the chip can issue in the launch's share of "
-                 "machine time (ms_per_step: ~13 launches overlap, so kernel_ms, one launch's own span, is not that share).  hbm_frac = measured HBM traffic (2 x FETCH_SIZE + "
+            pmc_source=entry["source"] if entry else None, pmc_kernel_source_sha16=entry.get("kernel_source_sha16") if entry else None,
+            pmc_stale=(entry.get("kernel_source_sha16") != RL.kernel_source_hash()) if entry else None,
+            note="frac = the binding roof among those MEASURED for this workload: wave-instructions issued per launch (committed rocprofv3 --pmc pass) over what the chip can issue in the launch's "
+                 "share of machine time (ms_per_step: ~13 launches overlap, so kernel_ms, one launch's own span, is not that share).  hbm_frac = measured HBM traffic (2 x FETCH_SIZE + "
                  "WRITE_SIZE, Infinity-Cache hits included) / 8 TB/s.  packet_frac = the oracle's packet-level algorithmic bytes (a node / triangle once per 8x8-pixel packet, "
                  "canonical LBVH) / 8 TB/s.  contract_frac = SURVEY.md 8(d)'s per-ray algorithmic bytes / 8 TB/s: above 1 because the tree (~30 MB) is cache-resident and a packet "
-                 "fetches a node once for 64 rays -- NOT an achieved bandwidth")
+                 "fetches a node once for 64 rays -- NOT an achieved bandwidth.  bound: null = no counter pass is committed for this workload (or N > 1): only the algorithmic fractions are given")
 
     line = {
         "metric": (("Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}") if args.scene == "sponza"
                    else f"Mray/s (primary+shadow), Bistro-class {W}x{H}") if not glb else f"Mray/s (primary+shadow), {os.path.basename(glb)} {W}x{H}",
         "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real glb" if glb else "synthetic",
-        "config": {"workload": workload_name(sc, glb, W, H, lights, shadow_total, args), "width": W, "height": H, "lights": len(lights),
+        "config": {"workload": workload, "width": W, "height": H, "lights": len(lights),
                    "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else (" (every rank assembles the frames f with f mod N = its rank)" if spread else f" (rank 0 composites too and traces {256 - relief}/256 of a share)"))
                                    + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGB32F HDR (12 B/px; alpha is the constant 1)'} colour tiles to {'the root of each frame' if spread else 'rank 0'}, {B} frames per launch, "
                                      f"{counts['launches_per_gather'] * B} frames per exchange") + f", {F * B} frames in flight"},

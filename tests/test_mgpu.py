@@ -213,4 +213,4 @@ def test_bench_takes_a_glb_through_the_real_ingest(tmp_path, get_scene):
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     line = json.loads(lines[0])
     assert line["data"] == "real glb" and "atrium.glb through art_scene_add_glb" in line["config"]["workload"] and line["value"] > 0
-    assert line["cpu_baseline"]["kind"] == "port" and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["packet_frac"] < 1
+    assert line["cpu_baseline"]["kind"] == "port" and line["roofline"]["bound"] is None and 0 < line["roofline"]["packet_frac"] < 1   # no counter pass for this workload: no roof is named

@@ -7,11 +7,12 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 i=0
-for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
-         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
-         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" \
-         "FETCH_SIZE" "WRITE_SIZE"; do
+# PMC_SHORT=1: the four passes a roofline needs (wave / lane cycles, instruction counts, HBM reads, HBM writes), without the cache passes
+SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
+      "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT")
+if [ -z "$PMC_SHORT" ]; then SETS+=("TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum"); fi
+SETS+=("FETCH_SIZE" "WRITE_SIZE")
+for C in "${SETS[@]}"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --plain --settle-seconds 0 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done

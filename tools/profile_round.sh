@@ -5,6 +5,8 @@
 #   <tag>_kernel_stats_bench_c2.csv       rocprofv3 --kernel-trace --stats of `bench.py --steps 1000 --plain`
 #   <tag>_bench_line_under_rocprof.json   that run's own line
 #   <tag>_pmc.txt                         tools/pmc.sh: PMC passes (kernel-trace only, one counter group per pass), means per kernel
+#   <tag>_config{3,4,5}.json, <tag>_pmc_c{3,4,5}.txt   the other BASELINE configs: plain bench line + the counter passes their rooflines need
+# then: python tools/roofline.py --tag <tag> --set-current (profiles/current_pmc.json: what bench.py's roofline object reads, keyed by workload)
 set -e
 TAG=$1
 R=$GRAFT_REPO_ROOT
@@ -18,4 +20,10 @@ cp "$(find $OUT/stats -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_s
 grep '^{' $OUT/stats.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 bash $R/tools/pmc.sh $TAG > $OUT/${TAG}_pmc.txt 2> $OUT/pmc.err
 rm -rf $OUT/stats $R/gpurun_out/pmc_$TAG/p*/   # the raw traces are large; the summaries above are what is kept
+# the other BASELINE configs on one GPU: a plain bench line and the counter passes a roofline needs, each (<tag>_configN.json, <tag>_pmc_cN.txt)
+other() { n=$1; steps=$2; shift 2; python3 $R/bench.py --plain --steps $steps --warmup 30 "$@" > $OUT/config$n.log 2>&1; grep '^{' $OUT/config$n.log | tail -1 > $OUT/${TAG}_config$n.json
+          PMC_SHORT=1 bash $R/tools/pmc.sh ${TAG}_c$n "$@" > $OUT/${TAG}_pmc_c$n.txt 2> $OUT/pmc_c$n.err; rm -rf $R/gpurun_out/pmc_${TAG}_c$n/p*/; echo "config $n done"; }
+other 3 300 --width 3840 --height 2160 --lights 4
+other 4 600 --scene bistro
+other 5 60 --width 3840 --height 2160 --ao 16
 echo "profile_round $TAG done"

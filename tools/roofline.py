@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Re-derives every number of bench.py's `roofline` object from what is committed under profiles/.
 
-    python tools/roofline.py --tag r2b [--set-current]
+    python tools/roofline.py --tag round3 [--set-current]
 
-Inputs (all under profiles/, all produced on the GPU box by tools/pmc.sh and a plain bench run):
-    <tag>_pmc.txt                    rocprofv3 --pmc passes of `bench.py --steps 6` (one line per kernel and pass: name {counter: mean} n=launches)
-    <tag>_kernel_stats_bench_c2.csv  rocprofv3 --kernel-trace --stats of `bench.py --steps 1000`
-    <tag>_bench_line.json            the JSON line of the un-profiled `bench.py --steps 1000`
-and tests/golden/c2_sponza_like_1080p_1light.stats.json (the oracle's per-ray and per-packet visit counters of that frame).
+Inputs (all under profiles/, all produced on the GPU box by tools/profile_round.sh: tools/pmc.sh passes and plain bench runs), per BASELINE config that was profiled:
+    config 2   <tag>_pmc.txt      <tag>_bench_line.json   (+ <tag>_kernel_stats_bench_c2.csv: rocprofv3 --kernel-trace --stats of `bench.py --steps 1000`)
+    config 3   <tag>_pmc_c3.txt   <tag>_config3.json
+    config 4   <tag>_pmc_c4.txt   <tag>_config4.json
+    config 5   <tag>_pmc_c5.txt   <tag>_config5.json      (dominant kernel: the AO launch's k_trace<4, 4>)
+(a pmc file: one line per kernel and pass, name {counter: mean} n=launches) and tests/golden/<config>.stats.json (the oracle's visit counters of that frame).
 
 What it prints (and writes to profiles/<tag>_roofline.json; --set-current also writes profiles/current_pmc.json, the file bench.py reads
 its instruction counts and HBM traffic from -- PMC counters cannot be read from inside the benchmarked process):
@@ -68,7 +69,7 @@ def fractions(pmc, us_per_launch, ab):
     if "SQ_INSTS_SALU" in pmc:
         r["salu_issue_us"] = pmc["SQ_INSTS_SALU"] / (CUS * CLOCK_HZ) * 1e6
         r["salu_issue_frac"] = r["salu_issue_us"] / us_per_launch
-    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and us_per_launch > 0:
         r["hbm_bytes_per_launch"] = int((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
         r["hbm_frac"] = r["hbm_bytes_per_launch"] / t / HBM_PEAK
     if "TCC_HIT_sum" in pmc and pmc.get("TCC_REQ_sum"):
@@ -90,9 +91,12 @@ def parse_pmc_txt(path, kernel_substr="k_frame"):
         if not m:
             continue
         name, counters, n = m.group(1), ast.literal_eval(m.group(2)), int(m.group(3))
-        if kernel_substr not in name and not re.search(r"\d, (true|false), (true|false)", name):   # the name is cut to its tail: k_frame<...> shows as its template arguments
-            continue
-        if "k_frame_stats" in name:
+        if kernel_substr == "k_frame":
+            if kernel_substr not in name and not re.search(r"\d, (true|false), (true|false)", name):   # the name is cut to its tail: k_frame<...> shows as its template arguments
+                continue
+            if "k_frame_stats" in name:
+                continue
+        elif kernel_substr not in name:
             continue
         for c, v in counters.items():
             if c not in best or n > best[c][1]:
@@ -108,32 +112,55 @@ def parse_stats_csv(path, kernel_substr="k_frame<"):
     return dict(name=top["Name"], calls=int(top["Calls"]), average_ns=float(top["AverageNs"]), min_ns=float(top["MinNs"]), max_ns=float(top["MaxNs"]))
 
 
+CONFIGS = {  # what a profile round covers: name -> (file suffixes under profiles/<tag>_*, dominant kernel as tools/pmc.sh prints it, golden stats, lights)
+    "c2": dict(pmc="pmc.txt", line="bench_line.json", kernel="k_frame", golden="c2_sponza_like_1080p_1light", lights=1),
+    "c3": dict(pmc="pmc_c3.txt", line="config3.json", kernel="k_frame", golden="c3_sponza_like_2160p_4lights", lights=4),
+    "c4": dict(pmc="pmc_c4.txt", line="config4.json", kernel="k_frame", golden="c4_bistro_like_1080p_1light", lights=1),
+    "c5": dict(pmc="pmc_c5.txt", line="config5.json", kernel="k_trace<4, 4>", golden="c5_sponza_like_2160p_16spp_ao", lights=1),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
-    ap.add_argument("--config", default="c2_sponza_like_1080p_1light")
-    ap.add_argument("--lights", type=int, default=1)
-    ap.add_argument("--set-current", action="store_true", help="also write profiles/current_pmc.json (what bench.py reads)")
+    ap.add_argument("--set-current", action="store_true", help="also write profiles/current_pmc.json (what bench.py reads: one entry per workload that has a counter pass)")
     a = ap.parse_args()
     P = os.path.join(ROOT, "profiles")
-    pmc, launches = parse_pmc_txt(os.path.join(P, f"{a.tag}_pmc.txt"))
-    stats = parse_stats_csv(os.path.join(P, f"{a.tag}_kernel_stats_bench_c2.csv"))
-    line = json.load(open(os.path.join(P, f"{a.tag}_bench_line.json")))
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", f"{a.config}.stats.json")))
-    ab = algorithmic_bytes(gold, a.lights)
-    us = line["ms_per_step"] * 1e3
-    fr = fractions(pmc, us, ab)
-    bound = max((k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac") if k in fr), key=lambda k: fr[k])
-    out = dict(tag=a.tag, kernel=stats["name"] if stats else "k_frame", us_per_launch_machine=us, ms_per_step=line["ms_per_step"], mray_per_s=line["value"],
-               kernel_ms_rocprof_average=stats["average_ns"] * 1e-6 if stats else None, kernel_ms_bench_events=(line.get("roofline") or {}).get("kernel_ms"),
-               launches_overlapping=(stats["average_ns"] * 1e-3 / us) if stats else None, pmc_launches_averaged=launches, pmc=pmc, algorithmic_bytes_per_frame=ab,
-               binding_roof=bound.replace("_frac", ""), **fr)
-    print(json.dumps(out, indent=1))
-    json.dump(out, open(os.path.join(P, f"{a.tag}_roofline.json"), "w"), indent=1)
+    out_all, workloads = {}, {}
+    for name, c in CONFIGS.items():
+        fp, fl = os.path.join(P, f"{a.tag}_{c['pmc']}"), os.path.join(P, f"{a.tag}_{c['line']}")
+        if not (os.path.exists(fp) and os.path.exists(fl)):
+            continue
+        pmc, launches = parse_pmc_txt(fp, c["kernel"])
+        line = json.load(open(fl))
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", c["golden"] + ".stats.json")))
+        if name == "c5":   # the AO launch: its machine time is the step minus the frames without their AO pass (bench.py measures both)
+            rl = line.get("roofline") or {}
+            us = rl.get("machine_us_per_launch") or line["ms_per_step"] * 1e3
+            ab = dict(contract=(32 + 1) * gold["ao_rays"] + 64 * gold["n_int_ao"] + 48 * gold["n_tri_ao"])
+        else:
+            us = line["ms_per_step"] * 1e3
+            ab = algorithmic_bytes(gold, c["lights"])
+        fr = fractions(pmc, us, ab)
+        cands = [k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac") if k in fr]
+        bound = max(cands, key=lambda k: fr[k]).replace("_frac", "") if cands else None
+        out = dict(tag=a.tag, config=name, workload=line["config"]["workload"], kernel=c["kernel"], us_per_launch_machine=us, ms_per_step=line["ms_per_step"], mray_per_s=line["value"],
+                   pmc_launches_averaged=launches, pmc=pmc, algorithmic_bytes_per_frame=ab, binding_roof=bound, **fr)
+        if "valu_issue_frac" in fr and "valu_lane_utilisation" in fr:
+            out["useful_valu_frac"] = fr["valu_issue_frac"] * fr["valu_lane_utilisation"]
+        if name == "c2":
+            sp = os.path.join(P, f"{a.tag}_kernel_stats_bench_c2.csv")
+            stats = parse_stats_csv(sp) if os.path.exists(sp) else None
+            if stats:
+                out.update(kernel=stats["name"], kernel_ms_rocprof_average=stats["average_ns"] * 1e-6, kernel_ms_bench_events=(line.get("roofline") or {}).get("kernel_ms"),
+                           launches_overlapping=stats["average_ns"] * 1e-3 / us)
+        out_all[name] = out
+        workloads[line["config"]["workload"]] = dict(tag=a.tag, config=name, kernel=c["kernel"], kernel_source_sha16=kernel_source_hash(), pmc=pmc,
+                                                     source=f"profiles/{a.tag}_{c['pmc']} (rocprofv3 --kernel-trace --pmc, separate passes, tools/pmc.sh; means over {launches} launches of {c['kernel']})")
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("pmc",)} for k, v in out_all.items()}, indent=1))
+    json.dump(out_all, open(os.path.join(P, f"{a.tag}_roofline.json"), "w"), indent=1)
     if a.set_current:
-        cur = dict(tag=a.tag, source=f"profiles/{a.tag}_pmc.txt (rocprofv3 --kernel-trace --pmc, separate passes, tools/pmc.sh; means over {launches} launches of {out['kernel']})",
-                   workload=line["config"]["workload"], kernel_source_sha16=kernel_source_hash(), pmc=pmc)
-        json.dump(cur, open(os.path.join(P, "current_pmc.json"), "w"), indent=1)
+        json.dump(dict(tag=a.tag, workloads=workloads), open(os.path.join(P, "current_pmc.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
