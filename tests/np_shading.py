@@ -124,7 +124,8 @@ def light_from_record(rec):
 
 
 def shade_pixel(prim, tri, u, v, cam_view, cam_view_inv, camera_pos, lights, shadowed_bits):
-    """prim: scenes.Primitive; cam_*: 4x4 numpy (row, col); returns (color3, depth, normal3, shadow_ray_mask)"""
+    """prim: scenes.Primitive; cam_*: 4x4 numpy (row, col); returns (color3, depth, normal3, mask): mask bit 16 + i = a shadow ray towards light i is due,
+    bit i = that light was found shadowed (only when shadowed_bits is a function that traces the ray)"""
     i0, i1, i2 = [int(x) for x in prim.indices[3 * tri:3 * tri + 3]]
     V = prim.verts.astype(np.float64)
     v0, v1, v2 = V[i0], V[i1], V[i2]
@@ -169,7 +170,13 @@ def shade_pixel(prim, tri, u, v, cam_view, cam_view_inv, camera_pos, lights, sha
         att = 1.0
         if l["casts"] and nc_NdotL > 0:
             mask |= 1 << (16 + i)
-            if shadowed_bits >> i & 1:
+            # shadowed_bits: the bits someone else found, or a function (light index, origin, direction, tmax) -> bool that traces the shadow ray itself
+            # (raytrace.rgen.glsl:165-181: origin world_pos, tmin 0.01, direction L, tmax length(nn_L))
+            if callable(shadowed_bits):
+                if shadowed_bits(i, world_pos, L, float(np.sqrt(nn_L @ nn_L))):
+                    att = 0.05
+                    mask |= 1 << i
+            elif shadowed_bits >> i & 1:
                 att = 0.05
         rho = rho + (rho_s + rho_d) * get_light_radiance(l, world_pos, L) * att * NdotL
     depth = -(cam_view @ np.append(world_pos, 1.0))[2]
@@ -233,3 +240,52 @@ def closest_hit(o, d, tris, tmin=0.001, tmax=10000.0, eps=0.0):
         return -1, tmax, 0.0, 0.0, 0.0
     i = int(np.argmin(np.where(ok, t, np.inf)))
     return i, float(t[i]), float(u[i]), float(v[i]), float(min(u[i], v[i], 1.0 - u[i] - v[i]))
+
+
+class BruteForce:
+    """Every triangle of a scene in float64, for a brute-force witness on scenes of 10^5 .. 10^6 triangles (the bench scenes): no tree, no traversal order, no
+    Morton keys, nothing the oracle's BVH could share a mistake with.  Rays that share an origin (a camera's) are tested in batches through the scalar triple
+    products of Moeller-Trumbore written as matrix products -- det = d . (e2 x e1), u det = d . (e2 x tv), v det = d . (tv x e1), t det = e2 . (tv x e1) -- which is
+    the same test in another order of operations (float64: the orders differ by ~1e-13)."""
+
+    def __init__(self, primitives):
+        self.tris, self.pid, self.tid = world_triangles(primitives)
+        self.v0 = np.ascontiguousarray(self.tris[:, 0]); self.e1 = self.tris[:, 1] - self.v0; self.e2 = self.tris[:, 2] - self.v0
+        self.n1 = np.cross(self.e2, self.e1)
+        self.lo, self.hi = self.tris.min(1), self.tris.max(1)
+
+    def closest_from(self, o, D, tmin, tmax, eps=0.0, chunk_elems=24_000_000):
+        """rays o + t D[r]: -> (index [R] into the triangles or -1, t, u, v, margin) of the closest accepted hit of each"""
+        tv = o - self.v0
+        A, Q = np.cross(self.e2, tv), np.cross(tv, self.e1)
+        tdet = np.einsum("ij,ij->i", self.e2, Q)
+        R, T = len(D), len(self.v0)
+        idx, tt, uu, vv, mm = np.full(R, -1), np.full(R, tmax), np.zeros(R), np.zeros(R), np.zeros(R)
+        step = max(1, chunk_elems // T)
+        for r0 in range(0, R, step):
+            d = D[r0:r0 + step]
+            det = d @ self.n1.T
+            with np.errstate(divide="ignore", invalid="ignore"):
+                inv = 1.0 / det
+                u = (d @ A.T) * inv
+                v = (d @ Q.T) * inv
+                t = tdet[None, :] * inv
+            ok = (det != 0) & (u >= -eps) & (v >= -eps) & (u + v <= 1 + eps) & (t > tmin) & (t < tmax)
+            t = np.where(ok, t, np.inf)
+            i = np.argmin(t, axis=1)
+            rr = np.arange(len(d))
+            hit = np.isfinite(t[rr, i])
+            sel = r0 + rr[hit]
+            idx[sel] = i[hit]; tt[sel] = t[rr[hit], i[hit]]; uu[sel] = u[rr[hit], i[hit]]; vv[sel] = v[rr[hit], i[hit]]
+            mm[sel] = np.minimum(np.minimum(uu[sel], vv[sel]), 1.0 - uu[sel] - vv[sel])
+        return idx, tt, uu, vv, mm
+
+    def any_hit(self, o, d, tmin, tmax, eps=0.0):
+        """is the segment o + t d, tmin < t < tmax, blocked?  -> (bool, the smallest barycentric margin among the triangles whose answer decided it)"""
+        a, b = o + d * tmin, o + d * tmax
+        lo, hi = np.minimum(a, b) - 1e-9, np.maximum(a, b) + 1e-9
+        cand = np.nonzero(((self.hi >= lo) & (self.lo <= hi)).all(1))[0]    # only triangles whose box the segment's box touches can be hit
+        if cand.size == 0:
+            return False, 1.0
+        i, t, u, v, m = closest_hit(o, d, self.tris[cand], tmin, tmax, eps)
+        return i >= 0, m

@@ -316,6 +316,71 @@ def test_all_light_types_against_numpy_in_fp64(orc64, scenes):
     assert checked > 1000 and (lit > 20).all(), (checked, lit)
 
 
+@pytest.mark.parametrize("config,n_pixels", [("c2", 2000), ("c4", 200)])
+def test_bench_scenes_against_a_brute_force_witness_in_fp64(orc, orc64, scenes, config, n_pixels):
+    """The scenes the bench runs, at FULL detail -- config 2 (262 816 triangles, a primitive with u32 indices) and config 4 (2.8 M triangles, 63-bit Morton keys on
+    the GPU) -- where until round 3 geometry was only checked oracle-BVH against oracle-brute-force: for a random sample of the 1080p frame's pixels, numpy in
+    float64 tests the camera ray against EVERY triangle (no tree, no keys, no traversal order: tests/np_shading.py BruteForce), and
+      - the hit's primitive, triangle, t, u, v are the fp64 build of the oracle's (its BVH walk), and the float oracle's ids -- the checker of every GPU test;
+      - the pixel is shaded by the numpy restatement FROM NUMPY'S OWN HIT, its shadow ray traced by brute force too: colour, depth, normal against the oracle's.
+    A transcription slip that only shows on large index ranges (u32 indices, global triangle ids past 2^16, primitive tables of 120 entries) would have to be made
+    twice, in two languages."""
+    import np_shading as NP
+    sc = scenes.sponza_like(1.0) if config == "c2" else scenes.bistro_like(1.0)
+    lights = scenes.sponza_lights(1) if config == "c2" else sc.lights
+    w, h = 1920, 1080
+    assert sc.n_tris > (250_000 if config == "c2" else 2_500_000) and (config != "c2" or any(p.indices.dtype == np.uint32 for p in sc.primitives))   # config 2 holds a primitive with u32 indices
+    S, cam, recs, out = _f64_frame(orc64, sc, lights, w, h)
+    c = sc.camera
+    view, view_inv, proj, proj_inv = NP.camera_matrices(c["pos"], c["dir"], w / h, c["fovy"], c["znear"], c["zfar"])
+    rng = np.random.default_rng(0xA17 + len(config))
+    xs, ys = rng.integers(0, w, n_pixels), rng.integers(0, h, n_pixels)
+    rays = np.array([np.concatenate(NP.primary_ray(int(x), int(y), w, h, view_inv, proj_inv)) for x, y in zip(xs, ys)])
+    o, D = rays[0, :3], rays[:, 3:]
+    assert np.allclose(rays[:, :3], o)
+    B = NP.BruteForce(sc.primitives)
+    tmin = float(np.float32(0.001))
+    idx, t, u, v, margin = B.closest_from(o, D, tmin, 10000.0)
+    S32 = orc.Scene(sc.primitives, morton_bits=63 if config == "c4" else 30)
+    r32 = np.zeros((n_pixels, 8), np.float32); r32[:, :3] = o; r32[:, 3] = 0.001; r32[:, 4:7] = D; r32[:, 7] = 10000.0
+    _, ids32, _, _ = S32.trace_closest(r32)
+    nl = [NP.light_from_record(recs[i]) for i in range(len(lights))]
+    cam_pos = np.array(cam.camera_pos, np.float64)
+    edge, hits, lit, shadowed, shadow_edge, prims_seen = 0, 0, 0, 0, 0, set()
+    for k in range(n_pixels):
+        x, y = int(xs[k]), int(ys[k])
+        pi, ti = out["hit_id"][y, x]
+        mine = (int(B.pid[idx[k]]), int(B.tid[idx[k]])) if idx[k] >= 0 else (-1, -1)
+        if mine != (pi, ti):   # only within the oracle's edge tolerance (1e-6 barycentric) of an edge may the two name different triangles (or one a miss)
+            i2, t2, u2, v2, m2 = NP.closest_hit(o, D[k], B.tris, tmin, eps=1e-6)
+            assert (margin[k] < 2e-6 or m2 < 2e-6) and (pi < 0 or np.isclose(out["hit_tuv"][y, x, 0], t2, rtol=1e-7)), (x, y, mine, (pi, ti), margin[k], m2)
+            edge += 1
+            continue
+        assert tuple(ids32[k]) == mine or margin[k] < 1e-4, (x, y, mine, tuple(ids32[k]), margin[k])     # the float oracle: the same triangle unless the ray grazes an edge
+        if pi < 0:
+            continue
+        hits += 1; prims_seen.add(int(pi))
+        assert np.allclose(out["hit_tuv"][y, x, :3], [t[k], u[k], v[k]], rtol=1e-9, atol=1e-11), (x, y)
+        grazing = []
+
+        def occluded(i, origin, L, tmax):
+            hit, m = B.any_hit(origin, L, float(np.float32(0.01)), tmax, eps=1e-6)
+            grazing.append(m < 2e-6)
+            return hit
+        rho, depth, on, mask = NP.shade_pixel(sc.primitives[pi], int(ti), u[k], v[k], view, view_inv, cam_pos, nl, occluded)
+        bits = int(out["shadow_bits"][y, x])
+        assert mask & 0xFFFF0000 == bits & 0xFFFF0000, (x, y)
+        lit += (mask >> 16) & 1
+        if mask & 0xFFFF != bits & 0xFFFF:      # the shadow ray grazes an edge of the blocker (or the blocker lies within rounding of the ray's start): either answer
+            shadow_edge += 1
+            continue
+        shadowed += mask & 1
+        assert np.allclose(out["color"][y, x, :3], rho, rtol=1e-6, atol=2e-7), (x, y, out["color"][y, x], rho)
+        assert np.isclose(out["depth"][y, x], depth, rtol=1e-9) and np.allclose(out["normal"][y, x, :3], on, rtol=1e-6, atol=2e-7)
+    assert hits > 0.6 * n_pixels and edge <= n_pixels // 100 and shadow_edge <= max(2, lit // 50), (hits, edge, shadow_edge, lit)
+    assert lit > hits // 10 and 0 < shadowed < lit and len(prims_seen) >= 8, (lit, shadowed, prims_seen)
+
+
 def test_float_build_is_the_double_build_up_to_rounding(orc, orc64, scenes):
     """the oracle everything else is compared with (float) against the double build of the same source.  On the Cornell G-buffer (constant
     textures) the radiance agrees to 1e-5 everywhere: SURVEY.md 8c-5's figure.  On textured, normal-mapped surfaces with all four light
