@@ -95,6 +95,40 @@ def test_one_rank_job_over_rccl_assembles_the_frame(get_scene, packed, spread):
 
 
 @pytest.mark.gpu
+def test_a_moving_model_through_the_sharded_frame(get_scene):
+    """art_scene_set_model_matrix under art_mgpu_*: every rank makes the same calls, each refits its copy of the scene in front of its next launch; the frames
+    the job assembles (one rank over RCCL here, spread roots) are the unsharded renders of the moved scene, bit for bit, also with launches in flight"""
+    from araytracingjourney_amd import renderer as R
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _pose
+    sc = get_scene("sponza_like", 0.12)
+    w, h, F = 480, 270, 4
+
+    def make(**kw):
+        r = R.Renderer((w, h), **kw)
+        r.add_model(sc.primitives[:-1]); r.add_model(sc.primitives[-1:])
+        cam = r.camera_mut()
+        cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
+        for d in sc.lights:
+            r.lights_mut().push_dict(d)
+        r.prepare_first_frame(); r.upload_state()
+        return r
+    whole, r = make(), make(frames_in_flight=F, tile_output=True)
+    mg = R.MultiGpu(r, 0, 1, unique_id=R.mgpu_unique_id(), launches_per_gather=2, spread=True)
+    for i in range(1, 10):
+        m = _pose(sc.primitives[-1].model, i)
+        r.models_mut()[1].set_model_matrix(m)
+        mg.trace()
+        if i in (1, 6, 9):
+            mg.flush()
+            whole.models_mut()[1].set_model_matrix(m)
+            whole.render_frame()
+            assert np.array_equal(mg.read_frame().view(np.uint32), whole.read_color().view(np.uint32)), i
+    assert r.stats()["refits"] == 9
+    mg.close(); r.close(); whole.close()
+
+
+@pytest.mark.gpu
 def test_a_failed_exchange_is_reported_and_latched(get_scene):
     """a transport that fails (the host hook here; an RCCL error alike) loses its group's frames and leaves the ranks out of step: the call that submitted the
     exchange returns the error, and so does every later trace and flush -- none reports success for frames that never arrived, none waits for the lost group"""
