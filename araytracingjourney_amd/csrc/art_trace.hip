@@ -315,10 +315,22 @@ struct ConstQuads {
 };
 template <class T> __device__ __forceinline__ ConstQuads const_quads(const T *p) { ConstQuads q; q.p = (__attribute__((address_space(4))) const ConstQuads::Quad *)(uintptr_t)p; return q; }
 
+#ifdef ART_PACKET_PROF
+// profiling build only (make EXTRA=-DART_PACKET_PROF; tools/packet_prof.py): what the packet walks of k_frame are made of, summed over all waves since the last reset.
+// [0..7] closest-hit (primary) walks, [8..15] any-hit (shadow) walks: walks, node steps, triangle steps, triangle steps that came off the stack, triangle steps in
+// which some lane accepted the triangle, lanes that accepted, child boxes hit by some lane (of 4 per node step), mixed-octant walks
+__device__ unsigned long long g_packet_prof[16];
+#define PPROF(i, n) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_packet_prof[(ANY ? 8 : 0) + (i)], (unsigned long long)(n)); } while (0)
+#else
+#define PPROF(i, n)
+#endif
 template <bool ANY, bool WIDE, int OCT, bool COUNT = false>
 __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps) {
     int cur = 0, sp = 0; // wave-uniform
-    constexpr int kPop = kAbsentChild; // "take the next node from the stack" (no leaf has position 2^31 - 1); also what an absent child of a 4-wide node refers to
+    constexpr int kPop = kAbsentChild;
+#ifdef ART_PACKET_PROF
+    unsigned long long pp_[8] = {1, 0, 0, 0, 0, 0, 0, OCT == 8}; bool from_stack_ = false;
+#endif // "take the next node from the stack" (no leaf has position 2^31 - 1); also what an absent child of a 4-wide node refers to
     for (;;) {
         if (COUNT) steps++; // wave-uniform: nodes + triangles the packet visited (the fused frame's wave plan feeds on it; one s_add here costs 3.5 %, so only sampled frames count)
         if (cur >= 0 && WIDE) {
@@ -337,6 +349,9 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             const uint64_t m1 = ballot64(slab_oct<OCT>(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, tbest, te));
             const uint64_t m2 = ballot64(slab_oct<OCT>(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, tbest, te));
             const uint64_t m3 = ballot64(slab_oct<OCT>(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, tbest, te));
+#ifdef ART_PACKET_PROF
+            pp_[1]++; pp_[6] += (m0 != 0ull) + (m1 != 0ull) + (m2 != 0ull) + (m3 != 0ull); from_stack_ = false;
+#endif
             const uint32_t ax = __float_as_uint(w7.y);                   // 0..2 (wave-uniform)
             // mixed packets (OCT 8) go by the majority sign on that axis
             const bool rev = OCT < 8 ? ((OCT >> ax) & 1) != 0 : 2 * (int)__popcll(ballot64(on && (ax == 0 ? r.inv.x : (ax == 1 ? r.inv.y : r.inv.z)) < 0.0f)) > (int)__popcll(ballot64(on));
@@ -390,6 +405,9 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
                 bool better = acc & ((teff < tbest) | ((teff == tbest) & (gid < bgid))); // (bitwise: three compares and three mask operations, no nested exec regions)
                 tbest = better ? teff : tbest; bu = better ? u : bu; bv = better ? v : bv; bpos = better ? pos : bpos; bgid = better ? gid : bgid;
             }
+#ifdef ART_PACKET_PROF
+            { uint64_t am_ = ballot64(acc); pp_[2]++; pp_[3] += from_stack_; pp_[4] += am_ != 0ull; pp_[5] += __popcll(am_); }
+#endif
             cur = kPop;
             if (ANY && ballot64(on) == 0ull) break; // every ray of the packet is occluded
         }
@@ -397,8 +415,14 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             if (sp == 0) break;
             sp--;
             cur = __builtin_amdgcn_readfirstlane(stk[sp]); // same address in every lane: one broadcast LDS read (lane 0's write is ordered before it within the wave)
+#ifdef ART_PACKET_PROF
+            from_stack_ = true;
+#endif
         }
     }
+#ifdef ART_PACKET_PROF
+    for (int i = 0; i < 8; i++) PPROF(i, pp_[i]);
+#endif
 }
 
 // one packet through the walk that fits its rays' direction signs
@@ -1287,6 +1311,14 @@ void launch_query_any(const BvhView &b, const float4 *rays, uint32_t n, uint32_t
     launch_trace<MODE_QUERY_ANY>(a, b.kind, false, b.tune, s);
 }
 // AO resolve: occluded count -> uint(pow(visibility, 2.2) * 255 + 0.5) through a host-built table; 255 where nothing was hit
+#ifdef ART_PACKET_PROF
+extern "C" int32_t art_debug_packet_prof(unsigned long long *out, int32_t reset) { // out[16]
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_packet_prof), sizeof(g_packet_prof)) != hipSuccess) return -1;
+    void *dp = nullptr;
+    if (reset && (hipGetSymbolAddress(&dp, HIP_SYMBOL(g_packet_prof)) != hipSuccess || hipMemset(dp, 0, sizeof(g_packet_prof)) != hipSuccess)) return -1;
+    return 0;
+}
+#endif
 #ifdef ART_TRACE_PROF
 extern "C" int32_t art_debug_trace_prof(unsigned long long *out, int32_t reset) { // out[8]
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace_prof), sizeof(g_trace_prof)) != hipSuccess) return -1;
