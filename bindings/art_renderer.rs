@@ -21,7 +21,7 @@ pub struct ArtRayTracedRenderer {
 impl ArtRayTracedRenderer {
     /// VulkanTempleRayTracedRenderer::new (renderer.rs:140): extent + the FrameData ring depth (renderer.rs:135 keeps 3)
     pub fn new(width: u32, height: u32, frames_in_flight: u32) -> Self {
-        let cfg = ArtConfig { device: -1, width, height, morton_bits: 0, shard_rank: 0, shard_count: 1, flags: 0, frames_in_flight };
+        let cfg = ArtConfig { device: -1, width, height, morton_bits: 0, shard_rank: 0, shard_count: 1, flags: 0, frames_in_flight, root_relief: 0 };
         let mut ctx = std::ptr::null_mut();
         check(unsafe { art_create(&cfg, &mut ctx) });
         let (pos, dir) = ([0.0f32; 3], [0.0f32, 0.0, 1.0]); // defaults of renderer.rs:222-231
@@ -39,6 +39,11 @@ impl ArtRayTracedRenderer {
         check(unsafe { art_scene_add_glb(self.ctx, glb, model_matrix_3x4.as_ptr(), &mut first, &mut n) });
         unsafe { art_glb_close(glb) };
         first..first + n
+    }
+    /// VkModel::set_model_matrix (vk_model.rs:461-466): the model's primitives get a new object -> world matrix; the reference rebuilds its TLAS every frame for
+    /// this (renderer.rs:637-651), libart refits on the device in front of the next frame
+    pub fn set_model_matrix(&mut self, model: std::ops::Range<u32>, model_matrix_3x4: &[f32; 12]) {
+        check(unsafe { art_scene_set_model_matrix(self.ctx, model.start, model.end - model.start, model_matrix_3x4.as_ptr()) });
     }
     /// prepare_first_frame (renderer.rs:356): uploads + BLAS/TLAS builds
     pub fn prepare_first_frame(&mut self) { check(unsafe { art_scene_build(self.ctx) }); }

@@ -53,6 +53,17 @@ int main(int argc, char **argv) {
             double sum = 0; for (float v : c) sum += v;
             std::printf("RENDER_OK tris=%u primary=%llu shadow=%llu hit=%llu ao=%llu frame_ms=%.3f colour_sum=%.6e\n", st.num_triangles, (unsigned long long)st.primary_rays,
                         (unsigned long long)st.shadow_rays, (unsigned long long)st.hit_pixels, (unsigned long long)st.ao_rays, st.frame_ms, sum);
+            // VkModel::set_model_matrix (vk_model.rs:461-466): the model moves half a unit to the right and back; the reference rebuilds its TLAS every frame for this
+            // (renderer.rs:637-651), libart refits in front of the next frame -- and the frame of the model back in place is the first frame again, bit for bit
+            renderer.models_mut()[0].set_model_matrix({2, 0, 0, 0.5f, 0, 2, 0, 0, 0, 0, 2, 0});
+            renderer.render_frame();
+            std::vector<float> moved = renderer.color_output();
+            renderer.models_mut()[0].set_model_matrix({2, 0, 0, 0, 0, 2, 0, 0, 0, 0, 2, 0});
+            renderer.render_frame();
+            std::vector<float> back = renderer.color_output();
+            ArtStats st2 = renderer.stats();
+            std::printf("MOVED_OK refits=%u rebuilds=%u moved_differs=%d back_equals_first=%d refit_ms=%.3f\n", st2.refits, st2.rebuilds, (int)(moved != c),
+                        (int)(std::memcmp(back.data(), c.data(), c.size() * sizeof(float)) == 0), st2.refit_ms);
             return 0;
         }
         std::puts("usage: host_mirror_demo check | render <file.glb> [W H]");

@@ -406,7 +406,8 @@ def test_glb_ingest_feeds_the_same_frame(R, get_scene, tmp_path):
 
 
 def test_cpp_host_mirror_renders_a_glb(R, get_scene, tmp_path):
-    """main.rs:15-66 on the C++ mirror: add_model(.glb) + lights + prepare_first_frame + render_frame + compute_ao"""
+    """main.rs:15-66 on the C++ mirror: add_model(.glb) + lights + prepare_first_frame + render_frame + compute_ao; then Model::set_model_matrix (vk_model.rs:461-466)
+    there and back: two refits, the moved frame differs, the frame of the model back in place is the first one bit for bit"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tests"))
@@ -417,8 +418,10 @@ def test_cpp_host_mirror_renders_a_glb(R, get_scene, tmp_path):
     write_glb(str(path), sc.primitives, png_modes=("RGBA", "RGBA", "RGBA"))
     out = subprocess.run([os.path.join(root, "examples", "host_mirror_demo"), "render", str(path), "160", "96"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "RENDER_OK" in out.stdout, out.stdout + out.stderr
-    f = dict(kv.split("=") for kv in out.stdout.split("RENDER_OK")[1].split())
+    f = dict(kv.split("=") for kv in out.stdout.split("RENDER_OK")[1].split("\n")[0].split())
     assert int(f["tris"]) == 34 and int(f["primary"]) == 160 * 96 and int(f["hit"]) > 1000 and int(f["ao"]) == 16 * int(f["hit"]) and float(f["colour_sum"]) > 0
+    m = dict(kv.split("=") for kv in out.stdout.split("MOVED_OK")[1].split())
+    assert (int(m["refits"]), int(m["rebuilds"]), int(m["moved_differs"]), int(m["back_equals_first"])) == (2, 0, 1, 1) and float(m["refit_ms"]) > 0, out.stdout
 
 
 def test_frame_ring_gives_the_same_frames(R, get_scene):
