@@ -872,7 +872,8 @@ int32_t art_scene_build(ArtContext *c) {
     hipEvent_t e0, e1;
     HIPC(hipEventCreate(&e0)); HIPC(hipEventCreate(&e1));
     HIPC(hipEventRecord(e0, c->main_stream()));
-    hipError_t e = lbvh_build(in, c->bvh, c->main_stream());
+    const bool own_tree = c->fast_trace && T >= 3;   // a PREFER_FAST_TRACE build makes its own tree over the leaves: the canonical tree's boxes are computed only when asked for (art_get_lbvh)
+    hipError_t e = lbvh_build(in, c->bvh, c->main_stream(), !own_tree);
     c->bvh.log = c->tuning.log;
     if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "lbvh_build"); }
     if (c->fast_trace) { // PREFER_FAST_TRACE (vk_model.rs:968): the traversal nodes get a SAH-driven topology over the same leaves
@@ -1581,6 +1582,7 @@ int32_t art_get_lbvh(ArtContext *c, uint32_t *leaf_gid, uint64_t *keys, int32_t 
     if (!c->built) return fail(ART_E_STATE, "art_get_lbvh: scene not built");
     int32_t r = use_device(c); if (r) return r;
     r = refresh_now(c); if (r) return r;       // after a move: the boxes of where the models are now (the keys and the topology are the build's)
+    if (!c->bvh.canon_boxes) c->binary_epoch = ~0ull;   // the build left the canonical tree's boxes for now: have them made
     r = ensure_binary(c, true); if (r) return r;
     size_t T = c->T, NI = T > 1 ? T - 1 : 0;
     if (leaf_gid) HIPC(hipMemcpy(leaf_gid, c->bvh.leaf_gid, T * 4, hipMemcpyDeviceToHost));

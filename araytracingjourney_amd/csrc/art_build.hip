@@ -643,6 +643,7 @@ hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s) 
         else k_emit_nodes<<<(NN + B - 1) / B, B, 0, s>>>(T, l.child, l.node_lo, l.node_hi, l.leaf_lo, l.leaf_hi, l.nodes);
         HIPQ(hipGetLastError());
         HIPQ(hipStreamSynchronize(s));
+        l.canon_boxes = true;
         return hipSuccess;
     };
     hipError_t e = body();
@@ -657,7 +658,7 @@ void lbvh_free(Lbvh &l) {
     l = Lbvh{};
 }
 
-hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
+hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node_boxes) {
     const uint32_t T = in.T;
     const uint32_t NI = T > 1 ? T - 1 : 1;
     out = Lbvh{};
@@ -690,9 +691,10 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s) {
         k_leaves<<<GT, B, 0, s>>>(T, out.leaf_gid, triw, tlo, thi, out.tri_prim, in.prim_first_tri, out.leaf_lo, out.leaf_hi, out.tris, in.prims, out.shade_tris);
         if (T > 1) {
             k_karras<<<(T - 1 + B - 1) / B, B, 0, s>>>((int)T, out.keys, out.leaf_gid, out.child, parent_int, parent_leaf);
-            k_refit<<<GT, B, 0, s>>>(T, out.child, parent_int, parent_leaf, out.leaf_lo, out.leaf_hi, out.node_lo, out.node_hi, arrive);
+            if (node_boxes) k_refit<<<GT, B, 0, s>>>(T, out.child, parent_int, parent_leaf, out.leaf_lo, out.leaf_hi, out.node_lo, out.node_hi, arrive); // (1.8 ms of arrival-counter waits on config 2: skipped when nothing will read the boxes)
         }
-        k_emit_nodes<<<(NI + B - 1) / B, B, 0, s>>>(T, out.child, out.node_lo, out.node_hi, out.leaf_lo, out.leaf_hi, out.nodes);
+        if (node_boxes) k_emit_nodes<<<(NI + B - 1) / B, B, 0, s>>>(T, out.child, out.node_lo, out.node_hi, out.leaf_lo, out.leaf_hi, out.nodes);
+        out.canon_boxes = node_boxes;
         HIPQ(hipGetLastError());
         HIPQ(hipStreamSynchronize(s));
         return hipSuccess;

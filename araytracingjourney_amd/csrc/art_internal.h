@@ -84,6 +84,7 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevNode4 *wide;         // [n_wide] collapsed + quantised traversal structure
     DevNodeW *widef;        // [n_wide] the same topology with float boxes (packet walk)
     uint32_t n_wide;
+    bool canon_boxes = false;          // host: node_lo / node_hi of the canonical tree hold its boxes (else: not computed yet, binary_refit does it on demand)
     uint32_t log = 0;                  // host: ArtTuning.log of the context that builds (bit 0: build phase times to stderr)
     std::vector<uint32_t> wide_levels; // host: first wide node of every level of the collapse (breadth-first numbering), then n_wide -- the refit goes through them bottom-up
     DevShadeTri *shade_tris; // [T] leaf order
@@ -92,7 +93,9 @@ struct Lbvh {               // canonical binary LBVH, device arrays
 };
 // art_jpeg.hip: baseline JPEG -> RGB8 (channels 3) or R8 (1), row-major
 bool decode_jpeg(const uint8_t *data, size_t n, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, int &channels, std::string &err);
-hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s); // allocates out.*, frees temporaries
+// allocates out.*, frees temporaries.  node_boxes false: the canonical tree's node boxes and the 64-byte node records are left for later -- a PREFER_FAST_TRACE build makes its
+// own tree over the leaves and never reads them (binary_refit fills them in when the parity surface asks: out.canon_boxes)
+hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node_boxes = true);
 // the 4-wide collapses (DevNode4, DevNodeW): built on first use -- only the per-ray shadow/AO walks and ART_PACKET_WIDE need them
 hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host = false); // level by level on the device, or the one-thread host loop (A/B)
 // PREFER_FAST_TRACE: rebuilds l.nodes as a binned-SAH tree over the same leaves (host threads); frames are unchanged by construction
