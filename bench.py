@@ -385,6 +385,7 @@ def main():
     moving_model = None
     if extras and not args.ao and not glb and args.moving_model > 0 and len(sc.primitives) > 1:
         import math
+        r.close()                     # the benchmarked context is done (its streams go back to the pool: two rings of 16 would share the 16 hardware queues)
         mv = renderer.Renderer((W, H), device=local_rank, frames_in_flight=F, tuning=tuning)
         mv.add_model(sc.primitives[:-1])
         mv.add_model(sc.primitives[-1:])

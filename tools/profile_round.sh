@@ -13,6 +13,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# PARTS="c2" or "others" runs one half only (a gpurun call is at most 20 minutes)
+if [ "${PARTS:-c2 others}" != "others" ]; then
 python3 $R/bench.py --steps 1000 --warmup 50 > $OUT/bench.log 2>&1
 grep '^{' $OUT/bench.log | tail -1 > $OUT/${TAG}_bench_line.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 1000 --warmup 50 --plain > $OUT/stats.log 2>&1
@@ -20,6 +22,10 @@ cp "$(find $OUT/stats -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_kernel_s
 grep '^{' $OUT/stats.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 bash $R/tools/pmc.sh $TAG > $OUT/${TAG}_pmc.txt 2> $OUT/pmc.err
 rm -rf $OUT/stats $R/gpurun_out/pmc_$TAG/p*/   # the raw traces are large; the summaries above are what is kept
+python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench20.log 2>&1; grep '^{' $OUT/bench20.log | tail -1 > $OUT/${TAG}_bench_line_steps20.json   # the driver's protocol
+echo "config 2 done"
+fi
+if [ "${PARTS:-c2 others}" == "c2" ]; then exit 0; fi
 # the other BASELINE configs on one GPU: a plain bench line and the counter passes a roofline needs, each (<tag>_configN.json, <tag>_pmc_cN.txt)
 other() { n=$1; steps=$2; shift 2; python3 $R/bench.py --plain --steps $steps --warmup 30 "$@" > $OUT/config$n.log 2>&1; grep '^{' $OUT/config$n.log | tail -1 > $OUT/${TAG}_config$n.json
           PMC_SHORT=1 bash $R/tools/pmc.sh ${TAG}_c$n "$@" > $OUT/${TAG}_pmc_c$n.txt 2> $OUT/pmc_c$n.err; rm -rf $R/gpurun_out/pmc_${TAG}_c$n/p*/; echo "config $n done"; }
