@@ -226,6 +226,10 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
     __device__ __forceinline__ bool step_internal(Nodes wide, int *lds, int *ovf) {
         const uint4 *nq = reinterpret_cast<const uint4 *>(wide + this->cur);
         uint4 a = nq[0], b = nq[1], c = nq[2], d = nq[3];
+        // the child references arrive WITH the boxes: left to itself the compiler sinks their load below the box tests (it is only needed when a child is hit),
+        // which makes every node step two dependent memory round trips instead of one -- and the AO launch waits on memory 44 % of the time (profiles round3):
+        // config 5 16 980 -> 17 800 Mray/s
+        asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
         float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
         float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
         int refs[4] = {(int)d.x, (int)d.y, (int)d.z, (int)d.w};
@@ -233,7 +237,7 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
         // The slab with the entry plane of each axis chosen by the lane's direction sign -- ONE select per axis picks the word that holds the four children's near
         // planes, one the far planes -- instead of min / max of both planes per child: fma is monotone in the plane coordinate, so min(t0, t1) IS the near plane's
         // t for a box with lo <= hi, bit for bit (the packet walks' octant trick, per lane).  An absent child carries an inverted box (art_build.hip): whatever the
-        // signs it is left before it is entered, so no valid-mask test.  33 -> 22 vector instructions a child; config 5 16 440 -> ... Mray/s (profiles/README.md r4).
+        // signs it is left before it is entered, so no valid-mask test.  33 -> 22 vector instructions a child; config 5 16 440 -> 16 980 Mray/s (profiles/README.md round 3).
         const Ray &r = this->r;
         const bool ngx = r.inv.x < 0.0f, ngy = r.inv.y < 0.0f, ngz = r.inv.z < 0.0f;
         const uint32_t nxw = ngx ? b.w : b.x, fxw = ngx ? b.x : b.w, nyw = ngy ? c.x : b.y, fyw = ngy ? b.y : c.x, nzw = ngz ? c.y : b.z, fzw = ngz ? b.z : c.y;
@@ -249,7 +253,7 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
         }
         float tn = 3.0e38f; int ni = -1; // continue with the nearest hit child, stack the others
         if (ANY) { // an any-hit ray's answer does not depend on the order of its visits, only how soon a hit ends it: the first hit child in the node's own order (the
-                   // children are sorted along an axis) instead of the nearest saves the selection chain -- config 5 15 650 -> 16 440 Mray/s (profiles/README.md r4)
+                   // children are sorted along an axis) instead of the nearest saves the selection chain -- config 5 15 650 -> 16 440 Mray/s (profiles/README.md round 3)
 #pragma unroll
             for (int i = 3; i >= 0; i--) if (h[i]) ni = i;
         } else
