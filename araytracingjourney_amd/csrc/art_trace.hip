@@ -180,6 +180,7 @@ template <bool ANY, int OVF> struct TravBase {
         uint32_t pos = (uint32_t)~cur;
         const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
         float4 ta = tq[0], tb = tq[1], tc = tq[2], td = tq[3];   // v0 e1 e2 lo hi gid (DevTri)
+        asm volatile("" : "+v"(td.x), "+v"(td.y), "+v"(td.z), "+v"(td.w), "+v"(tc.y), "+v"(tc.z), "+v"(tc.w)); // the box arrives with the vertices (else its load sinks below the triangle test: a second round trip for the lanes that pass it)
         float te, t, u, v;
         // triangle test first: the lane is here because this very box passed in the parent, so the slab (needed for t_eff and for
         // the conjunction) would nearly always run; after the triangle test it runs for the few hits only.  Same accept().
