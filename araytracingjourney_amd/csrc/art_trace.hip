@@ -759,10 +759,11 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
                         uint32_t p, smp;                               // smp: the sample's rank in the pixel's azimuth order (k_ao_table)
                         const bool real = ao_slot_decode(sidx, a.spp, p, smp);
                         float4 po = real ? a.ao_pix[2 * (size_t)p] : make_float4(0.f, 0.f, 0.f, __int_as_float(kAoNothingNear));
+                        float4 pn = real ? a.ao_pix[2 * (size_t)p + 1] : make_float4(0.f, 0.f, 1.f, 0.f);   // both halves of the pixel record in one round trip (the table entry needs the second)
+                        asm volatile("" : "+v"(pn.x), "+v"(pn.y), "+v"(pn.z), "+v"(pn.w));
                         int entry = __float_as_int(po.w);
                         if (entry == kAoNothingNear) a.occl[sidx] = 0; // a padding slot, a miss pixel, or no box within the AO radius: unoccluded, nothing to trace
                         else {
-                            float4 pn = a.ao_pix[2 * (size_t)p + 1];
                             float4 t = a.ao_tab[smp * kAoNoiseTile + __float_as_uint(pn.w)];
                             tr.start(mk(po.x, po.y, po.z), ao_dir(mk(pn.x, pn.y, pn.z), t.x, t.y, t.z), a.ao_radius * 0.01f, a.ao_radius);
                             tr.cur = entry;                            // the walk starts below the part of the tree that every ray of this pixel would cross alike
