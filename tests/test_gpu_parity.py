@@ -920,14 +920,16 @@ def test_lights_change_every_frame_while_sixteen_frames_are_in_flight(R, orc, ge
     r.close()
 
 
-def _pose(base, i):
-    """frame i's object -> world matrix of the moving model: its base matrix, rotated about y and z and carried along a small loop (float32 3x4, row-major)"""
+def _pose(base, i, warp=False):
+    """frame i's object -> world matrix of the moving model: its base matrix, rotated about y and z and carried along a small loop (float32 3x4, row-major);
+    warp: also mirrored, scaled differently along each axis and sheared (a negative determinant, an inverse-transpose that is not the matrix)"""
     import math
     a, b = 0.21 * i, 0.13 * i
     ry = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1]])
     rz = np.array([[math.cos(b), -math.sin(b), 0, 0], [math.sin(b), math.cos(b), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
     t = np.eye(4); t[:3, 3] = (0.25 * math.sin(0.4 * i), 0.05 * i, 0.2 * math.cos(0.3 * i) - 0.2)
-    m = t @ ry @ rz @ np.vstack([np.asarray(base, np.float64).reshape(3, 4), [0, 0, 0, 1]])
+    w = np.array([[-0.8, 0.15, 0, 0], [0, 1.3, 0, 0], [0.1, 0, 0.6, 0], [0, 0, 0, 1]]) if warp else np.eye(4)
+    m = t @ ry @ rz @ w @ np.vstack([np.asarray(base, np.float64).reshape(3, 4), [0, 0, 0, 1]])
     return np.ascontiguousarray(m[:3], np.float32)
 
 
@@ -1043,8 +1045,8 @@ def test_a_moved_model_in_every_form_of_the_frame(R, orc, get_scene, scenes, for
     cam = oracle_camera(orc, sc, w, h)
     L = orc.make_lights(lights)
     r.render_frame()
-    for i in (3, 7):
-        m = _pose(moving[0].model, i)
+    for i in (3, 7, 9):
+        m = _pose(moving[0].model, i, warp=i == 9)                       # the last one mirrored, anisotropic and sheared: normals go by the inverse transpose
         model.set_model_matrix(m)
         r.render_frame()
         S = _oracle_of_moved(orc, scenes, static, moving, m)
