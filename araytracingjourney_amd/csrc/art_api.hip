@@ -112,6 +112,8 @@ struct AsVersion {
     DevTri *tris = nullptr; DevNodeW *widef = nullptr; DevNode4 *wide = nullptr; DevPrim *prims = nullptr;
     bool owned = false;                  // version 0 aliases c->bvh.* and c->d_prims
     DevPrim *h_prims = nullptr;          // pinned staging copy of the primitive table (the upload is a fully asynchronous copy on the frame's stream)
+    uint8_t *d_touched = nullptr, *h_touched = nullptr; // per primitive: moved since this version was written (device copy + pinned staging)
+    uint8_t *dirty = nullptr;            // per 4-wide node: a box below it changes in the refit under way; all zero between refits
     uint64_t used[kMaxFrameSlots] = {};  // frame number + 1 of the newest launch on each ring slot that read this version (0: none)
     bool aux[kMaxFrameSlots] = {};       // art_trace_ao / art_present ran behind that frame on the slot's stream
     hipEvent_t ready = nullptr; bool ready_known = true; uint32_t ready_slot = 0; // the refit that wrote it: recorded on ring slot ready_slot's stream
@@ -149,6 +151,7 @@ struct ArtContext {
     // moving models (art_scene_set_model_matrix): versions of the structure, the primitive table as the next refit will upload it
     std::vector<AsVersion> as; uint32_t as_cur = 0; bool xform_dirty = false;
     std::vector<DevPrim> h_dev_prims;          // host copy of d_prims (build order), matrices kept current
+    std::vector<uint64_t> prim_moved;          // per primitive: the refit (as_epoch numbering) that first shows its latest move; 0: where the build put it
     uint64_t as_epoch = 0, binary_epoch = 0;   // refits so far; the refit the binary trees / node records reflect
     double as_cost0 = 0.0; float refit_cost_ratio = 1.0f; uint32_t refits = 0, rebuilds = 0; float last_refit_ms = 0.f;
     ArtCamera camera{};
@@ -258,6 +261,8 @@ void as_release(ArtContext *c) {
     for (AsVersion &V : c->as) {
         if (V.owned) { (void)hipFree(V.tris); (void)hipFree(V.widef); (void)hipFree(V.wide); (void)hipFree(V.prims); }
         if (V.h_prims) (void)hipHostFree(V.h_prims);
+        if (V.h_touched) (void)hipHostFree(V.h_touched);
+        (void)hipFree(V.d_touched); (void)hipFree(V.dirty);
         if (V.h_cost) (void)hipHostFree(V.h_cost);
         (void)hipFree(V.d_cost);
         for (hipEvent_t e : {V.ready, V.t0, V.t1, V.cost_ev}) if (e) (void)hipEventDestroy(e);
@@ -274,6 +279,11 @@ int32_t as_create(ArtContext *c) {
     const size_t np = c->h_dev_prims.size(), T = c->T, NW = c->bvh.n_wide;
     c->as.assign(K, AsVersion{});
     auto body = [&]() -> int32_t {
+        if (!c->bvh.leaf_parent) { // who holds whom in the 4-wide tree: the marks of a refit go up along it
+            HIPC(hipMalloc(&c->bvh.leaf_parent, T * 4)); HIPC(hipMalloc(&c->bvh.node_parent, NW * 4));
+            launch_wide_parents(c->bvh.n_wide, c->bvh.widef, c->bvh.leaf_parent, c->bvh.node_parent, c->main_stream());
+            HIPC(hipGetLastError());
+        }
         for (uint32_t v = 0; v < K; v++) {
             AsVersion &V = c->as[v];
             if (v == 0) { V.tris = c->bvh.tris; V.widef = c->bvh.widef; V.wide = c->bvh.wide; V.prims = c->d_prims.p; }
@@ -284,6 +294,7 @@ int32_t as_create(ArtContext *c) {
                 HIPC(hipMemcpy(V.wide, c->bvh.wide, NW * sizeof(DevNode4), hipMemcpyDeviceToDevice)); HIPC(hipMemcpy(V.prims, c->d_prims.p, np * sizeof(DevPrim), hipMemcpyDeviceToDevice));
             }
             HIPC(hipHostMalloc((void **)&V.h_prims, np * sizeof(DevPrim), hipHostMallocDefault)); HIPC(hipHostMalloc((void **)&V.h_cost, 16, hipHostMallocDefault)); HIPC(hipMalloc(&V.d_cost, 16));
+            HIPC(hipHostMalloc((void **)&V.h_touched, np, hipHostMallocDefault)); HIPC(hipMalloc(&V.d_touched, np)); HIPC(hipMalloc(&V.dirty, NW)); HIPC(hipMemset(V.dirty, 0, NW));
             HIPC(hipEventCreateWithFlags(&V.ready, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&V.cost_ev, hipEventDisableTiming));
             HIPC(hipEventCreate(&V.t0)); HIPC(hipEventCreate(&V.t1));
         }
@@ -341,10 +352,12 @@ int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
     if (c->graph_mode) drop_graphs(c); // a captured frame holds the old version's pointers
     const size_t np = c->h_dev_prims.size();
     std::memcpy(V.h_prims, c->h_dev_prims.data(), np * sizeof(DevPrim));
+    for (size_t p = 0; p < np; p++) V.h_touched[p] = (p < c->prim_moved.size() && c->prim_moved[p] > V.epoch) ? 1 : 0;   // what moved since THIS version was written (it may be several refits behind)
     HIPC(hipEventRecord(V.t0, s));
     HIPC(hipMemcpyAsync(V.prims, V.h_prims, np * sizeof(DevPrim), hipMemcpyHostToDevice, s));
-    launch_retri(c->T, c->bvh.shade_tris, V.prims, V.tris, s);
-    launch_wide_refit(c->bvh.wide_levels, V.tris, V.wide, V.widef, V.d_cost, s);
+    HIPC(hipMemcpyAsync(V.d_touched, V.h_touched, np, hipMemcpyHostToDevice, s));
+    launch_retri(c->T, c->bvh.shade_tris, V.prims, V.d_touched, c->bvh.leaf_parent, V.dirty, V.tris, s);
+    launch_wide_refit(c->bvh.wide_levels, V.tris, V.wide, V.widef, c->bvh.node_parent, V.dirty, V.d_cost, s);
     HIPC(hipEventRecord(V.t1, s)); V.timed = true;
     HIPC(hipMemcpyAsync(V.h_cost, V.d_cost, 16, hipMemcpyDeviceToHost, s));
     HIPC(hipEventRecord(V.cost_ev, s)); V.cost_pending = true;
@@ -810,6 +823,7 @@ int32_t art_scene_set_model_matrix(ArtContext *c, uint32_t first, uint32_t n, co
         std::memcpy(p.o2w, model3x4, 48); std::memcpy(p.w2o, w2o, 48);
         if (!c->built || id >= c->h_dev_prims.size()) continue;  // takes effect with the build
         std::memcpy(c->h_dev_prims[id].o2w, model3x4, 48); std::memcpy(c->h_dev_prims[id].w2o, w2o, 48);
+        if (id < c->prim_moved.size()) c->prim_moved[id] = c->as_epoch + 1;   // the next refit is the first to show it
         if (p.enabled) c->xform_dirty = true;                    // instanced: the next art_trace (or query) refits first
     }
     return ART_OK;
@@ -867,6 +881,7 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(hipMemcpy(c->d_first_tri.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
     c->h_first_tri = first;
     c->h_dev_prims = dp;
+    c->prim_moved.assign(dp.size(), 0);
     c->T = T;
     BuildInputs in{c->d_prims.p, (uint32_t)dp.size(), c->d_first_tri.p, T, c->cfg.morton_bits};
     hipEvent_t e0, e1;

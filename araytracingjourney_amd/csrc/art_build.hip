@@ -494,12 +494,17 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
 
 // the version's triangle records from the object-space shading records (the vertices k_leaves gathered) and the version's object->world matrices: the very
 // operations of k_soup (transform) and k_leaves (edges, box), so a refit with unchanged matrices writes the bits that are there
-__global__ __launch_bounds__(256) void k_retri(uint32_t T, const DevShadeTri *__restrict__ shade, const DevPrim *__restrict__ prims, DevTri *__restrict__ tris) {
+// Only what moved is made again: touched[primitive] says whose triangles (the primitives moved since this VERSION was last written), a rewritten triangle marks the
+// 4-wide node that holds it (dirty[]), and the level passes below go up from the marked nodes only -- a small model moving in a big scene costs its own share.
+__global__ __launch_bounds__(256) void k_retri(uint32_t T, const DevShadeTri *__restrict__ shade, const DevPrim *__restrict__ prims, const uint8_t *__restrict__ touched,
+                                               const uint32_t *__restrict__ leaf_parent, uint8_t *__restrict__ dirty, DevTri *__restrict__ tris) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= T) return;
+    const uint32_t prim = __float_as_uint(shade[p].f[34]);
+    if (!touched[prim]) return;
     const float4 *sq = reinterpret_cast<const float4 *>(shade + p);
-    const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s8 = sq[8];
-    const float *m = prims[__float_as_uint(s8.z)].o2w;
+    const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2];
+    const float *m = prims[prim].o2w;
     const float3 w0 = xform_point(m, s0.x, s0.y, s0.z), w1 = xform_point(m, s0.w, s1.x, s1.y), w2 = xform_point(m, s1.z, s1.w, s2.x);
     const float a[3] = {w0.x, w0.y, w0.z}, b[3] = {w1.x, w1.y, w1.z}, c[3] = {w2.x, w2.y, w2.z};
     DevTri t;
@@ -509,12 +514,26 @@ __global__ __launch_bounds__(256) void k_retri(uint32_t T, const DevShadeTri *__
     }
     t.f[15] = tris[p].f[15]; // the global triangle id never changes
     tris[p] = t;
+    dirty[leaf_parent[p]] = 1;
+}
+// which 4-wide node holds a leaf, which one a node (the root: ~0): made once per tree, when its first model moves
+__global__ __launch_bounds__(256) void k_wide_parents(uint32_t n_wide, const DevNodeW *__restrict__ widef, uint32_t *__restrict__ leaf_parent, uint32_t *__restrict__ node_parent) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_wide) return;
+    if (w == 0) node_parent[0] = ~0u;
+    for (int i = 0; i < 4; i++) {
+        const int32_t ch = widef[w].child[i];
+        if (ch == kAbsentChild) continue;
+        if (ch < 0) leaf_parent[(uint32_t)~ch] = w; else node_parent[ch] = w;
+    }
 }
 
 // One child box of one node of the 4-wide tree: a leaf child's box is its triangle's, an internal child's the union of that node's own child boxes (float min / max
 // are exact, so whatever the order the union is the box a build would find).  Four neighbouring lanes share a node; the pass is loads and min / max only -- the
 // quantised records are made afterwards, for all nodes at once (k_wide_requant): their double-precision arithmetic does not belong on the bottom-up critical path.
-__device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const DevTri *__restrict__ tris, DevNodeW *widef) {
+__device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const DevTri *__restrict__ tris, DevNodeW *widef, const uint32_t *__restrict__ node_parent, uint8_t *dirty) {
+    if (!dirty[w]) return;                              // nothing below this node moved
+    if (i == 0) { const uint32_t up = node_parent[w]; if (up != ~0u) dirty[up] = 1; }   // its parent's box of it changes: a level further up, a launch (or a barrier) later
     const int32_t ch = widef[w].child[i];
     if (ch == kAbsentChild) return;
     float lo[3], hi[3];
@@ -533,17 +552,17 @@ __device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const D
     float *o = widef[w].box[i];
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
 }
-__global__ __launch_bounds__(256) void k_wide_refit(uint32_t first, uint32_t n, const DevTri *__restrict__ tris, DevNodeW *widef) {
+__global__ __launch_bounds__(256) void k_wide_refit(uint32_t first, uint32_t n, const DevTri *__restrict__ tris, DevNodeW *widef, const uint32_t *__restrict__ node_parent, uint8_t *dirty) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 4u * n) wide_union_child(first + (i >> 2), i & 3u, tris, widef);
+    if (i < 4u * n) wide_union_child(first + (i >> 2), i & 3u, tris, widef, node_parent, dirty);
 }
 // the top of the tree: levels of at most 1024 nodes each, bottom-up in ONE workgroup (a launch per level would cost more than the levels)
 constexpr int kTopLevels = 16;
 struct TopLevels { uint32_t first[kTopLevels + 1]; int n; }; // level i = nodes [first[i], first[i + 1])
-__global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevTri *__restrict__ tris, DevNodeW *widef) {
+__global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevTri *__restrict__ tris, DevNodeW *widef, const uint32_t *__restrict__ node_parent, uint8_t *dirty) {
     for (int lv = L.n - 1; lv >= 0; lv--) {
         const uint32_t n = L.first[lv + 1] - L.first[lv];
-        for (uint32_t i = threadIdx.x; i < 4u * n; i += 1024u) wide_union_child(L.first[lv] + (i >> 2), i & 3u, tris, widef);
+        for (uint32_t i = threadIdx.x; i < 4u * n; i += 1024u) wide_union_child(L.first[lv] + (i >> 2), i & 3u, tris, widef, node_parent, dirty);
         __threadfence_block();
         __syncthreads(); // the level above reads these records
     }
@@ -552,17 +571,19 @@ __global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevT
 // cost[0] += the half-areas of all child boxes (the measure of the rays that cross each box: what a walk pays for), cost[1] = half-area of the root's union.  A refit
 // can only keep or grow the sum against the same rays; a rebuild restores it.  The rule compares the plain sums: dividing by the root's area would reward a model
 // that flies off (the root grows faster than the sum) although the rays of a camera among the rest of the scene cross more boxes than before.
-__global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const DevNodeW *__restrict__ widef, DevNode4 *__restrict__ wide, double *cost) {
+__global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const DevNodeW *__restrict__ widef, DevNode4 *__restrict__ wide, uint8_t *dirty /*null: every node*/, double *cost) {
     __shared__ double s_part[4];
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     double a = 0.0;
     if (w < n_wide) {
+        const bool requant = wide && (!dirty || dirty[w]);   // the double-precision quantisation only where a box changed; the cost sums every node
+        if (dirty && dirty[w]) dirty[w] = 0;                  // (the marks are this version's: cleared for its next refit)
         const float4 *q = reinterpret_cast<const float4 *>(widef + w);
         const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
         const int4 ch = *reinterpret_cast<const int4 *>(&widef[w].child[0]);
         const float lo[4][3] = {{a0.x, a0.y, a0.z}, {a1.z, a1.w, a2.x}, {a3.x, a3.y, a3.z}, {a4.z, a4.w, a5.x}}, hi[4][3] = {{a0.w, a1.x, a1.y}, {a2.y, a2.z, a2.w}, {a3.w, a4.x, a4.y}, {a5.y, a5.z, a5.w}};
         const int nc = (ch.x != kAbsentChild) + (ch.y != kAbsentChild) + (ch.z != kAbsentChild) + (ch.w != kAbsentChild); // the valid children are slots 0 .. nc-1
-        if (wide) {
+        if (requant) {
             const float *plo[4] = {lo[0], lo[1], lo[2], lo[3]}, *phi[4] = {hi[0], hi[1], hi[2], hi[3]};
             DevNode4 d;
             wide_quantise(plo, phi, nc, d);
@@ -583,29 +604,33 @@ __global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const Dev
     if (threadIdx.x == 0) { double t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]); if (t != 0.0) atomicAdd(&cost[0], t); }
 }
 
-void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, DevTri *tris, hipStream_t s) {
-    k_retri<<<(T + 255) / 256, 256, 0, s>>>(T, shade, prims, tris);
+void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, const uint8_t *touched, const uint32_t *leaf_parent, uint8_t *dirty, DevTri *tris, hipStream_t s) {
+    k_retri<<<(T + 255) / 256, 256, 0, s>>>(T, shade, prims, touched, leaf_parent, dirty, tris);
 }
-void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, double *cost, hipStream_t s) {
+void launch_wide_parents(uint32_t n_wide, const DevNodeW *widef, uint32_t *leaf_parent, uint32_t *node_parent, hipStream_t s) {
+    k_wide_parents<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, leaf_parent, node_parent);
+}
+void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, const uint32_t *node_parent, uint8_t *dirty, double *cost, hipStream_t s) {
     const int n_levels = (int)levels.size() - 1;
     if (n_levels <= 0) return;
     int top = 0; // levels [0, top) go into the one-workgroup launch
     while (top < n_levels && top < kTopLevels && levels[top + 1] - levels[top] <= 1024u) top++;
     for (int lv = n_levels - 1; lv >= top; lv--) {
         const uint32_t n = levels[lv + 1] - levels[lv];
-        k_wide_refit<<<(4 * n + 255) / 256, 256, 0, s>>>(levels[lv], n, tris, widef);
+        k_wide_refit<<<(4 * n + 255) / 256, 256, 0, s>>>(levels[lv], n, tris, widef, node_parent, dirty);
     }
     if (top) {
         TopLevels L{}; L.n = top;
         for (int i = 0; i <= top; i++) L.first[i] = levels[i];
-        k_wide_refit_top<<<1, 1024, 0, s>>>(L, tris, widef);
+        k_wide_refit_top<<<1, 1024, 0, s>>>(L, tris, widef, node_parent, dirty);
     }
-    launch_wide_cost((uint32_t)levels.back(), widef, wide, cost, s);
+    (void)hipMemsetAsync(cost, 0, 16, s);
+    k_wide_requant<<<((uint32_t)levels.back() + 255) / 256, 256, 0, s>>>((uint32_t)levels.back(), widef, wide, dirty, cost);
 }
 // the quantised records (wide; null: leave them) and the cost (2 doubles) of the float records
 void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide, double *cost, hipStream_t s) {
     (void)hipMemsetAsync(cost, 0, 16, s);
-    k_wide_requant<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, wide, cost);
+    k_wide_requant<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, wide, nullptr, cost);
 }
 
 // The binary trees (the canonical LBVH of art_get_lbvh, the traversal tree of the per-ray / binary walks) after a refit: leaf boxes from the triangle records,
@@ -654,7 +679,7 @@ hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s) 
 void lbvh_free(Lbvh &l) {
     hipFree(l.wide); hipFree(l.widef); hipFree(l.shade_tris);
     hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
-    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim); hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi);
+    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim); hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi); hipFree(l.leaf_parent); hipFree(l.node_parent);
     l = Lbvh{};
 }
 

@@ -88,6 +88,8 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     uint32_t log = 0;                  // host: ArtTuning.log of the context that builds (bit 0: build phase times to stderr)
     std::vector<uint32_t> wide_levels; // host: first wide node of every level of the collapse (breadth-first numbering), then n_wide -- the refit goes through them bottom-up
     DevShadeTri *shade_tris; // [T] leaf order
+    uint32_t *leaf_parent;  // [T] the 4-wide node that holds a leaf, [n_wide] the one that holds a node (root: ~0): made with the first refit (launch_wide_parents), else null
+    uint32_t *node_parent;
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
 };
@@ -108,8 +110,10 @@ void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s);
 // refit after a model moved (art_build.hip): the triangle records of a version of the acceleration structure from the shading records and that version's
 // primitive table; its 4-wide nodes bottom-up, level by level (l.wide_levels); the tree's surface-area cost (2 doubles: sum of child half-areas, root half-area);
 // the binary trees and node records from a version's triangles (on demand, synchronises)
-void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, DevTri *tris, hipStream_t s);
-void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, double *cost, hipStream_t s); // boxes bottom-up, then the quantised records + cost
+// touched: one byte per primitive (whose triangles to make again); dirty: one byte per 4-wide node, all zero between refits (marks go up from the rewritten triangles)
+void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, const uint8_t *touched, const uint32_t *leaf_parent, uint8_t *dirty, DevTri *tris, hipStream_t s);
+void launch_wide_parents(uint32_t n_wide, const DevNodeW *widef, uint32_t *leaf_parent, uint32_t *node_parent, hipStream_t s);
+void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, const uint32_t *node_parent, uint8_t *dirty, double *cost, hipStream_t s); // boxes bottom-up from the marked nodes, then their quantised records + the cost
 void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide /*null: cost only*/, double *cost, hipStream_t s);
 hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s);
 struct TraceTune { uint32_t chunk, refill, blocks, leaf_batch; }; // overrides of the persistent per-ray tracer's presets (ArtTuning.trace_chunk / trace_refill / trace_blocks; 0 = the preset): they travel with every launch
