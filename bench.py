@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--gather-launches", type=int, default=-1, help="N>1: ring slots (launches) per exchange; 0 = the whole ring (the slots are contiguous, so a group travels as one message "
                     "per peer); default: a quarter of the timed launches, at most the ring -- a run of a few launches then still overlaps its exchanges with its tracing "
                     "instead of paying one exchange of everything behind the last frame")
+    ap.add_argument("--second-placement-seconds", type=float, default=120.0, help="N>1: the second of the two placements runs under a timer of this many seconds; past it rank 0 prints the first "
+                    "placement's line and every rank exits with code 0 (0 = no timer)")
     ap.add_argument("--one-placement", action="store_true", help="N>1: time only the placement --roots names (default: both, back to back -- `value` is --roots', the other one's rate is reported beside it)")
     ap.add_argument("--roots", default="spread", choices=["spread", "rank0"],
                     help="N>1: where frames are assembled (the placement `value` is measured with; the other is timed too and reported as value_rank0_root / value_spread_roots).  'spread' (default) = frame f on rank f mod N: every group of launches is one grouped ncclSend / ncclRecv (each frame's "
@@ -290,275 +292,296 @@ def main():
             placements = ["rank0"]
     else:
         placements = [None]
-    jobs = {}
-    for pl in placements:             # N > 1: both placements of the assembled frames back to back, each a whole job of its own (context, communicator, settle, warm-up, K timed steps)
-        jobs[pl] = run_job(pl)
-    main_job = jobs[placements[0]]
-    r, wall, stage, n_timed, frame_ok, counts, st, rays_total, shadow_total, B, transport, relief, spread, settle_launches, step, fence = (main_job[k] for k in (
-        "r", "wall", "stage", "n_timed", "frame_ok", "counts", "st", "rays_total", "shadow_total", "B", "transport", "relief", "spread", "settle_launches", "step", "fence"))
-    other = None
-    if len(placements) > 1:
-        o = jobs[placements[1]]
-        other = dict(placement=placements[1], value=o["value"], unit="Mray/s", ms_per_step=o["ms_per_step"], gathered_frame_equals_single_gpu_frame=o["frame_ok"], gathers=o["counts"]["gathers"],
-                     frames_per_exchange=o["counts"]["launches_per_gather"] * o["B"], rank0_share_of_an_equal_share=f"{256 - o['relief']}/256")
-    mg = None
+    def finish(main_pl, other, bailing=False):   # everything behind the timed region(s): the extra legs (one GPU), the roofline, the line
+        main_job = jobs[main_pl]
+        r, wall, stage, n_timed, frame_ok, counts, st, rays_total, shadow_total, B, transport, relief, spread, settle_launches, step, fence = (main_job[k] for k in (
+            "r", "wall", "stage", "n_timed", "frame_ok", "counts", "st", "rays_total", "shadow_total", "B", "transport", "relief", "spread", "settle_launches", "step", "fence"))
+        mg = None
 
-    extras = world == 1 and not args.plain
-    # ---- steady state: the same K frames with the ring kept full on both sides (device timestamps behind the last priming frame and behind frame K) ----
-    steady = None
-    if extras and not args.ao and args.steps >= 4 * F:   # (a run of fewer than four ring depths is all fill and drain: nothing steady to report)
-        for _ in range(2 * F):
-            r.trace()
-        r.timestamp_mark(0)
-        for _ in range(args.steps):
-            r.trace()
-        r.timestamp_mark(1)
-        for _ in range(F):            # frames behind the mark: the ones in front of it never run on an emptying GPU
-            r.trace()
-        ms = r.timestamp_elapsed_ms()
-        fence()
-        steady = dict(ms_per_step=ms / args.steps, frames=args.steps, protocol=f"{2 * F} priming frames, device timestamp behind the last of them, {args.steps} frames, timestamp, {F} more frames; no host "
-                                                                               "synchronisation in between: what a render loop sees, where `value` (fenced on both sides) also pays the fill and the drain of the ring")
-    # ---- one frame on the GPU at a time, each timed by its own HIP events (median / p10 / p90 over 100 frames) -----------------
-    alone = None
-    if extras:
-        spans = []
-        for _ in range(100):
-            step()
-            fence()
-            spans.append(r.collect_timings()[0]["frame_ms"])
-        spans.sort()
-        alone = dict(median_ms=spans[50], p10_ms=spans[10], p90_ms=spans[90], frames=100)
-        if not args.ao and F > 1:
-            # the same frame in a context that keeps ONE frame in flight: there the wave plan splits the blocks whose packets crawl (with 16 in
-            # flight nothing needs splitting), which is what a caller that wants a frame's latency rather than frames per second would use
-            one = make_renderer(device=local_rank, frames_in_flight=1)
-            one.upload_state()
-            for _ in range(24):               # the plan settles within a few frames
-                one.trace(); one.sync()
-            one.collect_timings()
-            spans = []
-            for _ in range(60):
-                one.trace(); one.sync()
-                spans.append(one.collect_timings()[0]["frame_ms"])
-            spans.sort()
-            alone["single_frame_context"] = dict(median_ms=spans[30], p10_ms=spans[6], p90_ms=spans[54], frames=60, split_blocks=one.stats()["split_blocks"])
-            one.close()
-
-    # ---- a moving camera: every frame a different pose (no frame in flight shares its BVH path with its neighbours) --------------------------
-    campath = None
-    tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights)) if (args.scene == "sponza" and args.detail == 1.0 and not glb) else None
-    if args.scene == "bistro" and args.detail == 1.0 and (W, H) == (1920, 1080) and not glb:
-        tag = "c4_bistro_like_1080p_1light"
-    if extras and not args.ao and args.camera_path > 0:
-        poses = scenes.camera_path(sc, args.camera_path)
-        cams = [renderer.Camera(p["pos"], p["dir"], W / H, p["fovy"], p["znear"], p["zfar"]) for p in poses]
-        gold_path = os.path.join(ROOT, "tests", "golden", f"{tag}.camera_path_{args.camera_path}.json") if tag else None
-        gold = json.load(open(gold_path)) if gold_path and os.path.exists(gold_path) else None
-        rays_pose = []
-        for i, cam in enumerate(cams):            # every pose once alone: its ray counts, against the oracle's committed ones
-            r._camera = cam
-            r.upload_state(); r.trace(); r.sync()
-            ps = r.stats()
-            if gold:
-                assert (ps["shadow_rays"], ps["hit_pixels"]) == (gold["poses"][i]["shadow_rays"], gold["poses"][i]["hit_pixels"]), f"camera path pose {i}: GPU ray counts differ from the oracle's"
-            rays_pose.append(ps["primary_rays"] + ps["shadow_rays"])
-
-        def moving(n):
-            for i in range(n):
-                r._camera = cams[i % len(cams)]
-                r.upload_state()
+        extras = world == 1 and not args.plain
+        # ---- steady state: the same K frames with the ring kept full on both sides (device timestamps behind the last priming frame and behind frame K) ----
+        steady = None
+        if extras and not args.ao and args.steps >= 4 * F:   # (a run of fewer than four ring depths is all fill and drain: nothing steady to report)
+            for _ in range(2 * F):
                 r.trace()
-        moving(2 * F)
-        fence()
-        c0 = time.perf_counter()
-        moving(args.steps)
-        fence()
-        cwall = time.perf_counter() - c0
-        rays_moved = sum(rays_pose[i % len(cams)] for i in range(args.steps))
-        campath = dict(poses=len(cams), value=rays_moved / cwall / 1e6, unit="Mray/s", ms_per_step=cwall * 1e3 / args.steps, rays_per_frame_min=min(rays_pose), rays_per_frame_max=max(rays_pose),
-                       ray_counts_checked_against_oracle=bool(gold), protocol="art_set_camera before every frame, fenced on both sides like `value`")
-        r._camera = renderer.Camera(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
-        r.upload_state()
+            r.timestamp_mark(0)
+            for _ in range(args.steps):
+                r.trace()
+            r.timestamp_mark(1)
+            for _ in range(F):            # frames behind the mark: the ones in front of it never run on an emptying GPU
+                r.trace()
+            ms = r.timestamp_elapsed_ms()
+            fence()
+            steady = dict(ms_per_step=ms / args.steps, frames=args.steps, protocol=f"{2 * F} priming frames, device timestamp behind the last of them, {args.steps} frames, timestamp, {F} more frames; no host "
+                                                                                   "synchronisation in between: what a render loop sees, where `value` (fenced on both sides) also pays the fill and the drain of the ring")
+        # ---- one frame on the GPU at a time, each timed by its own HIP events (median / p10 / p90 over 100 frames) -----------------
+        alone = None
+        if extras:
+            spans = []
+            for _ in range(100):
+                step()
+                fence()
+                spans.append(r.collect_timings()[0]["frame_ms"])
+            spans.sort()
+            alone = dict(median_ms=spans[50], p10_ms=spans[10], p90_ms=spans[90], frames=100)
+            if not args.ao and F > 1:
+                # the same frame in a context that keeps ONE frame in flight: there the wave plan splits the blocks whose packets crawl (with 16 in
+                # flight nothing needs splitting), which is what a caller that wants a frame's latency rather than frames per second would use
+                one = make_renderer(device=local_rank, frames_in_flight=1)
+                one.upload_state()
+                for _ in range(24):               # the plan settles within a few frames
+                    one.trace(); one.sync()
+                one.collect_timings()
+                spans = []
+                for _ in range(60):
+                    one.trace(); one.sync()
+                    spans.append(one.collect_timings()[0]["frame_ms"])
+                spans.sort()
+                alone["single_frame_context"] = dict(median_ms=spans[30], p10_ms=spans[6], p90_ms=spans[54], frames=60, split_blocks=one.stats()["split_blocks"])
+                one.close()
 
-    # ---- a moving model: art_scene_set_model_matrix before every frame (row a3: the reference rebuilds its TLAS every frame so that models can move) --------
-    moving_model = None
-    if extras and not args.ao and not glb and args.moving_model > 0 and len(sc.primitives) > 1:
-        import math
-        r.close()                     # the benchmarked context is done (its streams go back to the pool: two rings of 16 would share the 16 hardware queues)
-        mv = renderer.Renderer((W, H), device=local_rank, frames_in_flight=F, tuning=tuning)
-        mv.add_model(sc.primitives[:-1])
-        mv.add_model(sc.primitives[-1:])
-        cam = mv.camera_mut()
-        cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
-        for d in lights:
-            mv.lights_mut().push_dict(d)
-        mv.prepare_first_frame()
-        mv.upload_state()
-        base = np.vstack([np.asarray(sc.primitives[-1].model, np.float64).reshape(3, 4), [0, 0, 0, 1]])
-        poses = []
-        for i in range(args.moving_model):   # a closed loop: rotation about y, a small orbit
-            a = 2 * math.pi * i / args.moving_model
-            ry = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1]])
-            t = np.eye(4); t[:3, 3] = (0.15 * math.cos(a) - 0.15, 0.05 * math.sin(2 * a), 0.15 * math.sin(a))
-            poses.append(np.ascontiguousarray((t @ ry @ base)[:3], np.float32))
-        model = mv.models_mut()[1]
-        rays_pose, refit_alone = [], []
-        for m in poses:                       # every pose once alone: its ray count, and the refit's device time with nothing else on the GPU
-            model.set_model_matrix(m)
-            mv.trace(); mv.sync()
-            ps = mv.stats()
-            rays_pose.append(ps["primary_rays"] + ps["shadow_rays"]); refit_alone.append(ps["refit_ms"])
+        # ---- a moving camera: every frame a different pose (no frame in flight shares its BVH path with its neighbours) --------------------------
+        campath = None
+        tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights)) if (args.scene == "sponza" and args.detail == 1.0 and not glb) else None
+        if args.scene == "bistro" and args.detail == 1.0 and (W, H) == (1920, 1080) and not glb:
+            tag = "c4_bistro_like_1080p_1light"
+        if extras and not args.ao and args.camera_path > 0:
+            poses = scenes.camera_path(sc, args.camera_path)
+            cams = [renderer.Camera(p["pos"], p["dir"], W / H, p["fovy"], p["znear"], p["zfar"]) for p in poses]
+            gold_path = os.path.join(ROOT, "tests", "golden", f"{tag}.camera_path_{args.camera_path}.json") if tag else None
+            gold = json.load(open(gold_path)) if gold_path and os.path.exists(gold_path) else None
+            rays_pose = []
+            for i, cam in enumerate(cams):            # every pose once alone: its ray counts, against the oracle's committed ones
+                r._camera = cam
+                r.upload_state(); r.trace(); r.sync()
+                ps = r.stats()
+                if gold:
+                    assert (ps["shadow_rays"], ps["hit_pixels"]) == (gold["poses"][i]["shadow_rays"], gold["poses"][i]["hit_pixels"]), f"camera path pose {i}: GPU ray counts differ from the oracle's"
+                rays_pose.append(ps["primary_rays"] + ps["shadow_rays"])
 
-        def moved(n):
-            for i in range(n):
-                model.set_model_matrix(poses[i % len(poses)])
-                mv.trace()
-        moved(2 * F); mv.sync()
-        m0 = time.perf_counter()
-        moved(args.steps); mv.sync()
-        mwall = time.perf_counter() - m0
-        ms_ = mv.stats()
-        refit_alone.sort()
-        moving_model = dict(poses=len(poses), value=sum(rays_pose[i % len(poses)] for i in range(args.steps)) / mwall / 1e6, unit="Mray/s", ms_per_step=mwall * 1e3 / args.steps,
-                            refit_ms=refit_alone[len(refit_alone) // 2], refit_ms_max=refit_alone[-1], refits=ms_["refits"], rebuilds=ms_["rebuilds"], refit_cost_ratio=ms_["refit_cost_ratio"],
-                            moving_triangles=sc.primitives[-1].n_tris, build_ms=ms_["build_ms"],
-                            protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, rotated and carried round a loop), fenced on both sides like `value`; "
-                                     "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses")
-        mv.close()
+            def moving(n):
+                for i in range(n):
+                    r._camera = cams[i % len(cams)]
+                    r.upload_state()
+                    r.trace()
+            moving(2 * F)
+            fence()
+            c0 = time.perf_counter()
+            moving(args.steps)
+            fence()
+            cwall = time.perf_counter() - c0
+            rays_moved = sum(rays_pose[i % len(cams)] for i in range(args.steps))
+            campath = dict(poses=len(cams), value=rays_moved / cwall / 1e6, unit="Mray/s", ms_per_step=cwall * 1e3 / args.steps, rays_per_frame_min=min(rays_pose), rays_per_frame_max=max(rays_pose),
+                           ray_counts_checked_against_oracle=bool(gold), protocol="art_set_camera before every frame, fenced on both sides like `value`")
+            r._camera = renderer.Camera(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
+            r.upload_state()
 
-    if rank != 0:
-        if world > 1:
+        # ---- a moving model: art_scene_set_model_matrix before every frame (row a3: the reference rebuilds its TLAS every frame so that models can move) --------
+        moving_model = None
+        if extras and not args.ao and not glb and args.moving_model > 0 and len(sc.primitives) > 1:
+            import math
+            r.close()                     # the benchmarked context is done (its streams go back to the pool: two rings of 16 would share the 16 hardware queues)
+            mv = renderer.Renderer((W, H), device=local_rank, frames_in_flight=F, tuning=tuning)
+            mv.add_model(sc.primitives[:-1])
+            mv.add_model(sc.primitives[-1:])
+            cam = mv.camera_mut()
+            cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
+            for d in lights:
+                mv.lights_mut().push_dict(d)
+            mv.prepare_first_frame()
+            mv.upload_state()
+            base = np.vstack([np.asarray(sc.primitives[-1].model, np.float64).reshape(3, 4), [0, 0, 0, 1]])
+            poses = []
+            for i in range(args.moving_model):   # a closed loop: rotation about y, a small orbit
+                a = 2 * math.pi * i / args.moving_model
+                ry = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1]])
+                t = np.eye(4); t[:3, 3] = (0.15 * math.cos(a) - 0.15, 0.05 * math.sin(2 * a), 0.15 * math.sin(a))
+                poses.append(np.ascontiguousarray((t @ ry @ base)[:3], np.float32))
+            model = mv.models_mut()[1]
+            rays_pose, refit_alone = [], []
+            for m in poses:                       # every pose once alone: its ray count, and the refit's device time with nothing else on the GPU
+                model.set_model_matrix(m)
+                mv.trace(); mv.sync()
+                ps = mv.stats()
+                rays_pose.append(ps["primary_rays"] + ps["shadow_rays"]); refit_alone.append(ps["refit_ms"])
+
+            def moved(n):
+                for i in range(n):
+                    model.set_model_matrix(poses[i % len(poses)])
+                    mv.trace()
+            moved(2 * F); mv.sync()
+            m0 = time.perf_counter()
+            moved(args.steps); mv.sync()
+            mwall = time.perf_counter() - m0
+            ms_ = mv.stats()
+            refit_alone.sort()
+            moving_model = dict(poses=len(poses), value=sum(rays_pose[i % len(poses)] for i in range(args.steps)) / mwall / 1e6, unit="Mray/s", ms_per_step=mwall * 1e3 / args.steps,
+                                refit_ms=refit_alone[len(refit_alone) // 2], refit_ms_max=refit_alone[-1], refits=ms_["refits"], rebuilds=ms_["rebuilds"], refit_cost_ratio=ms_["refit_cost_ratio"],
+                                moving_triangles=sc.primitives[-1].n_tris, build_ms=ms_["build_ms"],
+                                protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, rotated and carried round a loop), fenced on both sides like `value`; "
+                                         "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses")
+            mv.close()
+
+        if rank != 0:
+            if world > 1 and not bailing:
+                dist.destroy_process_group()
+            return
+
+        ms_per_step = wall * 1e3 / args.steps
+        value = rays_total / (wall / args.steps) / 1e6
+
+        # ---- the oracle's counters for this exact frame (canonical LBVH: per ray = SURVEY.md 8d's contract figure, per 8x8 packet) ------------------
+        fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and not args.ao else None
+        ost = json.load(open(fx)) if fx and os.path.exists(fx) else None
+
+        # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame ---------------------------------------
+        cpu = None
+        if not args.no_cpu_baseline and not args.plain and not args.ao and world == 1:   # rank 0 at N = 1 only (the contract)
+            from oracle import orc
+            ncores = host_cores()
+            S = orc.Scene(sc.primitives, morton_bits=30)
+            cam = orc.camera_from_params(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
+            L = orc.make_lights(lights)
+            S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)       # warm-up frame
+            reps, cdt, cst = 0, 0.0, None
+            c0 = time.perf_counter()
+            while cdt < args.cpu_seconds and reps < 400:   # the same whole frame, repeated for ~10 s of wall clock
+                cst = S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)["stats"]
+                reps += 1
+                cdt = time.perf_counter() - c0
+            rays1 = cst["primary_rays"] + cst["shadow_rays"]
+            c1 = time.perf_counter()
+            st1 = S.render(cam, L, len(lights), W, H, H // 2 - 128, H // 2 + 128, threads=1, reuse=True)["stats"]   # one thread, a 256-row band
+            dt1 = time.perf_counter() - c1
+            cpu = dict(value=rays1 * reps / cdt / 1e6, unit="Mray/s", cores=ncores, kind="port",
+                       value_1thread=(st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6,
+                       sample=f"the same {W}x{H} frame x {reps} repetitions ({rays1} rays each, {cdt:.1f} s wall) on {ncores} threads; 1-thread figure "
+                              f"on rows [{H // 2 - 128},{H // 2 + 128}) ({dt1:.1f} s); scalar C oracle (stands in for the scalar Rust tracer: no Rust "
+                              "toolchain in this image), pthreads over 1-row bands")
+            if ost is None:     # no committed counters for this workload (other extents, a .glb): the oracle's, counted now
+                pk, _ = orc.packet_stats(S, cam, L, len(lights), W, H, threads=ncores)
+                ost = dict(cst, **pk)
+        if ost is not None and world == 1:
+            assert ost["shadow_rays"] == st["shadow_rays"] and ost["hit_pixels"] == st["hit_pixels"], \
+                f"GPU ray counts differ from the oracle's: {st['shadow_rays']}/{st['hit_pixels']} vs {ost['shadow_rays']}/{ost['hit_pixels']}"
+
+        # ---- roofline (tools/roofline.py re-derives every number below from profiles/) -------------------------------------------------------------
+        # Which roof binds a launch is a MEASURED statement: instruction and traffic counts come from a committed rocprofv3 --pmc pass of this very workload
+        # (profiles/current_pmc.json, keyed by workload: PMC counters cannot be read from inside the benchmarked process).  Without one -- another extent,
+        # a .glb, N > 1 -- the line carries the algorithmic fractions only and says bound: null; it never guesses "hbm".
+        roof = None
+        workload = workload_name(sc, glb, W, H, lights, shadow_total, args)
+        cur_path = os.path.join(ROOT, "profiles", "current_pmc.json")
+        cur = json.load(open(cur_path)) if os.path.exists(cur_path) else {}
+        entry = (cur.get("workloads") or {}).get(workload) if world == 1 else None
+        pmc = entry["pmc"] if entry else {}
+        if args.ao and world == 1 and st.get("frame_launches") == 1:
+            # config 5: the dominant kernel is the AO launch's persistent tracer.  Its share of the machine's time per step = the step minus the same frames without
+            # their AO pass, timed here the same way (fenced on both sides)
+            for _ in range(2 * F):
+                r.trace()
+            fence()
+            f0 = time.perf_counter()
+            for _ in range(args.steps):
+                r.trace()
+            fence()
+            frame_only_ms = (time.perf_counter() - f0) * 1e3 / args.steps
+            us = max(ms_per_step - frame_only_ms, 1e-3) * 1e3
+            gold_ao = os.path.join(ROOT, "tests", "golden", "c5_sponza_like_2160p_16spp_ao.stats.json")
+            ga = json.load(open(gold_ao)) if (args.scene == "sponza" and (W, H) == (3840, 2160) and args.detail == 1.0 and not glb and args.ao == 16 and os.path.exists(gold_ao)) else None
+            ab = None
+            if ga and ga["ao_rays"] == st["ao_rays"]:
+                ab = dict(contract=(32 + 1) * ga["ao_rays"] + 64 * ga["n_int_ao"] + 48 * ga["n_tri_ao"])   # SURVEY 8(d) per ray on the canonical LBVH: ray + nodes + triangles + the occlusion byte
+            fr = RL.fractions(pmc, us, ab)
+            roof = dict(bound="valu_issue" if "valu_issue_frac" in fr else None, kernel="k_trace<MODE_AO, 4-wide> (the AO launch's persistent per-ray tracer)",
+                        achieved=pmc["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9 if "SQ_INSTS_VALU" in pmc else None, peak=RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES / 1e9, unit="G wave-instructions/s",
+                        frac=fr.get("valu_issue_frac"), traffic=fr.get("hbm_bytes_per_launch"), hbm_frac=fr.get("hbm_frac"), valu_issue_frac=fr.get("valu_issue_frac"), salu_issue_frac=fr.get("salu_issue_frac"),
+                        valu_lane_utilisation=fr.get("valu_lane_utilisation"),
+                        useful_valu_frac=(fr["valu_issue_frac"] * fr["valu_lane_utilisation"]) if ("valu_issue_frac" in fr and "valu_lane_utilisation" in fr) else None,
+                        contract_frac=fr.get("contract_frac"), l2_hit_rate=fr.get("l2_hit_rate"), machine_us_per_launch=us, frame_only_ms_per_step=frame_only_ms, ao_rays_per_launch=st["ao_rays"],
+                        algorithmic_bytes_per_launch=ab, pmc_source=entry["source"] if entry else None, pmc_kernel_source_sha16=entry.get("kernel_source_sha16") if entry else None,
+                        pmc_stale=(entry.get("kernel_source_sha16") != RL.kernel_source_hash()) if entry else None,
+                        note="the AO launch: machine time = this run's ms_per_step minus the same frames without their AO pass; frac = vector wave-instructions of the launch (committed rocprofv3 --pmc "
+                             "pass) x 2 cycles over what 1 024 SIMDs issue in that time; useful_valu_frac = frac x the share of lanes active per vector instruction (incoherent rays: a wave's "
+                             "lanes finish and wait at different times); contract_frac = SURVEY.md 8(d)'s per-ray bytes on the canonical LBVH / 8 TB/s (cache-resident: NOT an achieved bandwidth)")
+        elif ost is not None and st.get("frame_launches") == 1:
+            ab = RL.algorithmic_bytes(ost, len(lights))
+            us = ms_per_step * 1e3 * world                     # machine time one GPU spends per frame: each rank's launch handles 1/world of the frame's rays
+            share = 1.0 / world
+            ab_launch = {k: v * share * B for k, v in ab.items()}   # what ONE launch (B frames of a 1/world share) accounts for
+            fr = RL.fractions(pmc, us * B, ab_launch)
+            kernel_ms = stage["primary_ms"]                    # HIP events on the launch's own stream: one launch's span, overlapped by the others in flight
+            binding = max((k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac") if k in fr), key=lambda k: fr[k], default=None)
+            if binding is None:
+                roof = dict(bound=None, kernel="k_frame", achieved=None, peak=None, unit=None, frac=None)   # no counters for this workload: nothing measured says which roof binds it
+            elif binding == "hbm_frac":
+                roof = dict(bound="hbm", kernel="k_frame", achieved=fr["hbm_bytes_per_launch"] / (us * B * 1e-6) / 1e9, peak=RL.HBM_PEAK / 1e9, unit="GB/s", frac=fr["hbm_frac"])
+            else:
+                per_s = {"valu_issue_frac": RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES, "salu_issue_frac": RL.CUS * RL.CLOCK_HZ}[binding]
+                n_inst = pmc["SQ_INSTS_VALU" if binding == "valu_issue_frac" else "SQ_INSTS_SALU"]
+                roof = dict(bound=binding.replace("_frac", ""), kernel="k_frame", achieved=n_inst / (us * B * 1e-6) / 1e9, peak=per_s / 1e9, unit="G wave-instructions/s", frac=fr[binding])
+            roof.update(
+                traffic=fr.get("hbm_bytes_per_launch"), hbm_frac=fr.get("hbm_frac"), valu_issue_frac=fr.get("valu_issue_frac"), salu_issue_frac=fr.get("salu_issue_frac"),
+                packet_frac=fr.get("packet_frac"), contract_frac=fr.get("contract_frac"), l2_hit_rate=fr.get("l2_hit_rate"), valu_lane_utilisation=fr.get("valu_lane_utilisation"),
+                machine_us_per_launch=us * B, kernel_ms=kernel_ms, launches_overlapping=kernel_ms * 1e3 / (us * B) if us else None, frames_timed=n_timed, frames_in_flight=F * B,
+                algorithmic_bytes_per_launch=dict(packet=ab_launch.get("packet"), contract=ab_launch["contract"], packet_traversal=ab_launch.get("packet_traversal_bytes"),
+                                                  shading=ab_launch.get("shading_bytes"), outputs=ab_launch.get("output_bytes")),
+                pmc_source=entry["source"] if entry else None, pmc_kernel_source_sha16=entry.get("kernel_source_sha16") if entry else None,
+                pmc_stale=(entry.get("kernel_source_sha16") != RL.kernel_source_hash()) if entry else None,
+                note="frac = the binding roof among those MEASURED for this workload: wave-instructions issued per launch (committed rocprofv3 --pmc pass) over what the chip can issue in the launch's "
+                     "share of machine time (ms_per_step: ~13 launches overlap, so kernel_ms, one launch's own span, is not that share).  hbm_frac = measured HBM traffic (2 x FETCH_SIZE + "
+                     "WRITE_SIZE, Infinity-Cache hits included) / 8 TB/s.  packet_frac = the oracle's packet-level algorithmic bytes (a node / triangle once per 8x8-pixel packet, "
+                     "canonical LBVH) / 8 TB/s.  contract_frac = SURVEY.md 8(d)'s per-ray algorithmic bytes / 8 TB/s: above 1 because the tree (~30 MB) is cache-resident and a packet "
+                     "fetches a node once for 64 rays -- NOT an achieved bandwidth.  bound: null = no counter pass is committed for this workload (or N > 1): only the algorithmic fractions are given")
+
+        line = {
+            "metric": (("Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}") if args.scene == "sponza"
+                       else f"Mray/s (primary+shadow), Bistro-class {W}x{H}") if not glb else f"Mray/s (primary+shadow), {os.path.basename(glb)} {W}x{H}",
+            "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real glb" if glb else "synthetic",
+            "config": {"workload": workload, "width": W, "height": H, "lights": len(lights),
+                       "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else (" (every rank assembles the frames f with f mod N = its rank)" if spread else f" (rank 0 composites too and traces {256 - relief}/256 of a share)"))
+                                       + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGB32F HDR (12 B/px; alpha is the constant 1)'} colour tiles to {'the root of each frame' if spread else 'rank 0'}, {B} frames per launch, "
+                                         f"{counts['launches_per_gather'] * B} frames per exchange") + f", {F * B} frames in flight"},
+            "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
+            "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
+            "camera_path": campath, "moving_model": moving_model, "refit_ms": moving_model["refit_ms"] if moving_model else None,
+            "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": settle_launches * B,
+            "tuning": tuning, "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
+            **({("value_rank0_root" if other["placement"] == "rank0" else "value_spread_roots"): other.get("value"), "other_placement": other} if other else {}),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+        if world > 1 and not bailing:
             dist.destroy_process_group()
-        return
 
-    ms_per_step = wall * 1e3 / args.steps
-    value = rays_total / (wall / args.steps) / 1e6
+    # N > 1: both placements of the assembled frames back to back, each a whole job of its own (context, communicator, settle, warm-up, K timed steps, frame check).
+    # The one with the single ncclGather runs first; the second one runs under a timer: should it not finish -- no exchange with more than one rank has ever run on
+    # a fabric -- rank 0 still prints the line of the first and every rank leaves with exit code 0, instead of the run ending with nothing at the watchdog.
+    order = placements if world == 1 else sorted(placements, key=lambda p_: p_ != "rank0")
+    jobs = {}
 
-    # ---- the oracle's counters for this exact frame (canonical LBVH: per ray = SURVEY.md 8d's contract figure, per 8x8 packet) ------------------
-    fx = os.path.join(ROOT, "tests", "golden", f"{tag}.stats.json") if tag and not args.ao else None
-    ost = json.load(open(fx)) if fx and os.path.exists(fx) else None
+    def bail(pl_):
+        if rank == 0:
+            finish(order[0], dict(placement=pl_, error=f"did not finish within {args.second_placement_seconds:.0f} s: this line is the other placement's alone"), bailing=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+    for i_, pl in enumerate(order):
+        guard = None
+        if i_ > 0 and args.second_placement_seconds > 0:
+            import threading
+            guard = threading.Timer(args.second_placement_seconds, bail, args=(pl,))
+            guard.daemon = True
+            guard.start()
+        jobs[pl] = run_job(pl)
+        if guard:
+            guard.cancel()
 
-    # ---- CPU baseline: the scalar C oracle on this host's cores, on a bounded sample of the same frame ---------------------------------------
-    cpu = None
-    if not args.no_cpu_baseline and not args.plain and not args.ao and world == 1:   # rank 0 at N = 1 only (the contract)
-        from oracle import orc
-        ncores = host_cores()
-        S = orc.Scene(sc.primitives, morton_bits=30)
-        cam = orc.camera_from_params(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
-        L = orc.make_lights(lights)
-        S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)       # warm-up frame
-        reps, cdt, cst = 0, 0.0, None
-        c0 = time.perf_counter()
-        while cdt < args.cpu_seconds and reps < 400:   # the same whole frame, repeated for ~10 s of wall clock
-            cst = S.render(cam, L, len(lights), W, H, 0, H, threads=ncores, reuse=True)["stats"]
-            reps += 1
-            cdt = time.perf_counter() - c0
-        rays1 = cst["primary_rays"] + cst["shadow_rays"]
-        c1 = time.perf_counter()
-        st1 = S.render(cam, L, len(lights), W, H, H // 2 - 128, H // 2 + 128, threads=1, reuse=True)["stats"]   # one thread, a 256-row band
-        dt1 = time.perf_counter() - c1
-        cpu = dict(value=rays1 * reps / cdt / 1e6, unit="Mray/s", cores=ncores, kind="port",
-                   value_1thread=(st1["primary_rays"] + st1["shadow_rays"]) / dt1 / 1e6,
-                   sample=f"the same {W}x{H} frame x {reps} repetitions ({rays1} rays each, {cdt:.1f} s wall) on {ncores} threads; 1-thread figure "
-                          f"on rows [{H // 2 - 128},{H // 2 + 128}) ({dt1:.1f} s); scalar C oracle (stands in for the scalar Rust tracer: no Rust "
-                          "toolchain in this image), pthreads over 1-row bands")
-        if ost is None:     # no committed counters for this workload (other extents, a .glb): the oracle's, counted now
-            pk, _ = orc.packet_stats(S, cam, L, len(lights), W, H, threads=ncores)
-            ost = dict(cst, **pk)
-    if ost is not None and world == 1:
-        assert ost["shadow_rays"] == st["shadow_rays"] and ost["hit_pixels"] == st["hit_pixels"], \
-            f"GPU ray counts differ from the oracle's: {st['shadow_rays']}/{st['hit_pixels']} vs {ost['shadow_rays']}/{ost['hit_pixels']}"
-
-    # ---- roofline (tools/roofline.py re-derives every number below from profiles/) -------------------------------------------------------------
-    # Which roof binds a launch is a MEASURED statement: instruction and traffic counts come from a committed rocprofv3 --pmc pass of this very workload
-    # (profiles/current_pmc.json, keyed by workload: PMC counters cannot be read from inside the benchmarked process).  Without one -- another extent,
-    # a .glb, N > 1 -- the line carries the algorithmic fractions only and says bound: null; it never guesses "hbm".
-    roof = None
-    workload = workload_name(sc, glb, W, H, lights, shadow_total, args)
-    cur_path = os.path.join(ROOT, "profiles", "current_pmc.json")
-    cur = json.load(open(cur_path)) if os.path.exists(cur_path) else {}
-    entry = (cur.get("workloads") or {}).get(workload) if world == 1 else None
-    pmc = entry["pmc"] if entry else {}
-    if args.ao and world == 1 and st.get("frame_launches") == 1:
-        # config 5: the dominant kernel is the AO launch's persistent tracer.  Its share of the machine's time per step = the step minus the same frames without
-        # their AO pass, timed here the same way (fenced on both sides)
-        for _ in range(2 * F):
-            r.trace()
-        fence()
-        f0 = time.perf_counter()
-        for _ in range(args.steps):
-            r.trace()
-        fence()
-        frame_only_ms = (time.perf_counter() - f0) * 1e3 / args.steps
-        us = max(ms_per_step - frame_only_ms, 1e-3) * 1e3
-        gold_ao = os.path.join(ROOT, "tests", "golden", "c5_sponza_like_2160p_16spp_ao.stats.json")
-        ga = json.load(open(gold_ao)) if (args.scene == "sponza" and (W, H) == (3840, 2160) and args.detail == 1.0 and not glb and args.ao == 16 and os.path.exists(gold_ao)) else None
-        ab = None
-        if ga and ga["ao_rays"] == st["ao_rays"]:
-            ab = dict(contract=(32 + 1) * ga["ao_rays"] + 64 * ga["n_int_ao"] + 48 * ga["n_tri_ao"])   # SURVEY 8(d) per ray on the canonical LBVH: ray + nodes + triangles + the occlusion byte
-        fr = RL.fractions(pmc, us, ab)
-        roof = dict(bound="valu_issue" if "valu_issue_frac" in fr else None, kernel="k_trace<MODE_AO, 4-wide> (the AO launch's persistent per-ray tracer)",
-                    achieved=pmc["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9 if "SQ_INSTS_VALU" in pmc else None, peak=RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES / 1e9, unit="G wave-instructions/s",
-                    frac=fr.get("valu_issue_frac"), traffic=fr.get("hbm_bytes_per_launch"), hbm_frac=fr.get("hbm_frac"), valu_issue_frac=fr.get("valu_issue_frac"), salu_issue_frac=fr.get("salu_issue_frac"),
-                    valu_lane_utilisation=fr.get("valu_lane_utilisation"),
-                    useful_valu_frac=(fr["valu_issue_frac"] * fr["valu_lane_utilisation"]) if ("valu_issue_frac" in fr and "valu_lane_utilisation" in fr) else None,
-                    contract_frac=fr.get("contract_frac"), l2_hit_rate=fr.get("l2_hit_rate"), machine_us_per_launch=us, frame_only_ms_per_step=frame_only_ms, ao_rays_per_launch=st["ao_rays"],
-                    algorithmic_bytes_per_launch=ab, pmc_source=entry["source"] if entry else None, pmc_kernel_source_sha16=entry.get("kernel_source_sha16") if entry else None,
-                    pmc_stale=(entry.get("kernel_source_sha16") != RL.kernel_source_hash()) if entry else None,
-                    note="the AO launch: machine time = this run's ms_per_step minus the same frames without their AO pass; frac = vector wave-instructions of the launch (committed rocprofv3 --pmc "
-                         "pass) x 2 cycles over what 1 024 SIMDs issue in that time; useful_valu_frac = frac x the share of lanes active per vector instruction (incoherent rays: a wave's "
-                         "lanes finish and wait at different times); contract_frac = SURVEY.md 8(d)'s per-ray bytes on the canonical LBVH / 8 TB/s (cache-resident: NOT an achieved bandwidth)")
-    elif ost is not None and st.get("frame_launches") == 1:
-        ab = RL.algorithmic_bytes(ost, len(lights))
-        us = ms_per_step * 1e3 * world                     # machine time one GPU spends per frame: each rank's launch handles 1/world of the frame's rays
-        share = 1.0 / world
-        ab_launch = {k: v * share * B for k, v in ab.items()}   # what ONE launch (B frames of a 1/world share) accounts for
-        fr = RL.fractions(pmc, us * B, ab_launch)
-        kernel_ms = stage["primary_ms"]                    # HIP events on the launch's own stream: one launch's span, overlapped by the others in flight
-        binding = max((k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac") if k in fr), key=lambda k: fr[k], default=None)
-        if binding is None:
-            roof = dict(bound=None, kernel="k_frame", achieved=None, peak=None, unit=None, frac=None)   # no counters for this workload: nothing measured says which roof binds it
-        elif binding == "hbm_frac":
-            roof = dict(bound="hbm", kernel="k_frame", achieved=fr["hbm_bytes_per_launch"] / (us * B * 1e-6) / 1e9, peak=RL.HBM_PEAK / 1e9, unit="GB/s", frac=fr["hbm_frac"])
-        else:
-            per_s = {"valu_issue_frac": RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES, "salu_issue_frac": RL.CUS * RL.CLOCK_HZ}[binding]
-            n_inst = pmc["SQ_INSTS_VALU" if binding == "valu_issue_frac" else "SQ_INSTS_SALU"]
-            roof = dict(bound=binding.replace("_frac", ""), kernel="k_frame", achieved=n_inst / (us * B * 1e-6) / 1e9, peak=per_s / 1e9, unit="G wave-instructions/s", frac=fr[binding])
-        roof.update(
-            traffic=fr.get("hbm_bytes_per_launch"), hbm_frac=fr.get("hbm_frac"), valu_issue_frac=fr.get("valu_issue_frac"), salu_issue_frac=fr.get("salu_issue_frac"),
-            packet_frac=fr.get("packet_frac"), contract_frac=fr.get("contract_frac"), l2_hit_rate=fr.get("l2_hit_rate"), valu_lane_utilisation=fr.get("valu_lane_utilisation"),
-            machine_us_per_launch=us * B, kernel_ms=kernel_ms, launches_overlapping=kernel_ms * 1e3 / (us * B) if us else None, frames_timed=n_timed, frames_in_flight=F * B,
-            algorithmic_bytes_per_launch=dict(packet=ab_launch.get("packet"), contract=ab_launch["contract"], packet_traversal=ab_launch.get("packet_traversal_bytes"),
-                                              shading=ab_launch.get("shading_bytes"), outputs=ab_launch.get("output_bytes")),
-            pmc_source=entry["source"] if entry else None, pmc_kernel_source_sha16=entry.get("kernel_source_sha16") if entry else None,
-            pmc_stale=(entry.get("kernel_source_sha16") != RL.kernel_source_hash()) if entry else None,
-            note="frac = the binding roof among those MEASURED for this workload: wave-instructions issued per launch (committed rocprofv3 --pmc pass) over what the chip can issue in the launch's "
-                 "share of machine time (ms_per_step: ~13 launches overlap, so kernel_ms, one launch's own span, is not that share).  hbm_frac = measured HBM traffic (2 x FETCH_SIZE + "
-                 "WRITE_SIZE, Infinity-Cache hits included) / 8 TB/s.  packet_frac = the oracle's packet-level algorithmic bytes (a node / triangle once per 8x8-pixel packet, "
-                 "canonical LBVH) / 8 TB/s.  contract_frac = SURVEY.md 8(d)'s per-ray algorithmic bytes / 8 TB/s: above 1 because the tree (~30 MB) is cache-resident and a packet "
-                 "fetches a node once for 64 rays -- NOT an achieved bandwidth.  bound: null = no counter pass is committed for this workload (or N > 1): only the algorithmic fractions are given")
-
-    line = {
-        "metric": (("Mray/s (primary+shadow), Sponza-class 1080p" if (W, H) == (1920, 1080) else f"Mray/s (primary+shadow), Sponza-class {W}x{H}") if args.scene == "sponza"
-                   else f"Mray/s (primary+shadow), Bistro-class {W}x{H}") if not glb else f"Mray/s (primary+shadow), {os.path.basename(glb)} {W}x{H}",
-        "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real glb" if glb else "synthetic",
-        "config": {"workload": workload, "width": W, "height": H, "lights": len(lights),
-                   "parallelism": ("single GPU" if world == 1 else f"screen tiles 32x32 over {G} tracing GPUs" + (" + 1 compositing GPU" if dedicated else (" (every rank assembles the frames f with f mod N = its rank)" if spread else f" (rank 0 composites too and traces {256 - relief}/256 of a share)"))
-                                   + f", {transport}: gather of the {'B10G11R11 (4 B/px)' if packed else 'RGB32F HDR (12 B/px; alpha is the constant 1)'} colour tiles to {'the root of each frame' if spread else 'rank 0'}, {B} frames per launch, "
-                                     f"{counts['launches_per_gather'] * B} frames per exchange") + f", {F * B} frames in flight"},
-        "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
-        "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
-        "camera_path": campath, "moving_model": moving_model, "refit_ms": moving_model["refit_ms"] if moving_model else None,
-        "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": settle_launches * B,
-        "tuning": tuning, "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
-        **({("value_rank0_root" if other["placement"] == "rank0" else "value_spread_roots"): other["value"], "other_placement": other} if other else {}),
-        "roofline": roof, "cpu_baseline": cpu,
-    }
-    print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    def describe(o_, pl_):
+        return dict(placement=pl_, value=o_["value"], unit="Mray/s", ms_per_step=o_["ms_per_step"], gathered_frame_equals_single_gpu_frame=o_["frame_ok"], gathers=o_["counts"]["gathers"],
+                    frames_per_exchange=o_["counts"]["launches_per_gather"] * o_["B"], rank0_share_of_an_equal_share=f"{256 - o_['relief']}/256")
+    main_pl = placements[0]           # `value` is the placement --roots names
+    finish(main_pl, describe(jobs[placements[1]], placements[1]) if len(placements) > 1 else None)
 
 
 def workload_name(sc, glb, W, H, lights, shadow_total, args):
