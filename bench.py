@@ -63,6 +63,7 @@ def parse():
                     "instead of paying one exchange of everything behind the last frame")
     ap.add_argument("--second-placement-seconds", type=float, default=120.0, help="N>1: the second of the two placements runs under a timer of this many seconds; past it rank 0 prints the first "
                     "placement's line and every rank exits with code 0 (0 = no timer)")
+    ap.add_argument("--rehearse-hang", action="store_true", help="N>1, --backend gloo: the second placement's first exchange never returns (a test of --second-placement-seconds)")
     ap.add_argument("--one-placement", action="store_true", help="N>1: time only the placement --roots names (default: both, back to back -- `value` is --roots', the other one's rate is reported beside it)")
     ap.add_argument("--roots", default="spread", choices=["spread", "rank0"],
                     help="N>1: where frames are assembled (the placement `value` is measured with; the other is timed too and reported as value_rank0_root / value_spread_roots).  'spread' (default) = frame f on rank f mod N: every group of launches is one grouped ncclSend / ncclRecv (each frame's "
@@ -187,6 +188,8 @@ def main():
                 hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 
                 def gloo_gather(send, nbytes, recv, root, stream):   # the collective of the rehearsal: same call sequence, payload through host memory
+                    if args.rehearse_hang and jobs:
+                        time.sleep(1e6)
                     host = torch.empty(nbytes, dtype=torch.uint8)
                     assert hip.hipMemcpy(host.data_ptr(), send, nbytes, 2) == 0
                     parts = [torch.empty_like(host) for _ in range(world)] if rank == root else None

@@ -201,6 +201,22 @@ def test_sharded_bench_job_of_child_processes_gathers_the_single_gpu_frame(ranks
 
 
 @pytest.mark.gpu
+def test_a_second_placement_that_hangs_still_leaves_the_first_ones_line():
+    """no exchange with more than one rank has ever run on a fabric: should the second placement of a `bench.py --gpus N` run never finish, rank 0 prints the
+    first placement's line (the single ncclGather's: it runs first) with the failure noted, and every rank exits 0 -- rehearsed with an exchange that sleeps"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--detail", "0.12",
+           "--width", "640", "--height", "360", "--frames-in-flight", "6", "--settle-seconds", "0.05", "--watchdog-seconds", "200", "--rehearse-hang", "--second-placement-seconds", "15"]
+    out = _run_job(cmd, env, 240)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["gathered_frame_equals_single_gpu_frame"] is True and "rank 0 composites too" in line["config"]["parallelism"]
+    assert line["other_placement"]["placement"] == "spread" and "did not finish" in line["other_placement"]["error"] and line["value_spread_roots"] is None
+
+
+@pytest.mark.gpu
 def test_config4_eight_way_split_assembles_the_full_size_frame(get_scene):
     """BASELINE config 4's split at its real size on the one GPU there is: eight shard contexts of the 2.8 M-triangle scene at 1920x1080, each
     tracing its tiles; their compact tile buffers laid out as ncclGather leaves them on rank 0 and un-tiled by one launch give the unsharded
