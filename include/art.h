@@ -88,7 +88,7 @@ typedef struct ArtConfig {
                                   * geometry) are dealt to 4 or 16 waves in the following frames.  The image does not depend on it. */
 #define ART_FLAG_TILE_OUTPUT 32u /* write the compact tile buffer even when the frame is not sharded (shard_count <= 1: one shard owning every tile): a job of ONE rank
                                   * then runs the whole art_mgpu_* path -- gather from itself, un-tile -- which is how the RCCL transport is exercised on a one-GPU machine */
-#define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits) */
+#define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits: include/art_parity.h) */
 
 typedef struct ArtStats {
     uint64_t primary_rays;      /* W*H of the pixels this context owns */
@@ -106,7 +106,7 @@ typedef struct ArtStats {
     uint32_t split_blocks;      /* fused frame: 8x8 pixel blocks the current wave plan deals to 4 or 16 waves instead of one (see ART_FLAG_FIXED_WAVES) */
     float refit_ms;             /* last refit after art_scene_set_model_matrix, device time (triangle records + every box above them) */
     float refit_cost_ratio;     /* surface-area cost of the refitted tree over the cost of the tree as built (the latest refit whose figure has arrived); 1 = as built */
-    uint32_t refits, rebuilds;  /* refits since art_create; builds art_trace started by itself because refit_cost_ratio passed ArtTuning.refit_rebuild_ratio */
+    uint32_t refits, rebuilds;  /* refits since art_create; builds art_trace started by itself because refit_cost_ratio passed ArtTuning.refit_rebuild_ratio (include/art_parity.h; default 2) */
 } ArtStats;
 
 typedef struct ArtContext ArtContext;
@@ -118,7 +118,7 @@ int32_t art_device_count(void);
 int32_t art_create(const ArtConfig *cfg, ArtContext **out);
 int32_t art_destroy(ArtContext *ctx);
 /* use an externally owned hipStream_t (e.g. torch's current stream); NULL restores the context's own stream.
- * Only for one frame in flight: a ring owns its streams, see art_stream_wait_frame / art_wait_external_event. */
+ * Only for one frame in flight: a ring owns its streams (art_stream_wait_frame / art_wait_external_event in include/art_parity.h hand frames over to other streams). */
 int32_t art_set_stream(ArtContext *ctx, void *hip_stream);
 /* Several frames per launch (1..4; default 1; the fused frame only): every art_trace then traces n frames with ONE launch -- frame b with
  * the camera cams[b] of art_set_camera_batch (art_set_camera sets all n alike) -- and a ring slot holds n frames: every per-slot output,
@@ -151,7 +151,7 @@ int32_t art_scene_set_primitive_enabled(ArtContext *ctx, uint32_t primitive_id, 
  * (VkTlasBuilder::recreate_tlas every frame, renderer.rs:637-651, vk_tlas_builder.rs:38-233): primitives first_primitive .. first_primitive + n_primitives - 1
  * (one model's, art_scene_add_glb returns the range) get a new row-major object->world 3x4.  On a built scene nothing is built again: the NEXT art_trace
  * (or query) first REFITS on the device -- the world-space triangle records and every node box above them, the topology kept -- on that frame's own stream,
- * into the next of a small ring of versions of the structure (ArtTuning.as_versions, default 4), so frames in flight keep the scene they were launched
+ * into the next of a small ring of versions of the structure (4 by default; ArtTuning.as_versions in include/art_parity.h), so frames in flight keep the scene they were launched
  * with and nothing waits unless every version is still being read (the reference's per-frame fence, renderer.rs:451-466).  Frames are those of a fresh
  * build, bit for bit (hits are structure-independent).  When the refitted tree's surface-area cost passes ArtTuning.refit_rebuild_ratio (default 2) times
  * the built tree's, art_trace builds again instead (ArtStats.rebuilds).  Every rank of an art_mgpu job must make the same calls. */
@@ -249,7 +249,7 @@ int32_t art_get_layout(ArtContext *ctx, ArtLayout *out);
  * launches travel as ONE exchange -- an ncclGather (RCCL, rccl.h:745) to rank 0, or one ncclGroupStart .. ncclGroupEnd of ncclSend / ncclRecv that
  * takes every frame to its own root -- on a stream of their own, submitted by the host once it has SEEN the group's frames finish (art_frames_done:
  * no device-side wait in front of the collective or of the next frames -- such waits cost the frames in flight their L2 contents, profiles/README.md
- * r1n), and one launch un-tiles a root's frames of the group (art_untile_gathered_frames).  The payload is the context's tile format: RGB32F -- the
+ * r1n), and one launch un-tiles a root's frames of the group.  The payload is the context's tile format: RGB32F -- the
  * HDR buffer, 12 B per pixel (its alpha is the constant 1) -- by default, B10G11R11 words with ART_FLAG_PACKED_TILES.
  * RCCL is loaded at art_mgpu_create (dlopen of librccl.so.1: libart itself does not link it); ART_E_NO_DEVICE if it cannot be. */
 typedef struct ArtMgpu ArtMgpu;
