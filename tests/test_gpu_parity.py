@@ -1030,6 +1030,80 @@ def test_a_moved_model_at_the_bench_scenes_full_size(R, orc, get_scene, scenes, 
     r.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_edits_of_a_scene_with_frames_in_flight(R, orc, get_scene, scenes, seed):
+    """Row a3 under a random schedule: two models move independently (sometimes far enough that the rebuild rule -- ArtTuning.refit_rebuild_ratio --
+    fires by itself: it is set to 1.2 here), one of them leaves and re-enters the structure (vk_model.rs:360-372: a build), the camera moves; frames are launched in bursts of 1..4
+    without a host sync in between, three versions of the structure behind four ring slots.  Every frame of every burst is the oracle's frame of a scene
+    built from scratch in the state that frame was launched in: depth and normal bit for bit, radiance within 1e-4."""
+    from araytracingjourney_amd._lib import check
+    from helpers import device_to_host
+    sc = get_scene("sponza_like", 0.12)
+    w, h, F = 192, 108, 4
+    lights = scenes.sponza_lights(4)
+    n = len(sc.primitives)
+    groups = {"static": list(range(n - 4)), "a": [n - 1], "b": [n - 3, n - 2]}        # b last but one in id order: its absence shifts nobody's ids but a's, which no output shows
+    r = R.Renderer((w, h), frames_in_flight=F, tuning={"as_versions": 3, "refit_rebuild_ratio": 1.2})
+    for g in ("static", "b", "a"):
+        r.add_model([sc.primitives[j] for j in groups[g]])
+    model_b, model_a = r.models_mut()[1], r.models_mut()[2]
+    cam = r.camera_mut()
+    cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
+    for d in lights:
+        r.lights_mut().push_dict(d)
+    r.prepare_first_frame()
+    r.render_frame()
+    rng = np.random.default_rng(seed)
+    base = {"a": sc.primitives[n - 1].model, "b": sc.primitives[n - 2].model}
+    state = {"a": np.array(base["a"], np.float32).reshape(3, 4), "b": np.array(base["b"], np.float32).reshape(3, 4), "b_in": True, "pos": tuple(sc.camera["pos"])}
+    P = type(sc.primitives[0])
+    L = orc.make_lights(lights)
+    frames = 0
+    for burst in range(14):
+        launched = []
+        for _ in range(int(rng.integers(1, F + 1))):
+            op = int(rng.integers(0, 7))
+            if op in (0, 2):
+                state["a"] = _pose(base["a"], int(rng.integers(1, 40)), warp=bool(rng.integers(0, 4) == 0)); model_a.set_model_matrix(state["a"])
+            if op in (1, 2):
+                state["b"] = _pose(base["b"], int(rng.integers(1, 40))); model_b.set_model_matrix(state["b"])   # (while b is out: takes effect with the build that brings it back)
+            if op == 3:                                                                                         # far away: the tree inflates, a later move builds again
+                far = _pose(base["a"], int(rng.integers(1, 40))); far[:, 3] += np.array([0.0, 7.0, 3.0], np.float32)
+                state["a"] = far; model_a.set_model_matrix(far)
+            if op == 4:
+                state["b_in"] = not state["b_in"]
+                for pid in model_b.primitive_ids:
+                    check(r._L.art_scene_set_primitive_enabled(r._ctx, pid, 1 if state["b_in"] else 0))
+                check(r._L.art_scene_build(r._ctx))
+            if op == 5:
+                p0 = sc.camera["pos"]; state["pos"] = (p0[0] + float(rng.uniform(-1, 1)), p0[1] + float(rng.uniform(-0.3, 0.3)), p0[2] + float(rng.uniform(-0.5, 0.5)))
+                cam.set_pos(state["pos"])
+            r.upload_state(); r.trace()                                                                         # op 6: nothing changed
+            launched.append(((r.device_color(), r._dev("depth"), r._dev("normal")), dict(state)))
+        r.sync()
+        for ptrs, st in launched:
+            prims = [sc.primitives[j] for j in groups["static"]]
+            if st["b_in"]:
+                prims += [P(sc.primitives[j].verts, sc.primitives[j].indices, sc.primitives[j].tex, st["b"]) for j in groups["b"]]
+            prims += [P(sc.primitives[j].verts, sc.primitives[j].indices, sc.primitives[j].tex, st["a"]) for j in groups["a"]]
+            c = sc.camera
+            ocam = orc.camera_from_params(st["pos"], c["dir"], w / h, c["fovy"], c["znear"], c["zfar"])
+            ref = orc.Scene(prims, morton_bits=30).render(ocam, L, len(lights), w, h, threads=8, debug=True)
+            (pc, nc), (pd, nd), (pn, nn) = ptrs
+            depth = device_to_host(pd, nd).view(np.float32).reshape(h, w)
+            normal = device_to_host(pn, nn).view(np.float32).reshape(h, w, 4)
+            color = device_to_host(pc, nc).view(np.float32).reshape(h, w, 4)
+            what = f"seed {seed}, burst {burst}, frame {frames}"
+            assert np.array_equal(depth.view(np.uint32), ref["depth"].view(np.uint32)), what + ": depth"
+            assert np.array_equal(normal.view(np.uint32), ref["normal"].view(np.uint32)), what + ": normal"
+            assert_radiance_close(color, ref["color"], what=what)
+            frames += 1
+    st = r.stats()
+    print("random edits, seed", seed, ":", frames, "frames,", st["refits"], "refits,", st["rebuilds"], "rebuilds by the cost rule")
+    assert st["refits"] > 0 and frames >= 14
+    r.close()
+
+
 @pytest.mark.parametrize("form", ["fused", "fused-binary", "staged", "per-ray"])
 def test_a_moved_model_in_every_form_of_the_frame(R, orc, get_scene, scenes, form):
     """after art_scene_set_model_matrix every form of the frame -- the binary node records and the per-ray walks follow the refit on demand -- gives the oracle's
