@@ -97,6 +97,7 @@ SYMBOLS = {
     "art_scene_add_primitive": (_I32, [_P, _P, _U32, _P, _U32, _U32, _P, _U32, _U32, _P, _P]),
     "art_scene_clear": (_I32, [_P]),
     "art_scene_set_primitive_enabled": (_I32, [_P, _U32, _I32]),
+    "art_scene_needs_build": (_I32, [_P]),
     "art_scene_set_model_matrix": (_I32, [_P, _U32, _U32, _P]),
     "art_scene_build": (_I32, [_P]),
     "art_set_camera": (_I32, [_P, _P]),

@@ -152,6 +152,7 @@ struct ArtContext {
     std::vector<AsVersion> as; uint32_t as_cur = 0; bool xform_dirty = false;
     std::vector<DevPrim> h_dev_prims;          // host copy of d_prims (build order), matrices kept current
     std::vector<uint64_t> prim_moved;          // per primitive: the refit (as_epoch numbering) that first shows its latest move; 0: where the build put it
+    int64_t masked_tris = 0;                   // triangles of primitives disabled since the build (still in the arrays, written "nowhere")
     uint64_t as_epoch = 0, binary_epoch = 0;   // refits so far; the refit the binary trees / node records reflect
     double as_cost0 = 0.0; float refit_cost_ratio = 1.0f; uint32_t refits = 0, rebuilds = 0; float last_refit_ms = 0.f;
     ArtCamera camera{};
@@ -807,8 +808,30 @@ int32_t art_scene_clear(ArtContext *c) {
 int32_t art_scene_set_primitive_enabled(ArtContext *c, uint32_t id, int32_t enabled) {
     if (!c) return fail(ART_E_INVALID, "art_scene_set_primitive_enabled: null context");
     if (id >= c->prims.size()) return fail(ART_E_INVALID, "art_scene_set_primitive_enabled: no such primitive");
-    if (c->prims[id].enabled != (enabled != 0)) { c->prims[id].enabled = enabled != 0; c->built = false; } // takes effect at the next art_scene_build
+    HostPrim &p = c->prims[id];
+    if (p.enabled == (enabled != 0)) return ART_OK;
+    p.enabled = enabled != 0;
+    if (!c->built) return ART_OK;                                // takes effect with the build
+    if (p.n_indices < 3) return ART_OK;                          // no triangles: nothing to take out or bring back
+    if (id < c->h_dev_prims.size() && c->h_dev_prims[id].n_tri > 0) {
+        // Its triangles are in the built structure: they are masked (written "nowhere", every box above them shrunk) or restored by the refit in front of the
+        // next frame, like a move -- a model that crosses the residency radius (vk_model.rs:334-345) costs a fraction of a millisecond, not a build; its
+        // device arrays stay where they are until the next art_scene_build (288 GB of HBM: the way back is as cheap).
+        DevPrim &d = c->h_dev_prims[id];
+        d.masked = p.enabled ? 0u : 1u;
+        c->masked_tris += p.enabled ? -(int64_t)d.n_tri : (int64_t)d.n_tri;
+        c->prim_moved[id] = c->as_epoch + 1;
+        c->xform_dirty = true;
+        c->stats.num_triangles = (uint32_t)((int64_t)c->T - c->masked_tris);
+        return ART_OK;
+    }
+    c->built = false;                                            // not part of the built structure: art_scene_build
     return ART_OK;
+}
+
+int32_t art_scene_needs_build(const ArtContext *c) {
+    if (!c) return fail(ART_E_INVALID, "art_scene_needs_build: null context");
+    return c->built ? 0 : 1;
 }
 
 int32_t art_scene_set_model_matrix(ArtContext *c, uint32_t first, uint32_t n, const float model3x4[12]) {
@@ -880,7 +903,7 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(c->d_first_tri.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
     c->h_first_tri = first;
-    c->h_dev_prims = dp;
+    c->h_dev_prims = dp; c->masked_tris = 0;
     c->prim_moved.assign(dp.size(), 0);
     c->T = T;
     BuildInputs in{c->d_prims.p, (uint32_t)dp.size(), c->d_first_tri.p, T, c->cfg.morton_bits};

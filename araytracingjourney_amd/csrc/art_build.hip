@@ -173,18 +173,19 @@ __global__ __launch_bounds__(256) void k_refit(uint32_t T, const int32_t *__rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // keep the write-back ahead of the arrival (hipcc may drop the wait)
         if (atomicAdd(&arrive[n], 1u) == 0u) return;
         __threadfence();                       // acquire: see the sibling subtree's boxes
-        float lo[3], hi[3];
+        float l[2][3], h[2][3];
         for (int c = 0; c < 2; c++) {
             int ch = child[2 * n + c];
             const float *cl = ch < 0 ? leaf_lo + 3 * (size_t)(~ch) : node_lo + 3 * (size_t)ch;
             const float *chh = ch < 0 ? leaf_hi + 3 * (size_t)(~ch) : node_hi + 3 * (size_t)ch;
-            for (int k = 0; k < 3; k++) {
-                float l = __builtin_nontemporal_load(cl + k), h = __builtin_nontemporal_load(chh + k);
-                lo[k] = c == 0 ? l : fminf(lo[k], l);
-                hi[k] = c == 0 ? h : fmaxf(hi[k], h);
-            }
+            for (int k = 0; k < 3; k++) { l[c][k] = __builtin_nontemporal_load(cl + k); h[c][k] = __builtin_nontemporal_load(chh + k); }
         }
-        for (int k = 0; k < 3; k++) { node_lo[3 * (size_t)n + k] = lo[k]; node_hi[3 * (size_t)n + k] = hi[k]; }
+        // (a masked subtree -- a refit after art_scene_set_primitive_enabled -- is "nowhere" and leaves the union alone; a build never sees one)
+        const bool n0 = box_nowhere(l[0][0]), n1 = box_nowhere(l[1][0]);
+        for (int k = 0; k < 3; k++) {
+            node_lo[3 * (size_t)n + k] = n0 ? l[1][k] : (n1 ? l[0][k] : fminf(l[0][k], l[1][k]));
+            node_hi[3 * (size_t)n + k] = n0 ? h[1][k] : (n1 ? h[0][k] : fmaxf(h[0][k], h[1][k]));
+        }
         n = parent_int[n];
     }
 }
@@ -384,7 +385,8 @@ __device__ inline void wide_quantise(const float *const lo[4], const float *cons
     for (int k = 0; k < 6; k++) d.q[k] = 0;
     d.spare[0] = d.spare[1] = 0;
     float org[3] = {INFINITY, INFINITY, INFINITY}, top[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = 0; i < nc; i++) for (int k = 0; k < 3; k++) { org[k] = fminf(org[k], lo[i][k]); top[k] = fmaxf(top[k], hi[i][k]); }
+    for (int i = 0; i < nc; i++) if (!box_nowhere(lo[i][0])) for (int k = 0; k < 3; k++) { org[k] = fminf(org[k], lo[i][k]); top[k] = fmaxf(top[k], hi[i][k]); }
+    if (org[0] > top[0]) for (int k = 0; k < 3; k++) { org[k] = 0.f; top[k] = 0.f; }   // every child masked (refit): any frame of reference will do
     d.ox = org[0]; d.oy = org[1]; d.oz = org[2];
     uint32_t ebits[3]; float scale[3];
     for (int k = 0; k < 3; k++) { // smallest power of two with 255 * scale >= extent (as evaluated by the tracer's fma), at least 2^-100
@@ -398,6 +400,7 @@ __device__ inline void wide_quantise(const float *const lo[4], const float *cons
     for (int i = nc; i < 4; i++) for (int k = 0; k < 3; k++) d.q[k] |= 255u << (8 * i); // an absent child: an inverted box (lo planes 255, hi planes 0), which the per-ray walk's sign-selected slab never enters
     for (int i = 0; i < nc; i++) {
         mask |= 1u << i;
+        if (box_nowhere(lo[i][0])) { for (int k = 0; k < 3; k++) d.q[k] |= 255u << (8 * i); continue; }   // a masked subtree: the inverted box of an absent child
         for (int k = 0; k < 3; k++) {
             int ql = (int)floor(((double)lo[i][k] - (double)org[k]) / (double)scale[k]);
             int qh = (int)ceil(((double)hi[i][k] - (double)org[k]) / (double)scale[k]);
@@ -502,6 +505,14 @@ __global__ __launch_bounds__(256) void k_retri(uint32_t T, const DevShadeTri *__
     if (p >= T) return;
     const uint32_t prim = __float_as_uint(shade[p].f[34]);
     if (!touched[prim]) return;
+    if (prims[prim].masked) {   // out of the structure until it is enabled again: a point nowhere, no extent
+        DevTri t;
+        for (int k = 0; k < 3; k++) { t.f[k] = kNowhere; t.f[3 + k] = 0.f; t.f[6 + k] = 0.f; t.f[9 + k] = kNowhere; t.f[12 + k] = kNowhere; }
+        t.f[15] = tris[p].f[15];
+        tris[p] = t;
+        dirty[leaf_parent[p]] = 1;
+        return;
+    }
     const float4 *sq = reinterpret_cast<const float4 *>(shade + p);
     const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2];
     const float *m = prims[prim].o2w;
@@ -547,7 +558,8 @@ __device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const D
         const uint32_t cv = widef[ch].valid;
         const float b[4][6] = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y}, {a1.z, a1.w, a2.x, a2.y, a2.z, a2.w}, {a3.x, a3.y, a3.z, a3.w, a4.x, a4.y}, {a4.z, a4.w, a5.x, a5.y, a5.z, a5.w}};
         for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
-        for (int j = 0; j < 4; j++) if ((cv >> j) & 1u) for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[j][k]); hi[k] = fmaxf(hi[k], b[j][3 + k]); }
+        for (int j = 0; j < 4; j++) if (((cv >> j) & 1u) && !box_nowhere(b[j][0])) for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[j][k]); hi[k] = fmaxf(hi[k], b[j][3 + k]); }
+        if (lo[0] > hi[0]) for (int k = 0; k < 3; k++) { lo[k] = kNowhere; hi[k] = kNowhere; }   // nothing left below that node: nowhere itself
     }
     float *o = widef[w].box[i];
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
@@ -592,11 +604,12 @@ __global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const Dev
         }
         float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int j = 0; j < nc; j++) {
+            if (box_nowhere(lo[j][0])) continue;
             double dx = (double)hi[j][0] - lo[j][0], dy = (double)hi[j][1] - lo[j][1], dz = (double)hi[j][2] - lo[j][2];
             a += dx * dy + dy * dz + dz * dx;
             for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], lo[j][k]); rhi[k] = fmaxf(rhi[k], hi[j][k]); }
         }
-        if (w == 0) { double dx = (double)rhi[0] - rlo[0], dy = (double)rhi[1] - rlo[1], dz = (double)rhi[2] - rlo[2]; cost[1] = dx * dy + dy * dz + dz * dx; }
+        if (w == 0) { double dx = (double)rhi[0] - rlo[0], dy = (double)rhi[1] - rlo[1], dz = (double)rhi[2] - rlo[2]; cost[1] = dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
     }
     for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
     if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = a;

@@ -24,7 +24,12 @@ struct DevPrim {
     uint32_t first_tri, n_tri;
     float o2w[12];              // row-major 3x4
     float w2o[12];
+    uint32_t masked, pad_;      // a primitive that left the structure without a build (art_scene_set_primitive_enabled): its triangles are written "nowhere" by the next refit
 };
+// "Nowhere": the point box at 3e38 that absent children of a 4-wide node have carried since round 1 -- no ray passes it in any form of the slab test (|t| >= 3e38 on
+// every axis).  A masked triangle's record is one, and a union skips such boxes (a node with nothing else below it is nowhere itself).
+constexpr float kNowhere = 3.0e38f;
+__host__ __device__ inline bool box_nowhere(float lo_x) { return lo_x >= kNowhere; }
 
 // 64-byte binary traversal node: both child boxes inline, so one fetch decides both children.
 //   q0 = lo0.xyz hi0.x | q1 = hi0.yz lo1.xy | q2 = lo1.z hi1.xyz | q3 = child0 child1 - -

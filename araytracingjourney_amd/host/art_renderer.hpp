@@ -177,7 +177,7 @@ public:
             bool dev = m.state == ModelState::Device;
             if (dev != m.instanced) { m.instanced = dev; for (uint32_t id : m.primitive_ids) check(art_scene_set_primitive_enabled(ctx_, id, dev ? 1 : 0)); changed = true; }
         }
-        if (changed && build) check(art_scene_build(ctx_));
+        if (changed && build && art_scene_needs_build(ctx_) != 0) check(art_scene_build(ctx_)); // (part of the last build: in and out by the next frame's refit)
         return changed && build;
     }
     void add_primitive(const ArtVertex *v, uint32_t nv, const void *idx, uint32_t n_idx, uint32_t idx_bytes, const uint8_t *rgba8, uint32_t tw, uint32_t th, const Matrix3x4 &m) {

@@ -319,7 +319,8 @@ class Renderer:
 
     def update_models_status(self, build=True):
         """renderer.rs:637-651: every model decides its residency from the camera position; the acceleration structure is rebuilt over the
-        Device models when that set changed.  Returns True when it was rebuilt."""
+        Device models when that set changed -- by libart's refit when the models concerned were part of the last build (no build: art_scene_set_primitive_enabled),
+        by art_scene_build otherwise.  Returns True when it was built again."""
         changed = False
         for m in self._models:
             m.update_model_status(self._camera.pos())
@@ -329,9 +330,17 @@ class Renderer:
                 for pid in m.primitive_ids:
                     check(self._L.art_scene_set_primitive_enabled(self._ctx, pid, 1 if m._instanced else 0))
                 changed = True
-        if changed and build:
+        rebuilt = False
+        if changed and build and self.needs_build():   # (a model that was part of the last build leaves / re-enters by the next frame's refit: nothing to build)
             check(self._L.art_scene_build(self._ctx))
-        return changed and build
+            rebuilt = True
+        return rebuilt
+
+    def needs_build(self) -> bool:
+        nb = self._L.art_scene_needs_build(self._ctx)
+        if nb < 0:
+            check(nb)
+        return bool(nb)
 
     def set_stream(self, hip_stream_ptr):
         check(self._L.art_set_stream(self._ctx, C.c_void_p(hip_stream_ptr)))

@@ -418,11 +418,21 @@ def main():
             mwall = time.perf_counter() - m0
             ms_ = mv.stats()
             refit_alone.sort()
+            # the same model leaves and re-enters the structure (the residency rule, vk_model.rs:334-345): art_scene_set_primitive_enabled on a built scene is a refit too
+            from araytracingjourney_amd._lib import check
+            residency = []
+            for on in (0, 1, 0, 1):
+                for pid in model.primitive_ids:
+                    check(mv._L.art_scene_set_primitive_enabled(mv._ctx, pid, on))
+                mv.trace(); mv.sync()
+                residency.append(mv.stats()["refit_ms"])
+            assert not mv.needs_build() and mv.stats()["rebuilds"] == ms_["rebuilds"]
             moving_model = dict(poses=len(poses), value=sum(rays_pose[i % len(poses)] for i in range(args.steps)) / mwall / 1e6, unit="Mray/s", ms_per_step=mwall * 1e3 / args.steps,
                                 refit_ms=refit_alone[len(refit_alone) // 2], refit_ms_max=refit_alone[-1], refits=ms_["refits"], rebuilds=ms_["rebuilds"], refit_cost_ratio=ms_["refit_cost_ratio"],
-                                moving_triangles=sc.primitives[-1].n_tris, build_ms=ms_["build_ms"],
+                                moving_triangles=sc.primitives[-1].n_tris, build_ms=ms_["build_ms"], residency_change_ms=sorted(residency)[len(residency) // 2],
                                 protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, rotated and carried round a loop), fenced on both sides like `value`; "
-                                         "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses")
+                                         "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses; "
+                                         "residency_change_ms = the same for the model leaving / re-entering the structure (art_scene_set_primitive_enabled: no build)")
             mv.close()
 
         if rank != 0:

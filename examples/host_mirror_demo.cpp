@@ -64,6 +64,17 @@ int main(int argc, char **argv) {
             ArtStats st2 = renderer.stats();
             std::printf("MOVED_OK refits=%u rebuilds=%u moved_differs=%d back_equals_first=%d refit_ms=%.3f\n", st2.refits, st2.rebuilds, (int)(moved != c),
                         (int)(std::memcmp(back.data(), c.data(), c.size() * sizeof(float)) == 0), st2.refit_ms);
+            // the residency rule (vk_model.rs:334-345, renderer.rs:637-651): thirty units away the model leaves the structure, back at the first position it re-enters --
+            // by the refit in front of the frame, not by a build -- and the frame is the first frame again, bit for bit
+            renderer.camera_mut().set_pos({30.0f, 0.3f, -2.5f});
+            renderer.render_frame();
+            ArtStats far = renderer.stats();
+            renderer.camera_mut().set_pos({0.0f, 0.3f, -2.5f});
+            renderer.render_frame();
+            std::vector<float> again = renderer.color_output();
+            ArtStats st3 = renderer.stats();
+            std::printf("RESIDENT_OK hit_when_out=%llu tris_when_out=%u tris_back=%u rebuilds=%u refits=%u back_equals_first=%d\n", (unsigned long long)far.hit_pixels, far.num_triangles, st3.num_triangles,
+                        st3.rebuilds, st3.refits, (int)(std::memcmp(again.data(), c.data(), c.size() * sizeof(float)) == 0));
             return 0;
         }
         std::puts("usage: host_mirror_demo check | render <file.glb> [W H]");

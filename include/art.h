@@ -145,8 +145,13 @@ int32_t art_scene_add_primitive(ArtContext *ctx, const ArtVertex *verts, uint32_
                                 const float model3x4[12], uint32_t *out_primitive_id);
 int32_t art_scene_clear(ArtContext *ctx);
 /* residency (vk_model.rs:334-345, renderer.rs:637-651): only models in the Device state are instanced in the TLAS.  A disabled
- * primitive keeps its id and its host copy but is neither uploaded nor traced; takes effect at the next art_scene_build. */
+ * primitive keeps its id and its host copy but is not traced.  A primitive that is part of the built structure leaves and re-enters it WITHOUT a build: the refit
+ * in front of the next art_trace (see art_scene_set_model_matrix) writes its triangles nowhere / back and shrinks / grows every box above them -- frames are those
+ * of a scene built without / with it, bit for bit; its device arrays stay until the next art_scene_build.  A primitive that was disabled when the scene was built
+ * (never uploaded) needs art_scene_build to appear: art_scene_needs_build says which case the context is in. */
 int32_t art_scene_set_primitive_enabled(ArtContext *ctx, uint32_t primitive_id, int32_t enabled);
+/* 1: the next art_trace would fail with ART_E_STATE until art_scene_build has run (primitives added, or enabled that the last build did not contain); 0: it would not */
+int32_t art_scene_needs_build(const ArtContext *ctx);
 /* VkModel::set_model_matrix (vk_model.rs:461-466) -> get_transform_model_matrix (:358-363) -> the instance record of the per-frame TLAS
  * (VkTlasBuilder::recreate_tlas every frame, renderer.rs:637-651, vk_tlas_builder.rs:38-233): primitives first_primitive .. first_primitive + n_primitives - 1
  * (one model's, art_scene_add_glb returns the range) get a new row-major object->world 3x4.  On a built scene nothing is built again: the NEXT art_trace

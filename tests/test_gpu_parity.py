@@ -420,8 +420,10 @@ def test_cpp_host_mirror_renders_a_glb(R, get_scene, tmp_path):
     assert out.returncode == 0 and "RENDER_OK" in out.stdout, out.stdout + out.stderr
     f = dict(kv.split("=") for kv in out.stdout.split("RENDER_OK")[1].split("\n")[0].split())
     assert int(f["tris"]) == 34 and int(f["primary"]) == 160 * 96 and int(f["hit"]) > 1000 and int(f["ao"]) == 16 * int(f["hit"]) and float(f["colour_sum"]) > 0
-    m = dict(kv.split("=") for kv in out.stdout.split("MOVED_OK")[1].split())
+    m = dict(kv.split("=") for kv in out.stdout.split("MOVED_OK")[1].split("\n")[0].split())
     assert (int(m["refits"]), int(m["rebuilds"]), int(m["moved_differs"]), int(m["back_equals_first"])) == (2, 0, 1, 1) and float(m["refit_ms"]) > 0, out.stdout
+    res = dict(kv.split("=") for kv in out.stdout.split("RESIDENT_OK")[1].split())     # the model leaves (camera 30 units away) and re-enters the structure without a build
+    assert {k: int(v) for k, v in res.items()} == dict(hit_when_out=0, tris_when_out=0, tris_back=34, rebuilds=0, refits=4, back_equals_first=1), out.stdout
 
 
 def test_frame_ring_gives_the_same_frames(R, get_scene):
@@ -1033,7 +1035,7 @@ def test_a_moved_model_at_the_bench_scenes_full_size(R, orc, get_scene, scenes, 
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_edits_of_a_scene_with_frames_in_flight(R, orc, get_scene, scenes, seed):
     """Row a3 under a random schedule: two models move independently (sometimes far enough that the rebuild rule -- ArtTuning.refit_rebuild_ratio --
-    fires by itself: it is set to 1.2 here), one of them leaves and re-enters the structure (vk_model.rs:360-372: a build), the camera moves; frames are launched in bursts of 1..4
+    fires by itself: it is set to 1.2 here), one of them leaves and re-enters the structure (vk_model.rs:360-372; masked and restored by the refit, built again only when a build left it out), the camera moves; frames are launched in bursts of 1..4
     without a host sync in between, three versions of the structure behind four ring slots.  Every frame of every burst is the oracle's frame of a scene
     built from scratch in the state that frame was launched in: depth and normal bit for bit, radiance within 1e-4."""
     from araytracingjourney_amd._lib import check
@@ -1074,7 +1076,8 @@ def test_random_edits_of_a_scene_with_frames_in_flight(R, orc, get_scene, scenes
                 state["b_in"] = not state["b_in"]
                 for pid in model_b.primitive_ids:
                     check(r._L.art_scene_set_primitive_enabled(r._ctx, pid, 1 if state["b_in"] else 0))
-                check(r._L.art_scene_build(r._ctx))
+                if r.needs_build():                                                                             # (only after the cost rule built again while b was out)
+                    check(r._L.art_scene_build(r._ctx))
             if op == 5:
                 p0 = sc.camera["pos"]; state["pos"] = (p0[0] + float(rng.uniform(-1, 1)), p0[1] + float(rng.uniform(-0.3, 0.3)), p0[2] + float(rng.uniform(-0.5, 0.5)))
                 cam.set_pos(state["pos"])
@@ -1101,6 +1104,79 @@ def test_random_edits_of_a_scene_with_frames_in_flight(R, orc, get_scene, scenes
     st = r.stats()
     print("random edits, seed", seed, ":", frames, "frames,", st["refits"], "refits,", st["rebuilds"], "rebuilds by the cost rule")
     assert st["refits"] > 0 and frames >= 14
+    r.close()
+
+
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "per-ray"])
+def test_a_model_leaves_and_re_enters_the_structure_without_a_build(R, orc, get_scene, scenes, form):
+    """Residency (vk_model.rs:334-345 / :360-372, renderer.rs:637-651) on a built scene: a model that was part of the build is taken out and brought back by
+    art_scene_set_primitive_enabled WITHOUT art_scene_build -- the next frame's refit writes its triangles nowhere (or back) and shrinks (or grows) the boxes
+    above them.  Frames, ray queries, AO and the trees read back are those of a scene built without / with the model: hit ids, t, u, v, shadow bits bit for bit.
+    It moves while it is out; a model the build never saw still needs the build."""
+    from araytracingjourney_amd._lib import check
+    sc = get_scene("sponza_like", 0.12)
+    w, h = 240, 136
+    lights = scenes.sponza_lights(4)
+    fif, tuning = FORMS[form]
+    n = len(sc.primitives)
+    movers = [n - 1, n - 8]                                              # the displaced sphere and a column
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, keep_debug=True, frames_in_flight=fif, tuning=dict(tuning, refit_rebuild_ratio=-1.0))
+    model = r.models_mut()[1]
+    cam = oracle_camera(orc, sc, w, h)
+    L = orc.make_lights(lights)
+    r.render_frame()
+    P = type(moving[0])
+
+    def enable(on):
+        for pid in model.primitive_ids:
+            check(r._L.art_scene_set_primitive_enabled(r._ctx, pid, 1 if on else 0))
+        assert not r.needs_build()
+
+    def compare(S, what):
+        ref = S.render(cam, L, len(lights), w, h, threads=8, debug=True)
+        tuv, ids = r.read_hits()
+        assert np.array_equal(ids, ref["hit_id"]), f"{what}: {int((ids != ref['hit_id']).any(-1).sum())} hit ids differ"
+        assert np.array_equal(tuv.view(np.uint32)[..., :3], ref["hit_tuv"].view(np.uint32)[..., :3]), what
+        assert np.array_equal(r.read_shadow_bits(), ref["shadow_bits"]), what
+        st = r.stats()
+        assert st["shadow_rays"] == ref["stats"]["shadow_rays"] and st["hit_pixels"] == ref["stats"]["hit_pixels"] and st["num_triangles"] == S.n_tris, what
+        assert_radiance_close(r.read_color(), ref["color"], what=what)
+        r.trace_ao(8)
+        want_ao, _ = orc.render_ao(S, cam, ref["depth"], ref["normal"], 8, 0.2 * 1.457, threads=8)
+        assert np.array_equal(r.read_ao(), want_ao), what
+        rays = random_rays(20000, 5)
+        qt, qi = r.query_closest(rays)
+        rt, ri, _, _ = S.trace_closest(rays)
+        assert np.array_equal(qi, ri) and np.array_equal(qt.view(np.uint32)[:, :3], rt.view(np.uint32)[:, :3]), what   # (the static primitives come first: the same ids with and without the model)
+        short = rays.copy(); short[:, 7] = 1.5
+        assert np.array_equal(r.query_any(short), S.trace_any(short)[0]), what
+
+    without = orc.Scene(static, morton_bits=30)
+    enable(False); r.render_frame()
+    tuv, ids = r.read_hits()
+    ref = without.render(cam, L, len(lights), w, h, threads=8, debug=True)
+    assert np.array_equal(ids, ref["hit_id"]) and np.array_equal(r.read_shadow_bits(), ref["shadow_bits"])      # static primitives come first: same ids
+    compare(without, "model out")
+    m = _pose(moving[0].model, 5)
+    model.set_model_matrix(m)                                            # moved while it is out: nothing to see ...
+    r.render_frame()
+    assert np.array_equal(r.read_hits()[1], ref["hit_id"])
+    enable(True); r.render_frame()                                       # ... until it is back, where it was moved to
+    compare(_oracle_of_moved(orc, scenes, static, moving, m), "model back")
+    enable(False); enable(True); r.render_frame()                        # out and in between two frames: nothing changes
+    compare(_oracle_of_moved(orc, scenes, static, moving, m), "out and in")
+    st = r.stats()
+    assert st["rebuilds"] == 0 and st["refits"] >= 3
+    # the trees read back with the model out: every node box the exact union of what is left below it, nothing of the model in any box
+    enable(False); r.render_frame()
+    f = r.get_wide_nodes()[1].view(np.float32).reshape(-1, 32)
+    root = f[0, :24].reshape(4, 6)
+    root = root[root[:, 0] < 3.0e38]
+    lb = without.lbvh()
+    assert np.array_equal(root[:, :3].min(0), lb["leaf_lo"].min(0)) and np.array_equal(root[:, 3:].max(0), lb["leaf_hi"].max(0))
+    # a model the build has never seen needs the build
+    extra = r.add_model([P(moving[0].verts, moving[0].indices, moving[0].tex, _pose(moving[0].model, 9))])
+    assert r.needs_build()
     r.close()
 
 
