@@ -45,6 +45,12 @@ impl ArtRayTracedRenderer {
     pub fn set_model_matrix(&mut self, model: std::ops::Range<u32>, model_matrix_3x4: &[f32; 12]) {
         check(unsafe { art_scene_set_model_matrix(self.ctx, model.start, model.end - model.start, model_matrix_3x4.as_ptr()) });
     }
+    /// update_model_status (vk_model.rs:334-345) decided that a model enters or leaves the Device state (renderer.rs:637-651 instances Device models only): a model
+    /// that was part of the last build leaves / re-enters by the refit in front of the next frame; one that the build never saw needs the build
+    pub fn set_model_resident(&mut self, model: std::ops::Range<u32>, resident: bool) {
+        for id in model { check(unsafe { art_scene_set_primitive_enabled(self.ctx, id, resident as i32) }); }
+        if unsafe { art_scene_needs_build(self.ctx) } == 1 { check(unsafe { art_scene_build(self.ctx) }); }
+    }
     /// prepare_first_frame (renderer.rs:356): uploads + BLAS/TLAS builds
     pub fn prepare_first_frame(&mut self) { check(unsafe { art_scene_build(self.ctx) }); }
     /// render_frame (renderer.rs:371): camera.update_host_buffer, lights.update_host_and_device_buffer, lightning_layer.trace_rays
