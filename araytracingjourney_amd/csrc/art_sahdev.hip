@@ -37,10 +37,16 @@ __device__ __forceinline__ int bin_of(float c, float c0, float sc) { int b = (in
 
 // cb: [range][6] keys (lo xyz initialised to ~0, hi xyz to 0); bins: [range][axis][bin][7] = lo xyz keys, hi xyz keys, count
 // n_cb ranges' centroid boxes (0: leave them) and the bins of a window of n_win ranges
-__global__ void k_init_level(uint32_t n_cb, uint32_t n_win, uint32_t *cb, uint32_t *bins) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)n_cb * 6) cb[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
-    if (i < (size_t)n_win * 3 * kBins * 7) { uint32_t w = (uint32_t)(i % 7); bins[i] = w < 3 ? 0xFFFFFFFFu : 0u; }
+// (the number of open ranges of a level is read from the device -- n_dev, the counter the level before filled -- so that a level can be launched before the
+// host knows it: grid-stride loops over whatever the launch was given)
+__global__ void k_init_level(const uint32_t *__restrict__ n_dev, bool with_cb, uint32_t r0, uint32_t win_cap, uint32_t *cb, uint32_t *bins) {
+    const uint32_t n = *n_dev;
+    const uint32_t n_win = n > r0 ? (n - r0 < win_cap ? n - r0 : win_cap) : 0u;
+    const size_t n_cb_words = with_cb ? (size_t)n * 6 : 0, n_bin_words = (size_t)n_win * 3 * kBins * 7, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cb_words || i < n_bin_words; i += stride) {
+        if (i < n_cb_words) cb[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+        if (i < n_bin_words) { uint32_t w = (uint32_t)(i % 7); bins[i] = w < 3 ? 0xFFFFFFFFu : 0u; }
+    }
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m)); return v; }
 // Near the root thousands of leaves share a range: the centroid bounds are reduced per wave (segmented), the bins per block in LDS when the block has ONE range
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(kBlockB) void k_centroid_bounds(uint32_t T, const u
     if (valid && (lane == 63u || rn != r)) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)r * 6 + a], klo[a]); atomicMax(&cb[(size_t)r * 6 + 3 + a], khi[a]); }
 }
 __global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
-                                                 const uint32_t *__restrict__ cb, uint32_t *bins, uint32_t r0, uint32_t n_win) {
+                                                 const uint32_t *__restrict__ cb, uint32_t *bins, uint32_t r0, uint32_t n_win /* at most: the window's capacity */) {
     // bins holds the ranges [r0, r0 + n_win) of this level (a window: the bins of ALL ranges of a deep level would be 1344 bytes per triangle)
     __shared__ uint32_t s_lo, s_hi, s_bins[3 * kBins * 7];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,11 +111,11 @@ __device__ __forceinline__ void box_empty(Box &b) { for (int k = 0; k < 3; k++) 
 __device__ __forceinline__ void box_grow(Box &b, const uint32_t *w) { for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], fkey_inv(w[k])); b.hi[k] = fmaxf(b.hi[k], fkey_inv(w[3 + k])); } }
 __device__ __forceinline__ double half_area(const Box &b) { double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2]; return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
 
-__global__ void k_choose(uint32_t n_ranges, const Range *__restrict__ ranges, const uint32_t *__restrict__ cb, const uint32_t *__restrict__ bins, Split *splits, Range *next, uint32_t *n_next,
+__global__ void k_choose(const uint32_t *__restrict__ n_dev, uint32_t win_cap, const Range *__restrict__ ranges, const uint32_t *__restrict__ cb, const uint32_t *__restrict__ bins, Split *splits, Range *next, uint32_t *n_next,
                          int32_t *child, float *nlo, float *nhi, uint32_t r0) {
-    uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x;   // n_ranges: end of the window [r0, n_ranges) whose bins are in `bins`
-    if (r >= n_ranges) return;
+    const uint32_t n_all = *n_dev, n_ranges = n_all > r0 ? (n_all - r0 < win_cap ? n_all : r0 + win_cap) : r0;   // end of the window [r0, n_ranges) whose bins are in `bins`
     bins -= (size_t)r0 * 3 * kBins * 7;                        // indexed by r below
+    for (uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < n_ranges; r += gridDim.x * blockDim.x) {
     const Range R = ranges[r];
     const uint32_t n = R.e - R.b;
     Box node; box_empty(node);
@@ -141,6 +147,7 @@ __global__ void k_choose(uint32_t n_ranges, const Range *__restrict__ ranges, co
     if (nl > 1) { S.left = atomicAdd(n_next, 1u); next[S.left] = Range{R.b, R.b + nl, R.k + 1, R.depth + 1}; child[2 * (size_t)R.k] = (int32_t)(R.k + 1); }
     if (nr > 1) { S.right = atomicAdd(n_next, 1u); next[S.right] = Range{R.b + nl, R.e, R.k + nl, R.depth + 1}; child[2 * (size_t)R.k + 1] = (int32_t)(R.k + nl); }
     splits[r] = S;
+    }
 }
 __global__ __launch_bounds__(kBlockB) void k_flags(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
                                                    const Range *__restrict__ ranges, const Split *__restrict__ splits, const uint32_t *__restrict__ cb, uint32_t *flags) {
@@ -169,12 +176,13 @@ __global__ __launch_bounds__(kBlockB) void k_scatter(uint32_t T, const uint32_t 
     idx2[dst] = idx[i];
     range_of2[dst] = flags[i] ? S.left : S.right;
 }
-__global__ void k_leaf_refs(uint32_t n_ranges, const Range *__restrict__ ranges, const Split *__restrict__ splits, const uint32_t *__restrict__ idx2, int32_t *child) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_ranges) return;
-    const Range R = ranges[r]; const Split S = splits[r];
-    if (S.nl == 1) child[2 * (size_t)R.k] = ~(int32_t)idx2[R.b];
-    if (R.e - R.b - S.nl == 1) child[2 * (size_t)R.k + 1] = ~(int32_t)idx2[R.b + S.nl];
+__global__ void k_leaf_refs(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, const Split *__restrict__ splits, const uint32_t *__restrict__ idx2, int32_t *child) {
+    const uint32_t n_ranges = *n_dev;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_ranges; r += gridDim.x * blockDim.x) {
+        const Range R = ranges[r]; const Split S = splits[r];
+        if (S.nl == 1) child[2 * (size_t)R.k] = ~(int32_t)idx2[R.b];
+        if (R.e - R.b - S.nl == 1) child[2 * (size_t)R.k + 1] = ~(int32_t)idx2[R.b + S.nl];
+    }
 }
 __global__ void k_iota(uint32_t T, uint32_t *idx, uint32_t *range_of) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < T) { idx[i] = i; range_of[i] = 0; } }
 
@@ -188,7 +196,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     // whatever T is; config 2 (T/2 = 131 k ranges at most) still takes one pass per level, config 4's deepest levels take up to 11.
     constexpr uint32_t kWindow = 1u << 17;
     const uint32_t win_cap = max_ranges < kWindow ? max_ranges : kWindow;
-    uint32_t *idx[2] = {nullptr, nullptr}, *range_of[2] = {nullptr, nullptr}, *cb = nullptr, *bins = nullptr, *flags = nullptr, *scan = nullptr, *n_next = nullptr;
+    uint32_t *idx[2] = {nullptr, nullptr}, *range_of[2] = {nullptr, nullptr}, *cb = nullptr, *bins = nullptr, *flags = nullptr, *scan = nullptr, *n_cnt = nullptr;
     Range *ranges[2] = {nullptr, nullptr}; Split *splits = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
     const bool log = (l.log & 1u) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -197,7 +205,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     auto body = [&]() -> hipError_t {
         for (int k = 0; k < 2; k++) { HIPQ(hipMalloc(&idx[k], (size_t)T * 4)); HIPQ(hipMalloc(&range_of[k], (size_t)T * 4)); HIPQ(hipMalloc(&ranges[k], (size_t)max_ranges * sizeof(Range))); }
         HIPQ(hipMalloc(&cb, (size_t)max_ranges * 6 * 4)); HIPQ(hipMalloc(&bins, (size_t)win_cap * 3 * kBins * 7 * 4)); HIPQ(hipMalloc(&splits, (size_t)max_ranges * sizeof(Split)));
-        HIPQ(hipMalloc(&flags, (size_t)T * 4)); HIPQ(hipMalloc(&scan, (size_t)T * 4)); HIPQ(hipMalloc(&n_next, 4));
+        HIPQ(hipMalloc(&flags, (size_t)T * 4)); HIPQ(hipMalloc(&scan, (size_t)T * 4)); HIPQ(hipMalloc(&n_cnt, 8));
         if (!l.trav_child) { HIPQ(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPQ(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&l.trav_hi, (size_t)NI * 12)); }
         HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
         HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
@@ -206,28 +214,40 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
         k_iota<<<gT, kBlockB, 0, s>>>(T, idx[0], range_of[0]);
         Range root{0, T, 0, 0};
         HIPQ(hipMemcpyAsync(ranges[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
+        // The number of open ranges lives on the device (n_cnt[cur]: this level's, n_cnt[cur ^ 1]: the one k_choose counts up for the next); the range-indexed kernels
+        // read it there.  A scene whose levels fit two windows of bins (T <= 4 * kWindow: config 2) is launched four levels at a time without the host looking -- its
+        // levels are launch- and fence-bound (23 levels of 262 k leaves: 7.3 ms with a fence per level, a dozen 5 us kernels between two fences) -- and the host asks
+        // only every fourth level whether anything is still open; levels behind the last one find no open range and do nothing.  A bigger scene needs the count for its
+        // windows, and its levels are work-bound anyway: one fence per level as before.
+        const bool pipelined = max_ranges <= 2 * (uint64_t)win_cap;   // (config 2: T / 2 + 1 = 131 409 possible ranges against a window of 131 072 -- its deepest levels launch a second, nearly empty window)
+        const uint32_t one = 1;
+        HIPQ(hipMemcpyAsync(n_cnt, &one, 4, hipMemcpyHostToDevice, s));
         uint32_t n = 1; int cur = 0;
+        auto blocks = [](size_t items, uint32_t per_block, uint32_t cap) { size_t b = (items + per_block - 1) / per_block; return (uint32_t)(b < 1 ? 1 : (b > cap ? cap : b)); };
         for (uint32_t level = 0; n > 0 && level < 4096; level++) {
-            HIPQ(hipMemsetAsync(n_next, 0, 4, s));
-            for (uint32_t r0 = 0; r0 < n; r0 += win_cap) {
-                const uint32_t nw = n - r0 < win_cap ? n - r0 : win_cap;
-                const uint32_t n_cb = r0 == 0 ? n : 0u;   // the centroid boxes of the whole level are cleared with its first window
-                const size_t words = std::max((size_t)nw * 3 * kBins * 7, (size_t)n_cb * 6);
-                k_init_level<<<(uint32_t)((words + kBlockB - 1) / kBlockB), kBlockB, 0, s>>>(n_cb, nw, cb, bins);
+            HIPQ(hipMemsetAsync(n_cnt + (cur ^ 1), 0, 4, s));
+            const uint32_t n_up = pipelined ? (uint32_t)std::min<uint64_t>(1ull << std::min(level, 31u), max_ranges) : n;   // at most this many ranges are open (a level doubles them at most)
+            for (uint32_t r0 = 0; r0 < n_up; r0 += win_cap) {
+                const uint32_t nw = n_up - r0 < win_cap ? n_up - r0 : win_cap;
+                const size_t words = std::max((size_t)nw * 3 * kBins * 7, r0 == 0 ? (size_t)n_up * 6 : (size_t)0);   // the centroid boxes of the whole level are cleared with its first window
+                k_init_level<<<blocks(words, kBlockB, 8192), kBlockB, 0, s>>>(n_cnt + cur, r0 == 0, r0, win_cap, cb, bins);
                 if (r0 == 0) k_centroid_bounds<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb);
-                k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb, bins, r0, nw);
-                k_choose<<<(nw + 63) / 64, 64, 0, s>>>(r0 + nw, ranges[cur], cb, bins, splits, ranges[cur ^ 1], n_next, l.trav_child, l.trav_lo, l.trav_hi, r0);
+                k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb, bins, r0, win_cap);
+                k_choose<<<blocks(nw, 64, 4096), 64, 0, s>>>(n_cnt + cur, win_cap, ranges[cur], cb, bins, splits, ranges[cur ^ 1], n_cnt + (cur ^ 1), l.trav_child, l.trav_lo, l.trav_hi, r0);
             }
             k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, cb, flags);
             size_t tb = tmp_bytes;
             HIPQ(rocprim::exclusive_scan(tmp, tb, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
             k_scatter<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], ranges[cur], splits, flags, scan, idx[cur ^ 1], range_of[cur ^ 1]);
-            k_leaf_refs<<<(n + 255) / 256, 256, 0, s>>>(n, ranges[cur], splits, idx[cur ^ 1], l.trav_child);
-            uint32_t nn = 0;
-            HIPQ(hipMemcpyAsync(&nn, n_next, 4, hipMemcpyDeviceToHost, s));
-            HIPQ(hipStreamSynchronize(s));
-            if (nn > max_ranges) return hipErrorUnknown;
-            n = nn; cur ^= 1; levels++; widest = n > widest ? n : widest;
+            k_leaf_refs<<<blocks(n_up, 256, 2048), 256, 0, s>>>(n_cnt + cur, ranges[cur], splits, idx[cur ^ 1], l.trav_child);
+            cur ^= 1; levels++;
+            if (!pipelined || (level & 3u) == 3u) {
+                uint32_t nn = 0;
+                HIPQ(hipMemcpyAsync(&nn, n_cnt + cur, 4, hipMemcpyDeviceToHost, s));
+                HIPQ(hipStreamSynchronize(s));
+                if (nn > max_ranges) return hipErrorUnknown;
+                n = nn; widest = n > widest ? n : widest;
+            }
         }
         t2 = now();
         if (n != 0) return hipErrorUnknown;
@@ -240,8 +260,8 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     hipError_t err = body();
     auto t3 = now();
     for (int k = 0; k < 2; k++) { hipFree(idx[k]); hipFree(range_of[k]); hipFree(ranges[k]); }
-    hipFree(cb); hipFree(bins); hipFree(splits); hipFree(flags); hipFree(scan); hipFree(n_next); hipFree(tmp);
-    if (log) std::fprintf(stderr, "[art] sah_build_device %u leaves: wait + allocations %.1f ms, %u levels (at most %u open ranges) %.1f, node records %.1f, frees %.1f\n", T, ms(t0, t1), levels, widest, ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    hipFree(cb); hipFree(bins); hipFree(splits); hipFree(flags); hipFree(scan); hipFree(n_cnt); hipFree(tmp);
+    if (log) std::fprintf(stderr, "[art] sah_build_device %u leaves: wait + allocations %.1f ms, %u levels launched (at most %u open ranges seen) %.1f, node records %.1f, frees %.1f\n", T, ms(t0, t1), levels, widest, ms(t1, t2), ms(t2, t3), ms(t3, now()));
     return err;
 }
 
