@@ -138,6 +138,7 @@ struct ArtContext {
     int tree_builder = 3;     // with fast_trace: 3 = binned SAH on the device (art_sahdev.hip), 1 = the same on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip)
     bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD: keep the Karras tree)
     bool packet_wide = true;  // packets walk the 128-byte 4-wide float nodes (half the dependent node fetches); false: the 64-byte binary nodes
+    bool packet_beam = false; // the fused frame's node steps test the packet's beam (art_trace.hip beam_walk); ArtTuning.packet_wide 3
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised (measured: profiles/README.md)
     uint32_t macro = 2;       // XCD-aware launch order: macro-blocks of macro x macro tiles (0: identity)
     bool ao_entry = true;     // AO rays start at the per-pixel entry node (k_ao_entry)
@@ -756,7 +757,8 @@ int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     c->fast_trace = !(c->cfg.flags & ART_FLAG_FAST_BUILD);
     c->tree_builder = (c->cfg.flags & ART_FLAG_DEVICE_TREE) ? 2 : (t->tree_builder == 1 ? 1 : 3);
     c->frame_waves = t->frame_waves ? (int)t->frame_waves : 8;
-    c->packet_wide = t->packet_wide != 2;   // 0: the default (4-wide), 1: 4-wide, 2: binary
+    c->packet_wide = t->packet_wide != 2;   // 0: the default (4-wide), 1: 4-wide, 2: binary, 3: 4-wide walked by the packet's beam
+    c->packet_beam = t->packet_wide >= 3 && t->packet_wide <= 5;   // 4: primary rays only, 5: shadow rays only
     c->macro = t->block_order == 0 ? 2u : (t->block_order == 1 ? 0u : t->block_order);
     c->ao_entry = t->ao_entry_off == 0;
     c->wide_on_host = t->wide_builder == 1;
@@ -1063,7 +1065,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S, uint32_t version) 
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
     a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p; a.fold_counters = c->kind_primary == 8 && c->kind_shadow == 8 && c->n_local != 0;
     const AsPtrs as = as_ptrs(c, version); // the version of the acceleration structure this launch reads
-    a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.tune = TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
+    a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.packet_beam = c->packet_beam; a.beam_primary = c->tuning.packet_wide != 5; a.beam_shadow = c->tuning.packet_wide != 4; a.beam_fat = c->tuning.beam_fat > 0.0f ? c->tuning.beam_fat : (c->tuning.beam_fat < 0.0f ? INFINITY : 0.25f); a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.tune = TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
     a.n_lights = (uint32_t)c->lights.size();
     if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
     for (uint32_t i = 0; i < a.n_lights; i++) directional_constants(a.lights[i]);

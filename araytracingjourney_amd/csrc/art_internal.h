@@ -162,6 +162,8 @@ struct FrameArgs {
     const uint32_t *block_order; // [n_local / 256] launch block -> 256-pixel block (XCD-aware order, art_api.hip setup_frame)
     const DevNode *nodes; const DevNode4 *wide; const DevNodeW *widef; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
     bool packet_wide;          // packet walks use the 128-byte 4-wide nodes (else the binary nodes)
+    bool packet_beam;          // ... and the fused frame's node steps test the packet's beam (interval bounds on 32 lanes) instead of every ray against every box
+    bool beam_primary, beam_shadow; float beam_fat;   // which walks take the beam form; the largest spread of a shadow packet's origins (world units) that still does
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
     int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised
     TraceTune tune;            // host: the context's overrides of the persistent tracer's presets

@@ -27,7 +27,7 @@ typedef struct ArtTuning {
     uint32_t frame_form;        /* 0 one fused launch per frame (k_frame) | 1 four staged launches, packet walks | 2 four staged launches, per-ray walks */
     uint32_t tree_builder;      /* 0 the context's default (binned SAH on the device; ART_FLAG_FAST_BUILD: LBVH topology; ART_FLAG_DEVICE_TREE: PLOC) | 1 binned SAH on the host threads */
     uint32_t frame_waves;       /* fused frame: occupancy target per SIMD: 0 = 8 | 6 | 7 | 8 */
-    uint32_t packet_wide;       /* packet walks: 0 = default (the 128-byte 4-wide float nodes), 1 = 4-wide, 2 = the 64-byte binary nodes */
+    uint32_t packet_wide;       /* packet walks: 0 = default (the 128-byte 4-wide float nodes), 1 = 4-wide, 2 = the 64-byte binary nodes, 3 = 4-wide with beam node steps (4: primary rays only, 5: shadow rays only) */
     uint32_t primary_walk, shadow_walk, ao_walk; /* override one ray type's walk: 0 default | 8 packet | 2 per-ray binary | 4 per-ray 4-wide quantised */
     uint32_t block_order;       /* launch order of the 256-pixel blocks: 0 XCD-aware macro-blocks of 2x2 tiles | 1 identity | n: macro-blocks of n x n tiles */
     uint32_t fixed_waves;       /* 1: no adaptive wave plan (like ART_FLAG_FIXED_WAVES) */
@@ -42,6 +42,7 @@ typedef struct ArtTuning {
     uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..8 (0 = 4): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
     float refit_rebuild_ratio;  /* art_trace rebuilds instead of refitting once ArtStats.refit_cost_ratio exceeds this (0 = 2.0; negative: never) */
     uint32_t trace_leaf_batch;  /* persistent per-ray tracer: lanes that must be waiting for a triangle test before the wave runs one, 1..64 (0 = presets: 1, AO rays 8) */
+    float beam_fat;             /* beam node steps: a shadow packet whose ray origins spread further than this along an axis (world units) asks every ray instead (0 = 0.25; negative: never) */
 } ArtTuning;
 int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
 /* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */

@@ -50,7 +50,8 @@ def test_ray_queries_match_oracle_bitwise(R, orc, get_scene, name, detail):
     r.close()
 
 
-FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"frame_form": 1}), "per-ray": (1, {"frame_form": 2}), "fused-binary": (3, {"packet_wide": 2})}   # ArtTuning (art_set_tuning)
+FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"frame_form": 1}), "per-ray": (1, {"frame_form": 2}), "fused-binary": (3, {"packet_wide": 2}),
+         "fused-beam": (3, {"packet_wide": 3, "beam_fat": -1.0})}   # ArtTuning (art_set_tuning); fused-beam: node steps on the packet's beam, for every packet of one octant (no fat-beam fallback)
 
 
 def _frame_parity(R, orc, sc, w, h, n_lights, form="fused"):
@@ -102,7 +103,7 @@ def test_cornell_frame_matches_oracle(R, orc, get_scene, form):
     assert ref["stats"]["shadow_rays"] > 1000
 
 
-@pytest.mark.parametrize("form", ["fused", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-beam", "staged", "per-ray"])
 @pytest.mark.parametrize("n_lights", [1, 4])
 def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights, form):
     sc = get_scene("sponza_like", 0.12)
@@ -479,7 +480,9 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene):
                       ("per-ray on the PLOC tree", frame(1, device_tree=True, tuning={"frame_form": 2})), ("per-ray on the LBVH topology", frame(1, fast_build=True, tuning={"frame_form": 2})),
                       ("fused on the host-built SAH tree", frame(4, tuning={"tree_builder": 1})), ("fused, 7 waves/SIMD", frame(4, tuning={"frame_waves": 7, "packet_wide": 2})), ("fused, no block reordering", frame(4, tuning={"block_order": 1})),
                       ("staged, per-ray primary + packet shadow", frame(2, tuning={"frame_form": 1, "primary_walk": 2})), ("fused, binary packet nodes", frame(4, tuning={"packet_wide": 2})),
-                      ("fused, 4-wide collapse on the host", frame(4, tuning={"wide_builder": 1}))):
+                      ("fused, 4-wide collapse on the host", frame(4, tuning={"wide_builder": 1})),
+                      ("fused, beam node steps (fat shadow beams ask every ray)", frame(4, tuning={"packet_wide": 3})), ("fused, beam node steps for every one-octant packet", frame(4, tuning={"packet_wide": 3, "beam_fat": -1.0})),
+                      ("fused, beam node steps for primary rays only", frame(4, tuning={"packet_wide": 4})), ("fused, beam node steps for shadow rays only", frame(2, tuning={"packet_wide": 5, "beam_fat": 0.5}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
         assert got[3]["shadow_rays"] == ref[3]["shadow_rays"] and got[3]["hit_pixels"] == ref[3]["hit_pixels"], name
@@ -766,7 +769,7 @@ def test_api_state_and_argument_errors(R, get_scene):
     r.close()
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-binary", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "fused-beam", "staged", "per-ray"])
 def test_non_finite_cameras_are_errors_and_non_finite_rays_are_misses(R, orc, get_scene, form):
     """A camera looking along the up axis has no side vector (look_at_rh's cross product is zero): an error, like a NaN anywhere in a raw block.
     A finite block can still make non-finite rays (a projection inverse of zeros normalises the zero vector): such a ray accepts no triangle in
@@ -840,7 +843,7 @@ def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
     r.close()
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-binary", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "fused-beam", "staged", "per-ray"])
 def test_degenerate_geometry_resolves_as_the_oracle_does(R, orc, get_scene, scenes, form):
     """what a driver's traversal leaves undefined and DESIGN.md 1.1 defines: two IDENTICAL triangles (the hit goes to the lower global id), coplanar overlapping
     triangles, zero-area triangles (three collinear points, three equal points: never hit), a sliver a fraction of a pixel wide, and a fan whose shared vertex and
@@ -873,7 +876,7 @@ def test_degenerate_geometry_resolves_as_the_oracle_does(R, orc, get_scene, scen
     assert tris_hit & set(range(6, 14))                  # the fan is
 
 
-@pytest.mark.parametrize("form", ["fused", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-beam", "staged", "per-ray"])
 def test_directional_lights_along_the_axes_and_unnormalised(R, orc, get_scene, scenes, form):
     """a directional light's L, |nn_L| and the shadow ray's reciprocal direction are made on the host, once (art_api.hip directional_constants), with the
     operations the oracle runs per pixel: axis-aligned directions (zero components: the reciprocal's safe_dir branch, signed zeros), an unnormalised and a
