@@ -18,6 +18,7 @@ namespace art {
 
 __device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ inline float ord2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+constexpr uint32_t kCbSlots = 64;
 
 __device__ inline float3 xform_point(const float *m, float x, float y, float z) {
     return make_float3(((m[0] * x + m[1] * y) + m[2] * z) + m[3], ((m[4] * x + m[5] * y) + m[6] * z) + m[7],
@@ -27,7 +28,7 @@ __device__ inline float3 xform_point(const float *m, float x, float y, float z) 
 // one thread per triangle: fetch indices + vertices, transform, write world triangle, its AABB, reduce centroid bounds
 __global__ __launch_bounds__(256) void k_soup(const DevPrim *__restrict__ prims, uint32_t n_prims, const uint32_t *__restrict__ first_tri,
                                               uint32_t T, float *__restrict__ triw /*T*9*/, float *__restrict__ tlo, float *__restrict__ thi,
-                                              uint32_t *__restrict__ tri_prim, uint32_t *__restrict__ cbounds /*6 ordered ints*/) {
+                                              uint32_t *__restrict__ tri_prim, uint32_t *__restrict__ cslots /*kCbSlots x 32 words: 6 ordered ints each, a slot per 128-byte line*/) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     float cx = 0, cy = 0, cz = 0;
     bool on = g < T;
@@ -58,8 +59,18 @@ __global__ __launch_bounds__(256) void k_soup(const DevPrim *__restrict__ prims,
             kmin[k] = min(kmin[k], (uint32_t)__shfl_xor((int)kmin[k], off));
             kmax[k] = max(kmax[k], (uint32_t)__shfl_xor((int)kmax[k], off));
         }
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 3; k++) { atomicMin(&cbounds[k], kmin[k]); atomicMax(&cbounds[3 + k], kmax[k]); }
+    // (every wave of the launch on the same six words was 2.7 of the 3.0 ms this kernel took for the 2.8 M triangles of config 4: the waves are dealt to 64 slots, k_cb_fold joins them)
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t *cb = cslots + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kCbSlots) * 32;
+        for (int k = 0; k < 3; k++) { atomicMin(&cb[k], kmin[k]); atomicMax(&cb[3 + k], kmax[k]); }
+    }
+}
+__global__ __launch_bounds__(64) void k_cb_init(uint32_t *cslots) { for (int k = 0; k < 6; k++) cslots[threadIdx.x * 32 + k] = k < 3 ? 0xFFFFFFFFu : 0u; }
+__global__ __launch_bounds__(64) void k_cb_fold(const uint32_t *__restrict__ cslots, uint32_t *__restrict__ cbounds) {
+    uint32_t v[6];
+    for (int k = 0; k < 6; k++) v[k] = cslots[threadIdx.x * 32 + k];
+    for (int off = 32; off >= 1; off >>= 1) for (int k = 0; k < 6; k++) { uint32_t o = (uint32_t)__shfl_xor((int)v[k], off); v[k] = k < 3 ? min(v[k], o) : max(v[k], o); }
+    if (threadIdx.x == 0) for (int k = 0; k < 6; k++) cbounds[k] = v[k];
 }
 
 __device__ inline uint32_t expand10(uint32_t v) {
@@ -692,7 +703,7 @@ hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s) 
 void lbvh_free(Lbvh &l) {
     hipFree(l.wide); hipFree(l.widef); hipFree(l.shade_tris);
     hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
-    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim); hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi); hipFree(l.leaf_parent); hipFree(l.node_parent);
+    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim); hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi); hipFree(l.leaf_parent); hipFree(l.node_parent); hipFree(l.cbounds);
     l = Lbvh{};
 }
 
@@ -701,7 +712,7 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
     const uint32_t NI = T > 1 ? T - 1 : 1;
     out = Lbvh{};
     float *triw = nullptr, *tlo = nullptr, *thi = nullptr;
-    uint32_t *cb = nullptr, *gid_in = nullptr, *arrive = nullptr;
+    uint32_t *cslots = nullptr, *gid_in = nullptr, *arrive = nullptr;
     uint64_t *keys_in = nullptr;
     int32_t *parent_int = nullptr, *parent_leaf = nullptr;
     void *tmp = nullptr;
@@ -709,7 +720,7 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
     hipError_t err = hipSuccess;
     auto body = [&]() -> hipError_t {
         HIPQ(hipMalloc(&triw, (size_t)T * 36)); HIPQ(hipMalloc(&tlo, (size_t)T * 12)); HIPQ(hipMalloc(&thi, (size_t)T * 12));
-        HIPQ(hipMalloc(&cb, 24)); HIPQ(hipMalloc(&gid_in, (size_t)T * 4)); HIPQ(hipMalloc(&keys_in, (size_t)T * 8));
+        HIPQ(hipMalloc(&cslots, kCbSlots * 32 * 4)); HIPQ(hipMalloc(&out.cbounds, 32)); HIPQ(hipMalloc(&gid_in, (size_t)T * 4)); HIPQ(hipMalloc(&keys_in, (size_t)T * 8));
         HIPQ(hipMalloc(&arrive, (size_t)NI * 4)); HIPQ(hipMalloc(&parent_int, (size_t)NI * 4)); HIPQ(hipMalloc(&parent_leaf, (size_t)T * 4));
         HIPQ(hipMalloc(&out.leaf_gid, (size_t)T * 4)); HIPQ(hipMalloc(&out.keys, (size_t)T * 8)); HIPQ(hipMalloc(&out.child, (size_t)NI * 8));
         HIPQ(hipMalloc(&out.node_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&out.node_hi, (size_t)NI * 12));
@@ -717,12 +728,12 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
         HIPQ(hipMalloc(&out.tris, (size_t)T * sizeof(DevTri))); HIPQ(hipMalloc(&out.nodes, (size_t)NI * sizeof(DevNode)));
         HIPQ(hipMalloc(&out.tri_prim, (size_t)T * 4));
         HIPQ(hipMalloc(&out.shade_tris, (size_t)T * sizeof(DevShadeTri)));
-        const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-        HIPQ(hipMemcpyAsync(cb, init, 24, hipMemcpyHostToDevice, s));
+        k_cb_init<<<1, kCbSlots, 0, s>>>(cslots);
         HIPQ(hipMemsetAsync(arrive, 0, (size_t)NI * 4, s));
         const uint32_t B = 256, GT = (T + B - 1) / B;
-        k_soup<<<GT, B, 0, s>>>(in.prims, in.n_prims, in.prim_first_tri, T, triw, tlo, thi, out.tri_prim, cb);
-        k_morton<<<GT, B, 0, s>>>(T, in.morton_bits, tlo, thi, cb, keys_in, gid_in);
+        k_soup<<<GT, B, 0, s>>>(in.prims, in.n_prims, in.prim_first_tri, T, triw, tlo, thi, out.tri_prim, cslots);
+        k_cb_fold<<<1, kCbSlots, 0, s>>>(cslots, out.cbounds);
+        k_morton<<<GT, B, 0, s>>>(T, in.morton_bits, tlo, thi, out.cbounds, keys_in, gid_in);
         HIPQ(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
         HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
         HIPQ(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
@@ -738,7 +749,7 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
         return hipSuccess;
     };
     err = body();
-    hipFree(triw); hipFree(tlo); hipFree(thi); hipFree(cb); hipFree(gid_in); hipFree(keys_in); hipFree(arrive); hipFree(parent_int); hipFree(parent_leaf); hipFree(tmp);
+    hipFree(triw); hipFree(tlo); hipFree(thi); hipFree(cslots); hipFree(gid_in); hipFree(keys_in); hipFree(arrive); hipFree(parent_int); hipFree(parent_leaf); hipFree(tmp);
     if (err != hipSuccess) lbvh_free(out);
     return err;
 }

@@ -97,6 +97,7 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     uint32_t *node_parent;
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
+    uint32_t *cbounds;      // [6] the bounds of the triangle-box centroids the Morton keys were made over, as order-preserving keys (lo xyz, hi xyz): the root domain of the SAH bins
 };
 // art_jpeg.hip: baseline JPEG -> RGB8 (channels 3) or R8 (1), row-major
 bool decode_jpeg(const uint8_t *data, size_t n, std::vector<uint8_t> &pixels, uint32_t &width, uint32_t &height, int &channels, std::string &err);

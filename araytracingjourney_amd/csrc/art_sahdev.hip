@@ -1,15 +1,19 @@
-// The PREFER_FAST_TRACE traversal tree built on the device: the same binned surface-area heuristic as art_sah.hip (32 bins on each of the
-// three axes, binned by box centroid, pre-order node numbering: the left subtree follows its parent, the right one starts nl nodes on),
-// level by level over ALL open ranges at once.  Every node box is an exact min/max union of leaf boxes (unions go through an
-// order-preserving float <-> uint key, so the atomics are integer min / max), hence frames cannot depend on which builder ran.
+// The PREFER_FAST_TRACE traversal tree built on the device: a binned surface-area heuristic over the LBVH's leaves (one triangle per leaf, pre-order node
+// numbering: the left subtree follows its parent, the right one starts nl nodes on), level by level over ALL open ranges at once, and -- since round 3 -- one
+// thread per SMALL range (<= kSmall leaves) for everything below it.  Every node box is an exact min/max union of leaf boxes (unions go through an
+// order-preserving float <-> uint key, so the atomics are integer min / max), hence frames cannot depend on which builder ran (DESIGN.md 1.1).
 //
-// One level = a handful of launches over the T leaf positions:
-//   k_centroid_bounds   per position -> atomic min/max into its range's centroid box
-//   k_bin               per position -> its bin on each axis: leaf box + count (21 atomics; the top levels contend on 672 words, ~0.4 ms each)
-//   k_choose            per range    -> node box, best (axis, bin) by SAH or the median past the depth guard; opens the child ranges
+// A level = a handful of launches over the T leaf positions:
+//   k_bin               per position -> its bin on the range's LONGEST axis (32 bins over the range's own box): leaf box + count, 7 atomics
+//   k_choose            per range    -> node box, best bin by SAH (or the median past the depth guard), the children's boxes -> their axis and domain;
+//                                       a child of <= kSmall leaves goes to the small list instead of the next level
 //   k_flags + scan + k_scatter       -> stable partition of every range at once (one exclusive scan over T flags)
 //   k_leaf_refs         per range    -> child references of one-leaf sides (known only after the partition)
-// and one 4-byte read-back (how many ranges the next level has).
+// Round 3 (profiles/README.md, "build"): the levels were bound by their atomics -- 21 a leaf for bins on all three axes plus 6 for the centroid bounds of the
+// range, 27 ms + 14 ms of the 62 ms of config 4.  The bins now cover one axis, the longest of the range's box (the rule of pbrt's SAH builder), and a child's
+// domain is its own box, which k_choose has at hand from the bins: no centroid pass at all below the root.  Ranges of <= kSmall leaves used to be most of the
+// open ranges of the deep levels (1.4 M of them at once for config 4, binned in windows of 128 k); now a thread sweeps each of them exactly -- every axis, every
+// position, leaves sorted by centroid -- which is a better split than 32 bins gave them and takes the deepest third of the levels out of the loop.
 #include "art_internal.h"
 #include <rocprim/rocprim.hpp>
 #include <chrono>
@@ -22,145 +26,221 @@ namespace {
 
 #define HIPQ(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
-constexpr int kBins = 32;
+#ifndef ART_SAH_BINS
+#define ART_SAH_BINS 64
+#endif
+constexpr int kBins = ART_SAH_BINS;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kSahDepth = 48; // past it ranges are halved: the tree stays within kSahDepth + log2(T) levels (the walks' stacks)
 constexpr uint32_t kBlockB = 256;
+#ifndef ART_SAH_SMALL
+#define ART_SAH_SMALL 16
+#endif
+constexpr uint32_t kSmall = ART_SAH_SMALL;    // a range of at most this many leaves is finished by one thread (k_small)
+constexpr uint32_t kMid = 4096;    // a range of at most this many leaves (and more than kSmall) is binned and split by one block in its LDS (k_mid); larger ones leaf by leaf (k_bin + k_choose)
+constexpr uint32_t kSmallDepth = 10; // ... whose exact sweep may chain at most this deep before it halves (a degenerate fan of 16 leaves would be 15 levels)
 
-struct Range { uint32_t b, e, k, depth; };               // leaves idx[b, e) -> internal node k
-struct Split { uint32_t axis, bin, nl, left, right; };   // axis 3: by position (median); left / right: the child ranges' ids in the next level, or kNone
+#ifndef ART_SAH_AXES
+#define ART_SAH_AXES 3   // axes a range is binned on: 3 = all (21 atomics a leaf), 1 = the longest side of its box only (7: the rule of pbrt's builder)
+#endif
+constexpr int kAxes = ART_SAH_AXES;
+struct Range { uint32_t b, e, k, depth; float lo[3], hi[3]; uint32_t axis, pad; }; // leaves idx[b, e) -> internal node k; binned over its own box [lo, hi] (kAxes == 1: on `axis`, the longest side)
+struct Split { uint32_t axis, bin, nl, left, right; };   // bin kNone: by position (median); left / right: the child ranges' ids in the next level, or kNone (a leaf, or a small range)
 
 __device__ __forceinline__ uint32_t fkey(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 __device__ __forceinline__ float centroid(const float *lo, const float *hi, uint32_t leaf, int a) { return 0.5f * lo[3 * (size_t)leaf + a] + 0.5f * hi[3 * (size_t)leaf + a]; }
 __device__ __forceinline__ int bin_of(float c, float c0, float sc) { int b = (int)((c - c0) * sc); return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b); }
+__device__ __forceinline__ int bin_in(const Range &R, int a, const float *lo, const float *hi, uint32_t leaf) { return R.hi[a] > R.lo[a] ? bin_of(centroid(lo, hi, leaf, a), R.lo[a], (float)kBins / (R.hi[a] - R.lo[a])) : 0; }   // a flat side: everything in bin 0, never chosen
 
-// cb: [range][6] keys (lo xyz initialised to ~0, hi xyz to 0); bins: [range][axis][bin][7] = lo xyz keys, hi xyz keys, count
-// n_cb ranges' centroid boxes (0: leave them) and the bins of a window of n_win ranges
+// bins: [range][axis][bin][7] = lo xyz keys (initialised to ~0), hi xyz keys (0), count
 // (the number of open ranges of a level is read from the device -- n_dev, the counter the level before filled -- so that a level can be launched before the
 // host knows it: grid-stride loops over whatever the launch was given)
-__global__ void k_init_level(const uint32_t *__restrict__ n_dev, bool with_cb, uint32_t r0, uint32_t win_cap, uint32_t *cb, uint32_t *bins) {
+__global__ __launch_bounds__(kBlockB) void k_init_level(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, uint32_t *bins) {   // a block per range; only the ranges k_bin fills
     const uint32_t n = *n_dev;
-    const uint32_t n_win = n > r0 ? (n - r0 < win_cap ? n - r0 : win_cap) : 0u;
-    const size_t n_cb_words = with_cb ? (size_t)n * 6 : 0, n_bin_words = (size_t)n_win * 3 * kBins * 7, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cb_words || i < n_bin_words; i += stride) {
-        if (i < n_cb_words) cb[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
-        if (i < n_bin_words) { uint32_t w = (uint32_t)(i % 7); bins[i] = w < 3 ? 0xFFFFFFFFu : 0u; }
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+        if (ranges[r].e - ranges[r].b <= kMid) continue;
+        for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) bins[(size_t)r * kAxes * kBins * 7 + w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
     }
 }
-__device__ __forceinline__ uint32_t wave_min(uint32_t v) { for (int m = 32; m > 0; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m)); return v; }
-// Near the root thousands of leaves share a range: the centroid bounds are reduced per wave (segmented), the bins per block in LDS when the block has ONE range
-// -- 262 k leaves on the root's six words took 3.3 ms of serialised atomics otherwise.
-__global__ __launch_bounds__(kBlockB) void k_centroid_bounds(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi, uint32_t *cb) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t r = i < T ? range_of[i] : kNone;
-    const bool valid = r != kNone;
-    uint32_t klo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, khi[3] = {0u, 0u, 0u};
-    if (valid) { uint32_t leaf = idx[i]; for (int a = 0; a < 3; a++) klo[a] = khi[a] = fkey(centroid(lo, hi, leaf, a)); }
-    if (wave_min(valid ? r : 0xFFFFFFFFu) == 0xFFFFFFFFu) return; // no leaf of an open range in this wave
-    // A range is an interval of positions, so the lanes of one range are neighbours: a segmented scan over the wave leaves each range's
-    // bounds in its last lane, and only that lane sends atomics (up to 64 times fewer; all of them near the root).
-    const uint32_t lane = threadIdx.x & 63u;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t ro = (uint32_t)__shfl_up((int)r, off);
-        uint32_t ol[3], oh[3];
-        for (int a = 0; a < 3; a++) { ol[a] = (uint32_t)__shfl_up((int)klo[a], off); oh[a] = (uint32_t)__shfl_up((int)khi[a], off); }
-        if (lane >= (uint32_t)off && ro == r) for (int a = 0; a < 3; a++) { klo[a] = min(klo[a], ol[a]); khi[a] = max(khi[a], oh[a]); }
-    }
-    const uint32_t rn = (uint32_t)__shfl_down((int)r, 1);
-    if (valid && (lane == 63u || rn != r)) for (int a = 0; a < 3; a++) { atomicMin(&cb[(size_t)r * 6 + a], klo[a]); atomicMax(&cb[(size_t)r * 6 + 3 + a], khi[a]); }
+struct Box { float lo[3], hi[3]; };
+__device__ __forceinline__ void box_empty(Box &b) { for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; } }
+__device__ __forceinline__ void box_grow(Box &b, const uint32_t *w) { for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], fkey_inv(w[k])); b.hi[k] = fmaxf(b.hi[k], fkey_inv(w[3 + k])); } }
+__device__ __forceinline__ void box_grow(Box &b, const float *lo, const float *hi) { for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], lo[k]); b.hi[k] = fmaxf(b.hi[k], hi[k]); } }
+__device__ __forceinline__ double half_area(const Box &b) { double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2]; return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
+// the axis a range is binned on and its domain: the longest side of its box (a flat box: c1 == c0, everything lands in bin 0 and the range is halved)
+__device__ __forceinline__ void set_domain(Range &R, const Box &b) {
+    const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    const int a = ex >= ey ? (ex >= ez ? 0 : 2) : (ey >= ez ? 1 : 2);
+    R.axis = (uint32_t)a; R.pad = 0;
+    for (int k = 0; k < 3; k++) { R.lo[k] = b.lo[k]; R.hi[k] = b.hi[k]; }
 }
+__global__ void k_root_range(uint32_t T, const uint32_t *__restrict__ box, Range *ranges) {
+    Box b; for (int a = 0; a < 3; a++) { b.lo[a] = fkey_inv(box[a]); b.hi[a] = fkey_inv(box[3 + a]); }
+    Range R{0, T, 0, 0, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0, 0};
+    set_domain(R, b);
+    ranges[0] = R;
+}
+// Near the root thousands of leaves share a range: the bins are reduced per block in LDS when the block has ONE range (262 k leaves on the root's words took
+// 3.3 ms of serialised atomics otherwise)
 __global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
-                                                 const uint32_t *__restrict__ cb, uint32_t *bins, uint32_t r0, uint32_t n_win /* at most: the window's capacity */) {
-    // bins holds the ranges [r0, r0 + n_win) of this level (a window: the bins of ALL ranges of a deep level would be 1344 bytes per triangle)
-    __shared__ uint32_t s_lo, s_hi, s_bins[3 * kBins * 7];
+                                                 const Range *__restrict__ ranges, uint32_t *bins) {
+    __shared__ uint32_t s_lo, s_hi, s_bins[kAxes * kBins * 7];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t r = i < T ? range_of[i] : kNone;
-    const bool valid = r != kNone && r >= r0 && r - r0 < n_win;
+    Range R{};
+    if (r != kNone) { R = ranges[r]; if (R.e - R.b <= kMid) r = kNone; }   // k_mid's
+    const bool valid = r != kNone;
     if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
-    for (uint32_t w = threadIdx.x; w < 3 * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
+    for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
     __syncthreads();
     if (valid) { atomicMin(&s_lo, r); atomicMax(&s_hi, r); }
     __syncthreads();
     if (s_lo == 0xFFFFFFFFu) return;                      // nothing open in this block
     const bool one = s_lo == s_hi;                        // the whole block bins into ONE range: histogram in LDS, then one global atomic per touched word
-    uint32_t *base = one ? s_bins : bins + (size_t)(r - r0) * 3 * kBins * 7;
     if (valid) {
         uint32_t leaf = idx[i];
         uint32_t kl[3], kh[3];
-        for (int a = 0; a < 3; a++) { kl[a] = fkey(lo[3 * (size_t)leaf + a]); kh[a] = fkey(hi[3 * (size_t)leaf + a]); }
-        for (int a = 0; a < 3; a++) {
-            float c0 = fkey_inv(cb[(size_t)r * 6 + a]), c1 = fkey_inv(cb[(size_t)r * 6 + 3 + a]), ext = c1 - c0;
-            int b = ext > 0.0f ? bin_of(centroid(lo, hi, leaf, a), c0, (float)kBins / ext) : 0; // a flat axis: everything in bin 0, never chosen
-            uint32_t *w = base + ((size_t)a * kBins + b) * 7;
+        for (int k = 0; k < 3; k++) { kl[k] = fkey(lo[3 * (size_t)leaf + k]); kh[k] = fkey(hi[3 * (size_t)leaf + k]); }
+        uint32_t *base = one ? s_bins : bins + (size_t)r * kAxes * kBins * 7;
+        for (int j = 0; j < kAxes; j++) {
+            const int a = kAxes == 1 ? (int)R.axis : j;
+            uint32_t *w = base + ((size_t)j * kBins + bin_in(R, a, lo, hi, leaf)) * 7;
             for (int k = 0; k < 3; k++) { atomicMin(&w[k], kl[k]); atomicMax(&w[3 + k], kh[k]); }
             atomicAdd(&w[6], 1u);
         }
     }
     if (!one) return;
     __syncthreads();
-    uint32_t *g = bins + (size_t)(s_lo - r0) * 3 * kBins * 7;
-    for (uint32_t w = threadIdx.x; w < 3 * kBins * 7; w += kBlockB) {
+    uint32_t *g = bins + (size_t)s_lo * kAxes * kBins * 7;
+    for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) {
         const uint32_t k = w % 7, v = s_bins[w];
         if (s_bins[w - k + 6] == 0) continue;             // empty bin
         if (k < 3) atomicMin(&g[w], v); else if (k < 6) atomicMax(&g[w], v); else atomicAdd(&g[w], v);
     }
 }
-struct Box { float lo[3], hi[3]; };
-__device__ __forceinline__ void box_empty(Box &b) { for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; } }
-__device__ __forceinline__ void box_grow(Box &b, const uint32_t *w) { for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], fkey_inv(w[k])); b.hi[k] = fmaxf(b.hi[k], fkey_inv(w[3 + k])); } }
-__device__ __forceinline__ double half_area(const Box &b) { double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2]; return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
-
-__global__ void k_choose(const uint32_t *__restrict__ n_dev, uint32_t win_cap, const Range *__restrict__ ranges, const uint32_t *__restrict__ cb, const uint32_t *__restrict__ bins, Split *splits, Range *next, uint32_t *n_next,
-                         int32_t *child, float *nlo, float *nhi, uint32_t r0) {
-    const uint32_t n_all = *n_dev, n_ranges = n_all > r0 ? (n_all - r0 < win_cap ? n_all : r0 + win_cap) : r0;   // end of the window [r0, n_ranges) whose bins are in `bins`
-    bins -= (size_t)r0 * 3 * kBins * 7;                        // indexed by r below
-    for (uint32_t r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < n_ranges; r += gridDim.x * blockDim.x) {
-    const Range R = ranges[r];
+struct SmallRange { uint32_t b, e, k, depth; };
+__device__ __forceinline__ Box box_shfl(const Box &b, int src) { Box o; for (int k = 0; k < 3; k++) { o.lo[k] = __shfl(b.lo[k], src); o.hi[k] = __shfl(b.hi[k], src); } return o; }
+// One WAVE per range, a lane per bin (kBins <= 64): the boxes and counts of the bins in front of / behind every plane are two scans across the wave, the costs of all the
+// planes of an axis come out at once, the best of them by a wave-wide arg-min -- the thread that used to walk the 3 x 32 bins of a range alone took 55 us whatever the level
+// (the root: ONE thread busy on the whole chip), 213 us at 64 bins: 4.3 of config 2's 12.7 ms.  Same costs in the same doubles, ties to the lower (axis, bin): the same tree.
+static_assert(kBins <= 64, "k_choose: a lane per bin");
+struct LevelOut { Split *splits; Range *next; uint32_t *n_next; SmallRange *small; uint32_t *n_small; int32_t *child; float *nlo, *nhi; };
+// called by all 64 lanes of a wave; wr: the range's bins (global memory, or the LDS of k_mid)
+__device__ __forceinline__ void choose_range(const Range &R, uint32_t r, const uint32_t *wr, int lane, const LevelOut &o) {
+    Split *splits = o.splits; Range *next = o.next; uint32_t *n_next = o.n_next; SmallRange *small = o.small; uint32_t *n_small = o.n_small; int32_t *child = o.child; float *nlo = o.nlo, *nhi = o.nhi;
     const uint32_t n = R.e - R.b;
-    Box node; box_empty(node);
-    for (int i = 0; i < kBins; i++) { const uint32_t *w = bins + (((size_t)r * 3 + 0) * kBins + i) * 7; if (w[6]) box_grow(node, w); }
-    for (int k = 0; k < 3; k++) { nlo[3 * (size_t)R.k + k] = node.lo[k]; nhi[3 * (size_t)R.k + k] = node.hi[k]; }
-    int best_axis = -1, best_bin = 0; uint32_t best_left = 0; double best_cost = INFINITY;
-    if (n > 2 && R.depth < kSahDepth) {
-        for (int a = 0; a < 3; a++) {
-            if (!(fkey_inv(cb[(size_t)r * 6 + 3 + a]) > fkey_inv(cb[(size_t)r * 6 + a]))) continue;
-            const uint32_t *wa = bins + ((size_t)r * 3 + a) * kBins * 7;
-            double right_area[kBins]; uint32_t right_cnt[kBins];
-            Box acc; box_empty(acc); uint32_t c = 0;
-            for (int i = kBins - 1; i > 0; i--) { if (wa[i * 7 + 6]) box_grow(acc, wa + i * 7); c += wa[i * 7 + 6]; right_area[i] = half_area(acc); right_cnt[i] = c; }
-            box_empty(acc); c = 0;
-            for (int i = 0; i < kBins - 1; i++) {
-                if (wa[i * 7 + 6]) box_grow(acc, wa + i * 7);
-                c += wa[i * 7 + 6];
-                if (c == 0 || right_cnt[i + 1] == 0) continue;
-                double cost = half_area(acc) * c + right_area[i + 1] * right_cnt[i + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = i; best_left = c; }
-            }
+    const bool sah = n > 2 && R.depth < kSahDepth;
+    double best_cost = INFINITY; int best_key = 0x7FFFFFFF; uint32_t best_left = 0;
+    Box node, lbs, rbs;   // the node's box; the boxes on either side of this lane's best plane so far
+    box_empty(node); box_empty(lbs); box_empty(rbs);
+    for (int j = 0; j < kAxes; j++) {
+        const int a = kAxes == 1 ? (int)R.axis : j;
+        Box p; box_empty(p); uint32_t cp = 0;
+        if (lane < kBins) { const uint32_t *w = wr + ((size_t)j * kBins + lane) * 7; cp = w[6]; if (cp) box_grow(p, w); }
+        Box q = p; uint32_t cq = cp;
+        for (int off = 1; off < 64; off <<= 1) {   // p, cp: bins 0 .. lane;  q, cq: bins lane .. last
+            Box u, d; uint32_t cu = (uint32_t)__shfl_up((int)cp, off), cd = (uint32_t)__shfl_down((int)cq, off);
+            for (int k = 0; k < 3; k++) { u.lo[k] = __shfl_up(p.lo[k], off); u.hi[k] = __shfl_up(p.hi[k], off); d.lo[k] = __shfl_down(q.lo[k], off); d.hi[k] = __shfl_down(q.hi[k], off); }
+            if (lane >= off) { for (int k = 0; k < 3; k++) { p.lo[k] = fminf(p.lo[k], u.lo[k]); p.hi[k] = fmaxf(p.hi[k], u.hi[k]); } cp += cu; }
+            if (lane + off < 64) { for (int k = 0; k < 3; k++) { q.lo[k] = fminf(q.lo[k], d.lo[k]); q.hi[k] = fmaxf(q.hi[k], d.hi[k]); } cq += cd; }
         }
+        if (j == 0) node = box_shfl(p, 63);   // every leaf is in some bin of the first binned axis
+        // the plane behind bin `lane`: left = bins 0 .. lane, right = bins lane + 1 .. last
+        Box qr; uint32_t cr = (uint32_t)__shfl_down((int)cq, 1);
+        for (int k = 0; k < 3; k++) { qr.lo[k] = __shfl_down(q.lo[k], 1); qr.hi[k] = __shfl_down(q.hi[k], 1); }
+        const bool ok = sah && R.hi[a] > R.lo[a] && lane < kBins - 1 && cp != 0 && cr != 0;
+        const double cost = ok ? half_area(p) * cp + half_area(qr) * cr : (double)INFINITY;
+        if (cost < best_cost) { best_cost = cost; best_key = j * kBins + lane; best_left = cp; lbs = p; rbs = qr; }
     }
+    // the wave's best plane: lowest cost, ties to the lower (axis, bin)
+    double wc = best_cost; int wk = best_key;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oc = __shfl_xor(wc, off); const int ok_ = __shfl_xor(wk, off);
+        if (oc < wc || (oc == wc && ok_ < wk)) { wc = oc; wk = ok_; }
+    }
+    const bool split = wc < (double)INFINITY;
+    const int best_j = split ? wk / kBins : 0, best_bin = split ? wk % kBins : -1;
+    Box lb = box_shfl(lbs, split ? best_bin : 0), rb = box_shfl(rbs, split ? best_bin : 0);
+    const uint32_t left_n = (uint32_t)__shfl((int)best_left, split ? best_bin : 0);
+    if (lane != 0) return;
+    for (int k = 0; k < 3; k++) { nlo[3 * (size_t)R.k + k] = node.lo[k]; nhi[3 * (size_t)R.k + k] = node.hi[k]; }
     Split S;
-    if (best_axis < 0) { S.axis = 3; S.bin = 0; S.nl = n / 2; }       // two leaves, coincident centroids, or past the depth guard
-    else { S.axis = (uint32_t)best_axis; S.bin = (uint32_t)best_bin; S.nl = best_left; }
+    if (!split) { S.axis = 0; S.bin = kNone; S.nl = n / 2; }       // two leaves, coincident centroids, or past the depth guard
+    else { S.axis = kAxes == 1 ? R.axis : (uint32_t)best_j; S.bin = (uint32_t)best_bin; S.nl = left_n; }
     const uint32_t nl = S.nl, nr = n - nl;
     S.left = kNone; S.right = kNone;
-    if (nl > 1) { S.left = atomicAdd(n_next, 1u); next[S.left] = Range{R.b, R.b + nl, R.k + 1, R.depth + 1}; child[2 * (size_t)R.k] = (int32_t)(R.k + 1); }
-    if (nr > 1) { S.right = atomicAdd(n_next, 1u); next[S.right] = Range{R.b + nl, R.e, R.k + nl, R.depth + 1}; child[2 * (size_t)R.k + 1] = (int32_t)(R.k + nl); }
+    if (split) {
+        // A child's domain is where its leaves' CENTROIDS can be, not where their boxes reach (a wall's two triangles span the node; their centroids do not): inside
+        // the parent's domain, on the split axis on the child's side of the plane (a centroid in bin i lies within a rounding of the bin's edges, hence the margin of
+        // half a bin), and inside the child's own box.  The centroid bounds a separate pass over the leaves used to make (6 atomics a leaf and level) are not needed:
+        // with 64 bins the looser domain costs nothing (config 4: 17 270 Mray/s against 17 140 with 32 bins over exact centroid bounds; 16 750 with 32 bins over these).
+        const int a = (int)S.axis;
+        const float w = (R.hi[a] - R.lo[a]) * (1.0f / kBins), plane = R.lo[a] + w * (float)(best_bin + 1);
+        for (int k = 0; k < 3; k++) {
+            const float dl = R.lo[k], dh = R.hi[k];
+            lb.lo[k] = fmaxf(lb.lo[k], dl); lb.hi[k] = fminf(lb.hi[k], k == a ? fminf(dh, plane + 0.5f * w) : dh);
+            rb.lo[k] = fmaxf(rb.lo[k], k == a ? fmaxf(dl, plane - 0.5f * w) : dl); rb.hi[k] = fminf(rb.hi[k], dh);
+        }
+    } else for (int k = 0; k < 3; k++) { lb.lo[k] = rb.lo[k] = fmaxf(node.lo[k], R.lo[k]); lb.hi[k] = rb.hi[k] = fminf(node.hi[k], R.hi[k]); }   // a range split by position bins its halves over its own box
+    if (nl > 1) {
+        child[2 * (size_t)R.k] = (int32_t)(R.k + 1);
+        if (nl <= kSmall) small[atomicAdd(n_small, 1u)] = SmallRange{R.b, R.b + nl, R.k + 1, R.depth + 1};
+        else { S.left = atomicAdd(n_next, 1u); Range L{R.b, R.b + nl, R.k + 1, R.depth + 1, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0, 0}; set_domain(L, lb); next[S.left] = L; }
+    }
+    if (nr > 1) {
+        child[2 * (size_t)R.k + 1] = (int32_t)(R.k + nl);
+        if (nr <= kSmall) small[atomicAdd(n_small, 1u)] = SmallRange{R.b + nl, R.e, R.k + nl, R.depth + 1};
+        else { S.right = atomicAdd(n_next, 1u); Range Rr{R.b + nl, R.e, R.k + nl, R.depth + 1, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0, 0}; set_domain(Rr, rb); next[S.right] = Rr; }
+    }
     splits[r] = S;
+}
+// ranges of more than kMid leaves: their bins were made leaf by leaf (k_bin)
+__global__ __launch_bounds__(64) void k_choose(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, const uint32_t *__restrict__ bins, LevelOut o) {
+    const uint32_t n_ranges = *n_dev;
+    for (uint32_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        const Range R = ranges[r];
+        if (R.e - R.b <= kMid) continue;
+        choose_range(R, r, bins + (size_t)r * kAxes * kBins * 7, (int)threadIdx.x, o);
+    }
+}
+// Ranges of kSmall < n <= kMid leaves, a BLOCK per range: its leaves are an interval of positions, so the block walks them, bins them in its LDS and chooses the plane
+// there -- no bins in memory, no atomics outside the CU.  (Leaf by leaf these levels were the build: ten levels of config 4 at 1 - 2.4 ms of k_bin each, 59 M atomics a level
+// scattered over 230 MB of bins, and another millisecond of k_choose reading them back.)
+__global__ __launch_bounds__(kBlockB) void k_mid(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, const uint32_t *__restrict__ idx, const float *__restrict__ lo, const float *__restrict__ hi, LevelOut o) {
+    __shared__ uint32_t s_bins[kAxes * kBins * 7];
+    const uint32_t n_ranges = *n_dev;
+    for (uint32_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
+        const Range R = ranges[r];
+        if (R.e - R.b > kMid) continue;
+        for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        for (uint32_t i = R.b + threadIdx.x; i < R.e; i += kBlockB) {
+            const uint32_t leaf = idx[i];
+            uint32_t kl[3], kh[3];
+            for (int k = 0; k < 3; k++) { kl[k] = fkey(lo[3 * (size_t)leaf + k]); kh[k] = fkey(hi[3 * (size_t)leaf + k]); }
+            for (int j = 0; j < kAxes; j++) {
+                const int a = kAxes == 1 ? (int)R.axis : j;
+                uint32_t *w = s_bins + ((size_t)j * kBins + bin_in(R, a, lo, hi, leaf)) * 7;
+                for (int k = 0; k < 3; k++) { atomicMin(&w[k], kl[k]); atomicMax(&w[3 + k], kh[k]); }
+                atomicAdd(&w[6], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) choose_range(R, r, s_bins, (int)threadIdx.x, o);
+        __syncthreads();
     }
 }
 __global__ __launch_bounds__(kBlockB) void k_flags(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
-                                                   const Range *__restrict__ ranges, const Split *__restrict__ splits, const uint32_t *__restrict__ cb, uint32_t *flags) {
+                                                   const Range *__restrict__ ranges, const Split *__restrict__ splits, uint32_t *flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T) return;
     uint32_t r = range_of[i], f = 0;
     if (r != kNone) {
         const Split S = splits[r];
-        if (S.axis == 3) f = (i - ranges[r].b) < S.nl;
-        else {
-            float c0 = fkey_inv(cb[(size_t)r * 6 + S.axis]), c1 = fkey_inv(cb[(size_t)r * 6 + 3 + S.axis]);
-            f = bin_of(centroid(lo, hi, idx[i], (int)S.axis), c0, (float)kBins / (c1 - c0)) <= (int)S.bin;
-        }
+        const Range R = ranges[r];
+        if (S.bin == kNone) f = (i - R.b) < S.nl;
+        else f = bin_in(R, (int)S.axis, lo, hi, idx[i]) <= (int)S.bin;
     }
     flags[i] = f;
 }
@@ -174,7 +254,7 @@ __global__ __launch_bounds__(kBlockB) void k_scatter(uint32_t T, const uint32_t 
     uint32_t left_before = scan[i] - scan[R.b];                        // left-going leaves of this range in front of i
     uint32_t dst = flags[i] ? R.b + left_before : R.b + S.nl + ((i - R.b) - left_before);
     idx2[dst] = idx[i];
-    range_of2[dst] = flags[i] ? S.left : S.right;
+    range_of2[dst] = flags[i] ? S.left : S.right;                      // kNone: a leaf, or a small range (the position keeps its leaf from here on)
 }
 __global__ void k_leaf_refs(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, const Split *__restrict__ splits, const uint32_t *__restrict__ idx2, int32_t *child) {
     const uint32_t n_ranges = *n_dev;
@@ -184,64 +264,115 @@ __global__ void k_leaf_refs(const uint32_t *__restrict__ n_dev, const Range *__r
         if (R.e - R.b - S.nl == 1) child[2 * (size_t)R.k + 1] = ~(int32_t)idx2[R.b + S.nl];
     }
 }
-__global__ void k_iota(uint32_t T, uint32_t *idx, uint32_t *range_of) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < T) { idx[i] = i; range_of[i] = 0; } }
+__global__ void k_iota(uint32_t T, uint32_t *idx, uint32_t *range_of, uint32_t first_range) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < T) { idx[i] = i; range_of[i] = first_range; } }
+
+// One thread finishes a small range: the whole subtree under node k over the <= kSmall leaves idx[b, e), by the exact sweep -- on each axis the leaves sorted by
+// centroid, every position a candidate, cost = area(left) * n_left + area(right) * n_right -- iteratively with a stack of sub-ranges (pre-order numbering as above).
+// The leaves' boxes are copied into the thread's own memory once and stay where they are: what is sorted is a byte per leaf (its place in the order of the sub-range);
+// a sub-range left sorted on the winning axis is its own partition.
+__device__ __forceinline__ void small_sort(uint8_t *ord, uint32_t n, const float (*bl)[3], const float (*bh)[3], int a) {   // insertion sort by centroid on axis a, stable
+    for (uint32_t i = 1; i < n; i++) {
+        const uint8_t o = ord[i];
+        const float ck = 0.5f * bl[o][a] + 0.5f * bh[o][a];
+        uint32_t j = i;
+        while (j > 0 && 0.5f * bl[ord[j - 1]][a] + 0.5f * bh[ord[j - 1]][a] > ck) { ord[j] = ord[j - 1]; j--; }
+        ord[j] = o;
+    }
+}
+__global__ __launch_bounds__(64) void k_small(const uint32_t *__restrict__ n_dev, const SmallRange *__restrict__ small, const uint32_t *__restrict__ idx, const float *__restrict__ lo, const float *__restrict__ hi,
+                                              int32_t *child, float *nlo, float *nhi) {
+    const uint32_t n_small = *n_dev;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_small; s += gridDim.x * blockDim.x) {
+        const SmallRange SR = small[s];
+        const uint32_t n0 = SR.e - SR.b;
+        uint32_t leaf[kSmall]; float bl[kSmall][3], bh[kSmall][3]; uint8_t ord[kSmall];
+        for (uint32_t i = 0; i < n0; i++) { const uint32_t l = idx[SR.b + i]; leaf[i] = l; ord[i] = (uint8_t)i; for (int a = 0; a < 3; a++) { bl[i][a] = lo[3 * (size_t)l + a]; bh[i][a] = hi[3 * (size_t)l + a]; } }
+        struct Sub { uint8_t b, n, depth; uint32_t k; } stack[kSmall];
+        int sp = 0;
+        stack[sp++] = Sub{0, (uint8_t)n0, 0, SR.k};
+        while (sp > 0) {
+            const Sub U = stack[--sp];
+            const uint32_t b = U.b, n = U.n;
+            uint8_t *od = ord + b;
+            Box node; box_empty(node);
+            for (uint32_t i = 0; i < n; i++) box_grow(node, bl[od[i]], bh[od[i]]);
+            for (int a = 0; a < 3; a++) { nlo[3 * (size_t)U.k + a] = node.lo[a]; nhi[3 * (size_t)U.k + a] = node.hi[a]; }
+            uint32_t nl = n / 2; int best_axis = -1; double best_cost = INFINITY;
+            if (n > 2 && U.depth < kSmallDepth && SR.depth + U.depth < kSahDepth) {
+                for (int a = 0; a < 3; a++) {
+                    small_sort(od, n, bl, bh, a);
+                    double right_area[kSmall];
+                    Box acc; box_empty(acc);
+                    for (uint32_t i = n - 1; i > 0; i--) { box_grow(acc, bl[od[i]], bh[od[i]]); right_area[i] = half_area(acc); }
+                    box_empty(acc);
+                    for (uint32_t i = 1; i < n; i++) {   // i leaves on the left
+                        box_grow(acc, bl[od[i - 1]], bh[od[i - 1]]);
+                        const double cost = half_area(acc) * i + right_area[i] * (n - i);
+                        if (cost < best_cost) { best_cost = cost; best_axis = a; nl = i; }
+                    }
+                }
+                if (best_axis >= 0 && best_axis != 2) small_sort(od, n, bl, bh, best_axis);   // the sub-range is in z order now: once more on the winning axis
+            }
+            const uint32_t nr = n - nl;
+            if (nl == 1) child[2 * (size_t)U.k] = ~(int32_t)leaf[od[0]];
+            else { child[2 * (size_t)U.k] = (int32_t)(U.k + 1); stack[sp++] = Sub{(uint8_t)b, (uint8_t)nl, (uint8_t)(U.depth + 1), U.k + 1}; }
+            if (nr == 1) child[2 * (size_t)U.k + 1] = ~(int32_t)leaf[od[nl]];
+            else { child[2 * (size_t)U.k + 1] = (int32_t)(U.k + nl); stack[sp++] = Sub{(uint8_t)(b + nl), (uint8_t)nr, (uint8_t)(U.depth + 1), U.k + nl}; }
+        }
+    }
+}
 
 } // namespace
 
 hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     if (T < 3) return hipSuccess;
-    const uint32_t NI = T - 1, max_ranges = T / 2 + 1;
-    // Bins are 3 axes x 32 bins x 7 words = 2688 bytes per open range.  A deep level of a big scene has ~T/4 open ranges (3.8 GB for the
-    // 2.8 M triangles of config 4 if all had bins at once), so a level is binned and split in windows of at most kWindow ranges: 352 MB
-    // whatever T is; config 2 (T/2 = 131 k ranges at most) still takes one pass per level, config 4's deepest levels take up to 11.
-    constexpr uint32_t kWindow = 1u << 17;
-    const uint32_t win_cap = max_ranges < kWindow ? max_ranges : kWindow;
-    uint32_t *idx[2] = {nullptr, nullptr}, *range_of[2] = {nullptr, nullptr}, *cb = nullptr, *bins = nullptr, *flags = nullptr, *scan = nullptr, *n_cnt = nullptr;
-    Range *ranges[2] = {nullptr, nullptr}; Split *splits = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
+    const uint32_t NI = T - 1, max_ranges = T / (kSmall + 1) + 2, max_small = T / 2 + 2;   // a range in the level loop has more than kSmall leaves; a small one at least two
+    uint32_t *idx[2] = {nullptr, nullptr}, *range_of[2] = {nullptr, nullptr}, *bins = nullptr, *flags = nullptr, *scan = nullptr, *n_cnt = nullptr;
+    Range *ranges[2] = {nullptr, nullptr}; Split *splits = nullptr; SmallRange *small = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
     const bool log = (l.log & 1u) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    auto t0 = now(); auto t1 = t0, t2 = t0; uint32_t levels = 0, widest = 0;
+    auto t0 = now(); auto t1 = t0, t2 = t0; uint32_t levels = 0, widest = 0, n_small_host = 0;
     auto body = [&]() -> hipError_t {
         for (int k = 0; k < 2; k++) { HIPQ(hipMalloc(&idx[k], (size_t)T * 4)); HIPQ(hipMalloc(&range_of[k], (size_t)T * 4)); HIPQ(hipMalloc(&ranges[k], (size_t)max_ranges * sizeof(Range))); }
-        HIPQ(hipMalloc(&cb, (size_t)max_ranges * 6 * 4)); HIPQ(hipMalloc(&bins, (size_t)win_cap * 3 * kBins * 7 * 4)); HIPQ(hipMalloc(&splits, (size_t)max_ranges * sizeof(Split)));
-        HIPQ(hipMalloc(&flags, (size_t)T * 4)); HIPQ(hipMalloc(&scan, (size_t)T * 4)); HIPQ(hipMalloc(&n_cnt, 8));
+        HIPQ(hipMalloc(&bins, (size_t)max_ranges * kAxes * kBins * 7 * 4)); HIPQ(hipMalloc(&splits, (size_t)max_ranges * sizeof(Split))); HIPQ(hipMalloc(&small, (size_t)max_small * sizeof(SmallRange)));
+        HIPQ(hipMalloc(&flags, (size_t)T * 4)); HIPQ(hipMalloc(&scan, (size_t)T * 4)); HIPQ(hipMalloc(&n_cnt, 64));   // n_cnt[0 / 1]: open ranges of this / the next level, [2]: small ranges, [4..9]: the root's box
         if (!l.trav_child) { HIPQ(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPQ(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&l.trav_hi, (size_t)NI * 12)); }
         HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
         HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
         HIPQ(hipStreamSynchronize(s)); t1 = now();
         const uint32_t gT = (T + kBlockB - 1) / kBlockB;
-        k_iota<<<gT, kBlockB, 0, s>>>(T, idx[0], range_of[0]);
-        Range root{0, T, 0, 0};
-        HIPQ(hipMemcpyAsync(ranges[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
-        // The number of open ranges lives on the device (n_cnt[cur]: this level's, n_cnt[cur ^ 1]: the one k_choose counts up for the next); the range-indexed kernels
-        // read it there.  A scene whose levels fit two windows of bins (T <= 4 * kWindow: config 2) is launched four levels at a time without the host looking -- its
-        // levels are launch- and fence-bound (23 levels of 262 k leaves: 7.3 ms with a fence per level, a dozen 5 us kernels between two fences) -- and the host asks
-        // only every fourth level whether anything is still open; levels behind the last one find no open range and do nothing.  A bigger scene needs the count for its
-        // windows, and its levels are work-bound anyway: one fence per level as before.
-        const bool pipelined = max_ranges <= 2 * (uint64_t)win_cap;   // (config 2: T / 2 + 1 = 131 409 possible ranges against a window of 131 072 -- its deepest levels launch a second, nearly empty window)
-        const uint32_t one = 1;
-        HIPQ(hipMemcpyAsync(n_cnt, &one, 4, hipMemcpyHostToDevice, s));
-        uint32_t n = 1; int cur = 0;
         auto blocks = [](size_t items, uint32_t per_block, uint32_t cap) { size_t b = (items + per_block - 1) / per_block; return (uint32_t)(b < 1 ? 1 : (b > cap ? cap : b)); };
+        const uint32_t init[16] = {1u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        HIPQ(hipMemcpyAsync(n_cnt, init, sizeof(init), hipMemcpyHostToDevice, s));
+        const bool root_small = T <= kSmall;   // the whole scene is a small range
+        k_iota<<<gT, kBlockB, 0, s>>>(T, idx[0], range_of[0], root_small ? kNone : 0u);
+        if (root_small) {
+            const SmallRange root{0, T, 0, 0}; const uint32_t one_zero[3] = {0u, 0u, 1u};
+            HIPQ(hipMemcpyAsync(small, &root, sizeof(root), hipMemcpyHostToDevice, s));
+            HIPQ(hipMemcpyAsync(n_cnt, one_zero, sizeof(one_zero), hipMemcpyHostToDevice, s));
+        } else {
+            k_root_range<<<1, 1, 0, s>>>(T, l.cbounds, ranges[0]);   // the root's domain: the bounds of the centroids, which the Morton keys were made over
+        }
+        // The number of open ranges lives on the device (n_cnt[cur]: this level's, n_cnt[cur ^ 1]: the one k_choose counts up for the next); the range-indexed kernels
+        // read it there, and the levels are launched four at a time without the host looking -- they are launch- and fence-bound (a dozen 5-50 us kernels between two
+        // fences) -- the host asks only every fourth level whether anything is still open; levels behind the last one find no open range and do nothing.
+        uint32_t n = root_small ? 0u : 1u; int cur = 0;
         for (uint32_t level = 0; n > 0 && level < 4096; level++) {
             HIPQ(hipMemsetAsync(n_cnt + (cur ^ 1), 0, 4, s));
-            const uint32_t n_up = pipelined ? (uint32_t)std::min<uint64_t>(1ull << std::min(level, 31u), max_ranges) : n;   // at most this many ranges are open (a level doubles them at most)
-            for (uint32_t r0 = 0; r0 < n_up; r0 += win_cap) {
-                const uint32_t nw = n_up - r0 < win_cap ? n_up - r0 : win_cap;
-                const size_t words = std::max((size_t)nw * 3 * kBins * 7, r0 == 0 ? (size_t)n_up * 6 : (size_t)0);   // the centroid boxes of the whole level are cleared with its first window
-                k_init_level<<<blocks(words, kBlockB, 8192), kBlockB, 0, s>>>(n_cnt + cur, r0 == 0, r0, win_cap, cb, bins);
-                if (r0 == 0) k_centroid_bounds<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb);
-                k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, cb, bins, r0, win_cap);
-                k_choose<<<blocks(nw, 64, 4096), 64, 0, s>>>(n_cnt + cur, win_cap, ranges[cur], cb, bins, splits, ranges[cur ^ 1], n_cnt + (cur ^ 1), l.trav_child, l.trav_lo, l.trav_hi, r0);
-            }
-            k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, cb, flags);
+            const uint32_t n_up = (uint32_t)std::min<uint64_t>(1ull << std::min(level, 31u), max_ranges);   // at most this many ranges are open (a level doubles them at most)
+            const LevelOut lo_{splits, ranges[cur ^ 1], n_cnt + (cur ^ 1), small, n_cnt + 2, l.trav_child, l.trav_lo, l.trav_hi};
+            k_init_level<<<blocks(n_up, 1, 4096), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], bins);
+            k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], bins);
+            k_choose<<<blocks(n_up, 1, 4096), 64, 0, s>>>(n_cnt + cur, ranges[cur], bins, lo_);
+            k_mid<<<blocks(n_up, 1, 32768), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], idx[cur], l.leaf_lo, l.leaf_hi, lo_);
+            k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, flags);
             size_t tb = tmp_bytes;
             HIPQ(rocprim::exclusive_scan(tmp, tb, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
             k_scatter<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], ranges[cur], splits, flags, scan, idx[cur ^ 1], range_of[cur ^ 1]);
             k_leaf_refs<<<blocks(n_up, 256, 2048), 256, 0, s>>>(n_cnt + cur, ranges[cur], splits, idx[cur ^ 1], l.trav_child);
             cur ^= 1; levels++;
-            if (!pipelined || (level & 3u) == 3u) {
+            if ((level & 3u) == 3u) {
                 uint32_t nn = 0;
                 HIPQ(hipMemcpyAsync(&nn, n_cnt + cur, 4, hipMemcpyDeviceToHost, s));
                 HIPQ(hipStreamSynchronize(s));
@@ -249,8 +380,11 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
                 n = nn; widest = n > widest ? n : widest;
             }
         }
-        t2 = now();
         if (n != 0) return hipErrorUnknown;
+        // everything the levels left: one thread per small range (idx[cur] holds the leaves of every range in its final interval)
+        k_small<<<blocks(max_small, 64, 16384), 64, 0, s>>>(n_cnt + 2, small, idx[cur], l.leaf_lo, l.leaf_hi, l.trav_child, l.trav_lo, l.trav_hi);
+        if (log) { HIPQ(hipMemcpyAsync(&n_small_host, n_cnt + 2, 4, hipMemcpyDeviceToHost, s)); HIPQ(hipStreamSynchronize(s)); }
+        t2 = now();
         HIPQ(hipGetLastError());
         launch_emit_nodes(l, T, s);
         HIPQ(hipGetLastError());
@@ -260,8 +394,8 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     hipError_t err = body();
     auto t3 = now();
     for (int k = 0; k < 2; k++) { hipFree(idx[k]); hipFree(range_of[k]); hipFree(ranges[k]); }
-    hipFree(cb); hipFree(bins); hipFree(splits); hipFree(flags); hipFree(scan); hipFree(n_cnt); hipFree(tmp);
-    if (log) std::fprintf(stderr, "[art] sah_build_device %u leaves: wait + allocations %.1f ms, %u levels launched (at most %u open ranges seen) %.1f, node records %.1f, frees %.1f\n", T, ms(t0, t1), levels, widest, ms(t1, t2), ms(t2, t3), ms(t3, now()));
+    hipFree(bins); hipFree(splits); hipFree(small); hipFree(flags); hipFree(scan); hipFree(n_cnt); hipFree(tmp);
+    if (log) std::fprintf(stderr, "[art] sah_build_device %u leaves: wait + allocations %.1f ms, %u levels launched (at most %u open ranges seen at a fence), %u small ranges %.1f, node records %.1f, frees %.1f\n", T, ms(t0, t1), levels, widest, n_small_host, ms(t1, t2), ms(t2, t3), ms(t3, now()));
     return err;
 }
 
