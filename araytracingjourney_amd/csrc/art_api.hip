@@ -148,6 +148,7 @@ struct ArtContext {
     DevBuf<float> d_verts; DevBuf<uint8_t> d_indices; DevBuf<uint32_t> d_tex; DevBuf<DevPrim> d_prims; DevBuf<uint32_t> d_first_tri;
     std::vector<uint32_t> h_first_tri; // first global triangle id of every primitive slot (ascending): gid -> (primitive, triangle) on the host
     Lbvh bvh{};
+    Arena arena;              // the build phases' scratch, kept from build to build (art_internal.h)
     uint32_t T = 0;
     // moving models (art_scene_set_model_matrix): versions of the structure, the primitive table as the next refit will upload it
     std::vector<AsVersion> as; uint32_t as_cur = 0; bool xform_dirty = false;
@@ -723,7 +724,7 @@ int32_t art_destroy(ArtContext *c) {
     for (uint32_t k = 0; k < c->F; k++) if (c->stream_of(k)) (void)hipStreamSynchronize(c->stream_of(k));
     drop_graphs(c);
     as_release(c);
-    lbvh_free(c->bvh);
+    lbvh_free(c->bvh); c->arena.release();
     c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release(); c->d_ao_tab.release();
     c->d_tile_list.release(); c->d_tile_xy.release(); c->d_tile_slot.release(); c->d_block_order.release(); c->plan.release();
     for (uint32_t k = 0; k < kMaxFrames; k++) {
@@ -860,7 +861,7 @@ int32_t art_scene_build(ArtContext *c) {
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
     as_release(c); c->xform_dirty = false; c->as_epoch = 0; c->binary_epoch = 0; c->refit_cost_ratio = 1.0f; // the versions were copies of the tree that goes away
-    lbvh_free(c->bvh); c->built = false; drop_graphs(c);
+    lbvh_free(c->bvh); c->bvh.arena = &c->arena; c->built = false; drop_graphs(c);
     // Only enabled primitives are uploaded and instanced (get_acceleration_structure_instance returns None unless the model is in
     // the Device state, vk_model.rs:360-372).  Ids keep their meaning: a disabled primitive stays in the table with zero triangles.
     // With nothing enabled the tree is one zero-area triangle that no ray can hit (an empty TLAS: every ray misses).

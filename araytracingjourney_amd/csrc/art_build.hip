@@ -460,12 +460,14 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
     int32_t *front[2] = {nullptr, nullptr}, *cand = nullptr; uint32_t *meta = nullptr, *cnt = nullptr, *offs = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
     DevNode4 *wide = nullptr; DevNodeW *widef = nullptr;
     std::vector<uint32_t> levels; // first node of every level (breadth-first numbering: a level is contiguous), then n_wide
+    Arena own; Arena &A = l.arena ? *l.arena : own;
     auto body = [&]() -> hipError_t {
-        HIPQ(hipMalloc(&front[0], (size_t)cap * 4)); HIPQ(hipMalloc(&front[1], (size_t)cap * 4)); HIPQ(hipMalloc(&cand, (size_t)cap * 16));
-        HIPQ(hipMalloc(&meta, (size_t)cap * 4)); HIPQ(hipMalloc(&cnt, ((size_t)cap + 1) * 4)); HIPQ(hipMalloc(&offs, ((size_t)cap + 1) * 4));
-        HIPQ(hipMalloc(&wide, (size_t)cap * sizeof(DevNode4))); HIPQ(hipMalloc(&widef, (size_t)cap * sizeof(DevNodeW)));
         HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, offs, 0u, (size_t)cap + 1, rocprim::plus<uint32_t>(), s));
-        HIPQ(hipMalloc(&tmp, tmp_bytes));
+        HIPQ(A.reserve(3 * Arena::pad((size_t)cap * 4) + Arena::pad((size_t)cap * 16) + 2 * Arena::pad(((size_t)cap + 1) * 4) + Arena::pad((size_t)cap * sizeof(DevNode4)) + Arena::pad((size_t)cap * sizeof(DevNodeW)) + Arena::pad(tmp_bytes ? tmp_bytes : 16)));
+        front[0] = A.take<int32_t>(cap); front[1] = A.take<int32_t>(cap); cand = A.take<int32_t>((size_t)cap * 4);
+        meta = A.take<uint32_t>(cap); cnt = A.take<uint32_t>((size_t)cap + 1); offs = A.take<uint32_t>((size_t)cap + 1);
+        wide = A.take<DevNode4>(cap); widef = A.take<DevNodeW>(cap);
+        tmp = A.take<char>(tmp_bytes ? tmp_bytes : 16);
         const int32_t root = NI ? 0 : ~0;
         HIPQ(hipMemcpyAsync(front[0], &root, 4, hipMemcpyHostToDevice, s));
         uint32_t first = 0, n = 1; int cur = 0;
@@ -489,7 +491,6 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
         return hipSuccess;
     };
     hipError_t e = body();
-    hipFree(front[0]); hipFree(front[1]); hipFree(cand); hipFree(meta); hipFree(cnt); hipFree(offs); hipFree(tmp);
     if (e == hipSuccess) { // the work arrays are sized for the worst case (NI nodes); a 4-wide collapse of a binary tree has about a third of that
         e = hipMalloc(&l.wide, (size_t)l.n_wide * sizeof(DevNode4));
         if (e == hipSuccess) e = hipMalloc(&l.widef, (size_t)l.n_wide * sizeof(DevNodeW));
@@ -498,7 +499,7 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { hipFree(l.wide); hipFree(l.widef); l.wide = nullptr; l.widef = nullptr; l.n_wide = 0; }
     }
-    hipFree(wide); hipFree(widef);
+    own.release();
     return e;
 }
 
@@ -710,7 +711,10 @@ void lbvh_free(Lbvh &l) {
 hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node_boxes) {
     const uint32_t T = in.T;
     const uint32_t NI = T > 1 ? T - 1 : 1;
+    Arena *const ctx_arena = out.arena;
     out = Lbvh{};
+    out.arena = ctx_arena;
+    Arena own; Arena &A = ctx_arena ? *ctx_arena : own;
     float *triw = nullptr, *tlo = nullptr, *thi = nullptr;
     uint32_t *cslots = nullptr, *gid_in = nullptr, *arrive = nullptr;
     uint64_t *keys_in = nullptr;
@@ -719,9 +723,14 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
     size_t tmp_bytes = 0;
     hipError_t err = hipSuccess;
     auto body = [&]() -> hipError_t {
-        HIPQ(hipMalloc(&triw, (size_t)T * 36)); HIPQ(hipMalloc(&tlo, (size_t)T * 12)); HIPQ(hipMalloc(&thi, (size_t)T * 12));
-        HIPQ(hipMalloc(&cslots, kCbSlots * 32 * 4)); HIPQ(hipMalloc(&out.cbounds, 32)); HIPQ(hipMalloc(&gid_in, (size_t)T * 4)); HIPQ(hipMalloc(&keys_in, (size_t)T * 8));
-        HIPQ(hipMalloc(&arrive, (size_t)NI * 4)); HIPQ(hipMalloc(&parent_int, (size_t)NI * 4)); HIPQ(hipMalloc(&parent_leaf, (size_t)T * 4));
+        // the temporaries: one reservation of the context's arena (the sort's own scratch included)
+        HIPQ(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
+        HIPQ(A.reserve(Arena::pad((size_t)T * 36) + 2 * Arena::pad((size_t)T * 12) + Arena::pad(kCbSlots * 32 * 4) + Arena::pad((size_t)T * 4) + Arena::pad((size_t)T * 8) + 2 * Arena::pad((size_t)NI * 4) + Arena::pad((size_t)T * 4) + Arena::pad(tmp_bytes ? tmp_bytes : 16)));
+        triw = A.take<float>((size_t)T * 9); tlo = A.take<float>((size_t)T * 3); thi = A.take<float>((size_t)T * 3);
+        cslots = A.take<uint32_t>(kCbSlots * 32); gid_in = A.take<uint32_t>(T); keys_in = A.take<uint64_t>(T);
+        arrive = A.take<uint32_t>(NI); parent_int = A.take<int32_t>(NI); parent_leaf = A.take<int32_t>(T);
+        tmp = A.take<char>(tmp_bytes ? tmp_bytes : 16);
+        HIPQ(hipMalloc(&out.cbounds, 32));
         HIPQ(hipMalloc(&out.leaf_gid, (size_t)T * 4)); HIPQ(hipMalloc(&out.keys, (size_t)T * 8)); HIPQ(hipMalloc(&out.child, (size_t)NI * 8));
         HIPQ(hipMalloc(&out.node_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&out.node_hi, (size_t)NI * 12));
         HIPQ(hipMalloc(&out.leaf_lo, (size_t)T * 12)); HIPQ(hipMalloc(&out.leaf_hi, (size_t)T * 12));
@@ -734,8 +743,6 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
         k_soup<<<GT, B, 0, s>>>(in.prims, in.n_prims, in.prim_first_tri, T, triw, tlo, thi, out.tri_prim, cslots);
         k_cb_fold<<<1, kCbSlots, 0, s>>>(cslots, out.cbounds);
         k_morton<<<GT, B, 0, s>>>(T, in.morton_bits, tlo, thi, out.cbounds, keys_in, gid_in);
-        HIPQ(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
-        HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
         HIPQ(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, out.keys, gid_in, out.leaf_gid, T, 0, 64, s));
         k_leaves<<<GT, B, 0, s>>>(T, out.leaf_gid, triw, tlo, thi, out.tri_prim, in.prim_first_tri, out.leaf_lo, out.leaf_hi, out.tris, in.prims, out.shade_tris);
         if (T > 1) {
@@ -749,7 +756,7 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
         return hipSuccess;
     };
     err = body();
-    hipFree(triw); hipFree(tlo); hipFree(thi); hipFree(cslots); hipFree(gid_in); hipFree(keys_in); hipFree(arrive); hipFree(parent_int); hipFree(parent_leaf); hipFree(tmp);
+    own.release();
     if (err != hipSuccess) lbvh_free(out);
     return err;
 }

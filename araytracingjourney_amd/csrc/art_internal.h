@@ -77,7 +77,26 @@ struct BuildInputs {
     const DevPrim *prims; uint32_t n_prims; const uint32_t *prim_first_tri; // device
     uint32_t T; uint32_t morton_bits;
 };
+// Scratch memory of the builders: ONE device allocation that a context keeps from build to build (it only grows), cut up by each build phase.  The phases used to
+// hipMalloc / hipFree their three dozen temporaries one by one -- 40 us apiece with the GPU idle in between: 2.1 of the 6.8 ms a rebuild of config 2 took.
+// A phase reserves what it needs (nothing of an earlier phase is live: every phase ends with a stream synchronisation), then takes its pieces.
+struct Arena {
+    char *base = nullptr; size_t cap = 0, off = 0;
+    static size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    hipError_t reserve(size_t bytes) {
+        off = 0;
+        if (bytes <= cap) return hipSuccess;
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&base, bytes + bytes / 8);   // (some room: the next scene is rarely the same size to the byte)
+        if (e == hipSuccess) cap = bytes + bytes / 8;
+        return e;
+    }
+    template <class T> T *take(size_t n) { T *p = reinterpret_cast<T *>(base + off); off += pad(n * sizeof(T)); return p; }   // the caller reserved the sum of pad(...)
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; off = 0; }
+};
 struct Lbvh {               // canonical binary LBVH, device arrays
+    Arena *arena = nullptr; // host: the context's scratch for the build phases (not owned; null: a phase allocates and frees its own)
     uint32_t *leaf_gid;     // [T]
     uint64_t *keys;         // [T]
     int32_t *child;         // [2*(T-1)]
