@@ -128,9 +128,13 @@ __device__ __forceinline__ Box box_shfl(const Box &b, int src) { Box o; for (int
 // (the root: ONE thread busy on the whole chip), 213 us at 64 bins: 4.3 of config 2's 12.7 ms.  Same costs in the same doubles, ties to the lower (axis, bin): the same tree.
 static_assert(kBins <= 64, "k_choose: a lane per bin");
 struct LevelOut { Split *splits; Range *next; uint32_t *n_next; SmallRange *small; uint32_t *n_small; int32_t *child; float *nlo, *nhi; };
-// called by all 64 lanes of a wave; wr: the range's bins (global memory, or the LDS of k_mid)
-__device__ __forceinline__ void choose_range(const Range &R, uint32_t r, const uint32_t *wr, int lane, const LevelOut &o) {
-    Split *splits = o.splits; Range *next = o.next; uint32_t *n_next = o.n_next; SmallRange *small = o.small; uint32_t *n_small = o.n_small; int32_t *child = o.child; float *nlo = o.nlo, *nhi = o.nhi;
+// What a range's split leaves to be written once its children have their places in the next level's / the small ranges' lists.  The places are handed out by ONE atomic per
+// list for a whole batch of ranges (commit_batch): an atomic per child on the two counters was the deep levels' time -- 43 k ranges x 2 returning atomics on one word, at
+// the ~90 per microsecond a word takes (MI355X_MICROARCH.md), is the 1.3 ms a level that k_mid measured.
+struct Pending { Split S; Range L, Rr; uint32_t r; uint32_t kind_l, kind_r; };   // kind: 0 a leaf (or nothing), 1 a small range, 2 a range of the next level; r kNone: empty
+// called by all 64 lanes of a wave; wr: the range's bins (global memory, or the LDS of k_mid); lane 0 fills *out
+__device__ __forceinline__ void choose_range(const Range &R, uint32_t r, const uint32_t *wr, int lane, const LevelOut &o, Pending *out) {
+    int32_t *child = o.child; float *nlo = o.nlo, *nhi = o.nhi;
     const uint32_t n = R.e - R.b;
     const bool sah = n > 2 && R.depth < kSahDepth;
     double best_cost = INFINITY; int best_key = 0x7FFFFFFF; uint32_t best_left = 0;
@@ -185,51 +189,71 @@ __device__ __forceinline__ void choose_range(const Range &R, uint32_t r, const u
             rb.lo[k] = fmaxf(rb.lo[k], k == a ? fmaxf(dl, plane - 0.5f * w) : dl); rb.hi[k] = fminf(rb.hi[k], dh);
         }
     } else for (int k = 0; k < 3; k++) { lb.lo[k] = rb.lo[k] = fmaxf(node.lo[k], R.lo[k]); lb.hi[k] = rb.hi[k] = fminf(node.hi[k], R.hi[k]); }   // a range split by position bins its halves over its own box
-    if (nl > 1) {
-        child[2 * (size_t)R.k] = (int32_t)(R.k + 1);
-        if (nl <= kSmall) small[atomicAdd(n_small, 1u)] = SmallRange{R.b, R.b + nl, R.k + 1, R.depth + 1};
-        else { S.left = atomicAdd(n_next, 1u); Range L{R.b, R.b + nl, R.k + 1, R.depth + 1, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0, 0}; set_domain(L, lb); next[S.left] = L; }
+    Pending P; P.r = r; P.kind_l = 0; P.kind_r = 0;
+    P.L = Range{R.b, R.b + nl, R.k + 1, R.depth + 1, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0, 0};
+    P.Rr = Range{R.b + nl, R.e, R.k + nl, R.depth + 1, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0, 0};
+    if (nl > 1) { child[2 * (size_t)R.k] = (int32_t)(R.k + 1); if (nl <= kSmall) P.kind_l = 1; else { P.kind_l = 2; set_domain(P.L, lb); } }
+    if (nr > 1) { child[2 * (size_t)R.k + 1] = (int32_t)(R.k + nl); if (nr <= kSmall) P.kind_r = 1; else { P.kind_r = 2; set_domain(P.Rr, rb); } }
+    P.S = S;
+    *out = P;
+}
+// one thread: the places of a batch's children (one atomic per list), then the records
+__device__ __forceinline__ void commit_batch(Pending *p, uint32_t count, const LevelOut &o) {
+    uint32_t cn = 0, cs = 0;
+    for (uint32_t j = 0; j < count; j++) if (p[j].r != kNone) { cn += (p[j].kind_l == 2) + (p[j].kind_r == 2); cs += (p[j].kind_l == 1) + (p[j].kind_r == 1); }
+    uint32_t bn = cn ? atomicAdd(o.n_next, cn) : 0u, bs = cs ? atomicAdd(o.n_small, cs) : 0u;
+    for (uint32_t j = 0; j < count; j++) {
+        if (p[j].r == kNone) continue;
+        Split S = p[j].S;
+        if (p[j].kind_l == 2) { S.left = bn; o.next[bn++] = p[j].L; } else if (p[j].kind_l == 1) o.small[bs++] = SmallRange{p[j].L.b, p[j].L.e, p[j].L.k, p[j].L.depth};
+        if (p[j].kind_r == 2) { S.right = bn; o.next[bn++] = p[j].Rr; } else if (p[j].kind_r == 1) o.small[bs++] = SmallRange{p[j].Rr.b, p[j].Rr.e, p[j].Rr.k, p[j].Rr.depth};
+        o.splits[p[j].r] = S;
     }
-    if (nr > 1) {
-        child[2 * (size_t)R.k + 1] = (int32_t)(R.k + nl);
-        if (nr <= kSmall) small[atomicAdd(n_small, 1u)] = SmallRange{R.b + nl, R.e, R.k + nl, R.depth + 1};
-        else { S.right = atomicAdd(n_next, 1u); Range Rr{R.b + nl, R.e, R.k + nl, R.depth + 1, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0, 0}; set_domain(Rr, rb); next[S.right] = Rr; }
-    }
-    splits[r] = S;
 }
 // ranges of more than kMid leaves: their bins were made leaf by leaf (k_bin)
 __global__ __launch_bounds__(64) void k_choose(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, const uint32_t *__restrict__ bins, LevelOut o) {
+    __shared__ Pending s_p;
     const uint32_t n_ranges = *n_dev;
     for (uint32_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
         const Range R = ranges[r];
         if (R.e - R.b <= kMid) continue;
-        choose_range(R, r, bins + (size_t)bin_slot(R) * kAxes * kBins * 7, (int)threadIdx.x, o);
+        choose_range(R, r, bins + (size_t)bin_slot(R) * kAxes * kBins * 7, (int)threadIdx.x, o, &s_p);
+        if (threadIdx.x == 0) commit_batch(&s_p, 1, o);   // (few of these: at most T / kMid a level)
     }
 }
 // Ranges of kSmall < n <= kMid leaves, a BLOCK per range: its leaves are an interval of positions, so the block walks them, bins them in its LDS and chooses the plane
 // there -- no bins in memory, no atomics outside the CU.  (Leaf by leaf these levels were the build: ten levels of config 4 at 1 - 2.4 ms of k_bin each, 59 M atomics a level
 // scattered over 230 MB of bins, and another millisecond of k_choose reading them back.)
+constexpr uint32_t kBatch = 8;   // ranges a block of k_mid takes before it asks the two counters for their children's places
 __global__ __launch_bounds__(kBlockB) void k_mid(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, const uint32_t *__restrict__ idx, const float *__restrict__ lo, const float *__restrict__ hi, LevelOut o) {
     __shared__ uint32_t s_bins[kAxes * kBins * 7];
+    __shared__ Pending s_p[kBatch];
     const uint32_t n_ranges = *n_dev;
-    for (uint32_t r = blockIdx.x; r < n_ranges; r += gridDim.x) {
-        const Range R = ranges[r];
-        if (R.e - R.b > kMid) continue;
-        for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
-        __syncthreads();
-        for (uint32_t i = R.b + threadIdx.x; i < R.e; i += kBlockB) {
-            const uint32_t leaf = idx[i];
-            uint32_t kl[3], kh[3];
-            for (int k = 0; k < 3; k++) { kl[k] = fkey(lo[3 * (size_t)leaf + k]); kh[k] = fkey(hi[3 * (size_t)leaf + k]); }
-            for (int j = 0; j < kAxes; j++) {
-                const int a = kAxes == 1 ? (int)R.axis : j;
-                uint32_t *w = s_bins + ((size_t)j * kBins + bin_in(R, a, lo, hi, leaf)) * 7;
-                for (int k = 0; k < 3; k++) { atomicMin(&w[k], kl[k]); atomicMax(&w[3 + k], kh[k]); }
-                atomicAdd(&w[6], 1u);
+    for (uint32_t r0 = blockIdx.x * kBatch; r0 < n_ranges; r0 += gridDim.x * kBatch) {
+        for (uint32_t j = 0; j < kBatch; j++) {
+            const uint32_t r = r0 + j;
+            if (threadIdx.x == 0) s_p[j].r = kNone;
+            if (r >= n_ranges) continue;            // (block-uniform)
+            const Range R = ranges[r];
+            if (R.e - R.b > kMid) continue;
+            for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
+            __syncthreads();
+            for (uint32_t i = R.b + threadIdx.x; i < R.e; i += kBlockB) {
+                const uint32_t leaf = idx[i];
+                uint32_t kl[3], kh[3];
+                for (int k = 0; k < 3; k++) { kl[k] = fkey(lo[3 * (size_t)leaf + k]); kh[k] = fkey(hi[3 * (size_t)leaf + k]); }
+                for (int jj = 0; jj < kAxes; jj++) {
+                    const int a = kAxes == 1 ? (int)R.axis : jj;
+                    uint32_t *w = s_bins + ((size_t)jj * kBins + bin_in(R, a, lo, hi, leaf)) * 7;
+                    for (int k = 0; k < 3; k++) { atomicMin(&w[k], kl[k]); atomicMax(&w[3 + k], kh[k]); }
+                    atomicAdd(&w[6], 1u);
+                }
             }
+            __syncthreads();
+            if (threadIdx.x < 64) choose_range(R, r, s_bins, (int)threadIdx.x, o, &s_p[j]);
+            __syncthreads();
         }
-        __syncthreads();
-        if (threadIdx.x < 64) choose_range(R, r, s_bins, (int)threadIdx.x, o);
+        if (threadIdx.x == 0) commit_batch(s_p, kBatch, o);
         __syncthreads();
     }
 }
@@ -371,7 +395,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
             k_init_level<<<blocks(n_up, 1, 4096), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], bins);
             k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], bins);
             k_choose<<<blocks(n_up, 1, 4096), 64, 0, s>>>(n_cnt + cur, ranges[cur], bins, lo_);
-            k_mid<<<blocks(n_up, 1, 32768), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], idx[cur], l.leaf_lo, l.leaf_hi, lo_);
+            k_mid<<<blocks(n_up, kBatch, 32768), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], idx[cur], l.leaf_lo, l.leaf_hi, lo_);
             k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, flags);
             size_t tb = tmp_bytes;
             HIPQ(rocprim::exclusive_scan(tmp, tb, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
