@@ -83,42 +83,54 @@ __global__ void k_root_range(uint32_t T, const uint32_t *__restrict__ box, Range
     set_domain(R, b);
     ranges[0] = R;
 }
-// Near the root thousands of leaves share a range: the bins are reduced per block in LDS when the block has ONE range (262 k leaves on the root's words took
-// 3.3 ms of serialised atomics otherwise)
+// The bins of the ranges of more than kMid leaves, leaf by leaf.  A block takes a window of kWin positions; a window is shorter than such a range, so it holds leaves
+// of at most two of them (the one that ends in it, the one that begins): each gets the block's LDS histogram in turn, and what leaves the CU is one atomic per
+// touched word and window -- leaf by leaf straight to memory, 262 k leaves on the root's words took 3.3 ms of serialised atomics.
+constexpr uint32_t kWin = 2048, kWinItems = kWin / kBlockB;
+static_assert(kWin <= kMid, "k_bin: a window holds at most two large ranges");
 __global__ __launch_bounds__(kBlockB) void k_bin(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
                                                  const Range *__restrict__ ranges, uint32_t *bins) {
     __shared__ uint32_t s_lo, s_hi, s_bins[kAxes * kBins * 7];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t r = i < T ? range_of[i] : kNone;
-    Range R{};
-    if (r != kNone) { R = ranges[r]; if (R.e - R.b <= kMid) r = kNone; }   // k_mid's
-    const bool valid = r != kNone;
+    const uint32_t w0 = blockIdx.x * kWin;
     if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; }
-    for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
     __syncthreads();
-    if (valid) { atomicMin(&s_lo, r); atomicMax(&s_hi, r); }
-    __syncthreads();
-    if (s_lo == 0xFFFFFFFFu) return;                      // nothing open in this block
-    const bool one = s_lo == s_hi;                        // the whole block bins into ONE range: histogram in LDS, then one global atomic per touched word
-    if (valid) {
-        uint32_t leaf = idx[i];
-        uint32_t kl[3], kh[3];
-        for (int k = 0; k < 3; k++) { kl[k] = fkey(lo[3 * (size_t)leaf + k]); kh[k] = fkey(hi[3 * (size_t)leaf + k]); }
-        uint32_t *base = one ? s_bins : bins + (size_t)bin_slot(R) * kAxes * kBins * 7;
-        for (int j = 0; j < kAxes; j++) {
-            const int a = kAxes == 1 ? (int)R.axis : j;
-            uint32_t *w = base + ((size_t)j * kBins + bin_in(R, a, lo, hi, leaf)) * 7;
-            for (int k = 0; k < 3; k++) { atomicMin(&w[k], kl[k]); atomicMax(&w[3 + k], kh[k]); }
-            atomicAdd(&w[6], 1u);
-        }
+    uint32_t rr[kWinItems], mn = 0xFFFFFFFFu, mx = 0u;
+    for (uint32_t it = 0; it < kWinItems; it++) {
+        const uint32_t i = w0 + it * kBlockB + threadIdx.x;
+        uint32_t r = i < T ? range_of[i] : kNone;
+        if (r != kNone && ranges[r].e - ranges[r].b <= kMid) r = kNone;   // k_mid's
+        rr[it] = r;
+        if (r != kNone) { mn = min(mn, r); mx = max(mx, r); }
     }
-    if (!one) return;
+    if (mn != 0xFFFFFFFFu) { atomicMin(&s_lo, mn); atomicMax(&s_hi, mx); }
     __syncthreads();
-    uint32_t *g = bins + (size_t)bin_slot(ranges[s_lo]) * kAxes * kBins * 7;
-    for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) {
-        const uint32_t k = w % 7, v = s_bins[w];
-        if (s_bins[w - k + 6] == 0) continue;             // empty bin
-        if (k < 3) atomicMin(&g[w], v); else if (k < 6) atomicMax(&g[w], v); else atomicAdd(&g[w], v);
+    if (s_lo == 0xFFFFFFFFu) return;                      // no large range in this window
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t target = pass == 0 ? s_lo : s_hi;
+        if (pass == 1 && s_hi == s_lo) break;
+        for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        const Range R = ranges[target];
+        for (uint32_t it = 0; it < kWinItems; it++) {
+            if (rr[it] != target) continue;
+            const uint32_t leaf = idx[w0 + it * kBlockB + threadIdx.x];
+            uint32_t kl[3], kh[3];
+            for (int k = 0; k < 3; k++) { kl[k] = fkey(lo[3 * (size_t)leaf + k]); kh[k] = fkey(hi[3 * (size_t)leaf + k]); }
+            for (int j = 0; j < kAxes; j++) {
+                const int a = kAxes == 1 ? (int)R.axis : j;
+                uint32_t *w = s_bins + ((size_t)j * kBins + bin_in(R, a, lo, hi, leaf)) * 7;
+                for (int k = 0; k < 3; k++) { atomicMin(&w[k], kl[k]); atomicMax(&w[3 + k], kh[k]); }
+                atomicAdd(&w[6], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t *g = bins + (size_t)bin_slot(R) * kAxes * kBins * 7;
+        for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) {
+            const uint32_t k = w % 7, v = s_bins[w];
+            if (s_bins[w - k + 6] == 0) continue;             // empty bin
+            if (k < 3) atomicMin(&g[w], v); else if (k < 6) atomicMax(&g[w], v); else atomicAdd(&g[w], v);
+        }
+        __syncthreads();
     }
 }
 struct SmallRange { uint32_t b, e, k, depth; };
@@ -393,7 +405,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
             const uint32_t n_up = (uint32_t)std::min<uint64_t>(1ull << std::min(level, 31u), max_ranges);   // at most this many ranges are open (a level doubles them at most)
             const LevelOut lo_{splits, ranges[cur ^ 1], n_cnt + (cur ^ 1), small, n_cnt + 2, l.trav_child, l.trav_lo, l.trav_hi};
             k_init_level<<<blocks(n_up, 1, 4096), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], bins);
-            k_bin<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], bins);
+            k_bin<<<(T + kWin - 1) / kWin, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], bins);
             k_choose<<<blocks(n_up, 1, 4096), 64, 0, s>>>(n_cnt + cur, ranges[cur], bins, lo_);
             k_mid<<<blocks(n_up, kBatch, 32768), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], idx[cur], l.leaf_lo, l.leaf_hi, lo_);
             k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, flags);
