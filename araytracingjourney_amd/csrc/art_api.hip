@@ -714,6 +714,8 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     // kernels, profiles/README.md r1h); art_set_tuning selects the other forms
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
     if (cfg->flags & ART_FLAG_DEVICE_TREE) c->tree_builder = 2;
+    build_prewarm(c->main_stream()); sah_prewarm(c->main_stream());   // the builders' code objects are loaded here, once a process, not inside the first art_scene_build
+    (void)hipGetLastError();
     *out = c;
     return ART_OK;
 }

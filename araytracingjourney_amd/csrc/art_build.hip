@@ -701,6 +701,9 @@ hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s) 
     return e;
 }
 
+__global__ void k_build_noop() {}
+void build_prewarm(hipStream_t s) { k_build_noop<<<1, 1, 0, s>>>(); }
+
 void lbvh_free(Lbvh &l) {
     hipFree(l.wide); hipFree(l.widef); hipFree(l.shade_tris);
     hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);

@@ -132,6 +132,10 @@ hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out);
 // the binned SAH of sah_build, level by level on the device (art_sahdev.hip)
 hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s);
 void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s);
+// an empty launch from the translation unit of each builder: the runtime loads a unit's code object at its first launch (10-20 ms a process used to pay inside its first
+// art_scene_build); art_create pays it instead
+void build_prewarm(hipStream_t s);   // art_build.hip (LBVH, 4-wide collapse, refit, rocPRIM's sort and scans)
+void sah_prewarm(hipStream_t s);     // art_sahdev.hip
 // refit after a model moved (art_build.hip): the triangle records of a version of the acceleration structure from the shading records and that version's
 // primitive table; its 4-wide nodes bottom-up, level by level (l.wide_levels); the tree's surface-area cost (2 doubles: sum of child half-areas, root half-area);
 // the binary trees and node records from a version's triangles (on demand, synchronises)

@@ -360,7 +360,9 @@ __global__ __launch_bounds__(64) void k_small(const uint32_t *__restrict__ n_dev
     }
 }
 
+__global__ void k_sah_noop() {}
 } // namespace
+void sah_prewarm(hipStream_t s) { k_sah_noop<<<1, 1, 0, s>>>(); }
 
 hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     if (T < 3) return hipSuccess;
