@@ -139,7 +139,7 @@ __device__ __forceinline__ Box box_shfl(const Box &b, int src) { Box o; for (int
 // planes of an axis come out at once, the best of them by a wave-wide arg-min -- the thread that used to walk the 3 x 32 bins of a range alone took 55 us whatever the level
 // (the root: ONE thread busy on the whole chip), 213 us at 64 bins: 4.3 of config 2's 12.7 ms.  Same costs in the same doubles, ties to the lower (axis, bin): the same tree.
 static_assert(kBins <= 64, "k_choose: a lane per bin");
-struct LevelOut { Split *splits; Range *next; uint32_t *n_next; SmallRange *small; uint32_t *n_small; int32_t *child; float *nlo, *nhi; };
+struct LevelOut { Split *splits; Range *next; uint32_t *n_next; SmallRange *small; uint32_t *n_small; int32_t *child; float *nlo, *nhi; uint32_t *n_big; };   // n_big: how many of the next level's ranges have more than kMid leaves
 // What a range's split leaves to be written once its children have their places in the next level's / the small ranges' lists.  The places are handed out by ONE atomic per
 // list for a whole batch of ranges (commit_batch): an atomic per child on the two counters was the deep levels' time -- 43 k ranges x 2 returning atomics on one word, at
 // the ~90 per microsecond a word takes (MI355X_MICROARCH.md), is the 1.3 ms a level that k_mid measured.
@@ -213,13 +213,15 @@ __device__ __forceinline__ void choose_range(const Range &R, uint32_t r, const u
 __device__ __forceinline__ void commit_batch(Pending *p, uint32_t count, const LevelOut &o) {
     uint32_t cn = 0, cs = 0;
     for (uint32_t j = 0; j < count; j++) if (p[j].r != kNone) { cn += (p[j].kind_l == 2) + (p[j].kind_r == 2); cs += (p[j].kind_l == 1) + (p[j].kind_r == 1); }
-    uint32_t bn = cn ? atomicAdd(o.n_next, cn) : 0u, bs = cs ? atomicAdd(o.n_small, cs) : 0u;
+    uint32_t bn = cn ? atomicAdd(o.n_next, cn) : 0u, bs = cs ? atomicAdd(o.n_small, cs) : 0u, big = 0;
+    for (uint32_t j = 0; j < count; j++) if (p[j].r != kNone) { big += (p[j].kind_l == 2 && p[j].L.e - p[j].L.b > kMid) + (p[j].kind_r == 2 && p[j].Rr.e - p[j].Rr.b > kMid); }
+    if (big) atomicAdd(o.n_big, big);
     for (uint32_t j = 0; j < count; j++) {
         if (p[j].r == kNone) continue;
         Split S = p[j].S;
         if (p[j].kind_l == 2) { S.left = bn; o.next[bn++] = p[j].L; } else if (p[j].kind_l == 1) o.small[bs++] = SmallRange{p[j].L.b, p[j].L.e, p[j].L.k, p[j].L.depth};
         if (p[j].kind_r == 2) { S.right = bn; o.next[bn++] = p[j].Rr; } else if (p[j].kind_r == 1) o.small[bs++] = SmallRange{p[j].Rr.b, p[j].Rr.e, p[j].Rr.k, p[j].Rr.depth};
-        o.splits[p[j].r] = S;
+        if (o.splits) o.splits[p[j].r] = S;
     }
 }
 // ranges of more than kMid leaves: their bins were made leaf by leaf (k_bin)
@@ -237,17 +239,24 @@ __global__ __launch_bounds__(64) void k_choose(const uint32_t *__restrict__ n_de
 // there -- no bins in memory, no atomics outside the CU.  (Leaf by leaf these levels were the build: ten levels of config 4 at 1 - 2.4 ms of k_bin each, 59 M atomics a level
 // scattered over 230 MB of bins, and another millisecond of k_choose reading them back.)
 constexpr uint32_t kBatch = 8;   // ranges a block of k_mid takes before it asks the two counters for their children's places
-__global__ __launch_bounds__(kBlockB) void k_mid(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, const uint32_t *__restrict__ idx, const float *__restrict__ lo, const float *__restrict__ hi, LevelOut o) {
+// FULL: the level's only kernel once no range of more than kMid leaves is open (the host learns that at a fence) -- the block also PARTITIONS its range, in place (the
+// leaves staged in LDS: a stable split by the chosen plane) and writes the references of one-leaf sides: no flags, no scan over T, no scatter, no range-of-position array,
+// two launches a level instead of a dozen.  Not FULL: the level's other kernels do that for every open range at once (k_flags, the scan, k_scatter, k_leaf_refs).
+template <bool FULL> __global__ __launch_bounds__(kBlockB) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_mid(const uint32_t *__restrict__ n_dev, const Range *__restrict__ ranges, uint32_t *idx, const float *__restrict__ lo, const float *__restrict__ hi, LevelOut o) {
     __shared__ uint32_t s_bins[kAxes * kBins * 7];
     __shared__ Pending s_p[kBatch];
+    __shared__ uint32_t s_out[FULL ? kMid : 1], s_wave[kBlockB / 64], s_base;
     const uint32_t n_ranges = *n_dev;
-    for (uint32_t r0 = blockIdx.x * kBatch; r0 < n_ranges; r0 += gridDim.x * kBatch) {
-        for (uint32_t j = 0; j < kBatch; j++) {
+    // a batch is walked range after range: its length is the level's latency when the ranges are few (8 x ~12 us against a chip two thirds idle), the counters' relief when
+    // they are many (one returning atomic per list and batch; a word takes ~90 a microsecond)
+    const uint32_t batch = n_ranges <= 512 ? 1u : (n_ranges <= 4096 ? 2u : (n_ranges <= 16384 ? 4u : kBatch));
+    for (uint32_t r0 = blockIdx.x * batch; r0 < n_ranges; r0 += gridDim.x * batch) {
+        for (uint32_t j = 0; j < batch; j++) {
             const uint32_t r = r0 + j;
             if (threadIdx.x == 0) s_p[j].r = kNone;
             if (r >= n_ranges) continue;            // (block-uniform)
             const Range R = ranges[r];
-            if (R.e - R.b > kMid) continue;
+            if (R.e - R.b > kMid) continue;         // (FULL: there is none)
             for (uint32_t w = threadIdx.x; w < kAxes * kBins * 7; w += kBlockB) s_bins[w] = (w % 7) < 3 ? 0xFFFFFFFFu : 0u;
             __syncthreads();
             for (uint32_t i = R.b + threadIdx.x; i < R.e; i += kBlockB) {
@@ -263,12 +272,40 @@ __global__ __launch_bounds__(kBlockB) void k_mid(const uint32_t *__restrict__ n_
             }
             __syncthreads();
             if (threadIdx.x < 64) choose_range(R, r, s_bins, (int)threadIdx.x, o, &s_p[j]);
+            if (FULL && threadIdx.x == 0) s_base = 0;
             __syncthreads();
+            if (FULL) {
+                const Split S = s_p[j].S;
+                const uint32_t n = R.e - R.b, nl = S.nl;
+                for (uint32_t c0 = 0; c0 < n; c0 += kBlockB) {
+                    const uint32_t i = c0 + threadIdx.x;
+                    const bool valid = i < n;
+                    const uint32_t leaf = valid ? idx[R.b + i] : 0u;
+                    const bool f = valid && (S.bin == kNone ? i < nl : bin_in(R, (int)S.axis, lo, hi, leaf) <= (int)S.bin);
+                    const uint64_t m = __ballot(f);
+                    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+                    if (lane == 0) s_wave[wv] = (uint32_t)__popcll(m);
+                    __syncthreads();
+                    uint32_t before = s_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));   // left-going leaves in front of i
+                    for (uint32_t w = 0; w < wv; w++) before += s_wave[w];
+                    if (valid) s_out[f ? before : nl + (i - before)] = leaf;
+                    __syncthreads();
+                    if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < kBlockB / 64; w++) t += s_wave[w]; s_base += t; }
+                    __syncthreads();
+                }
+                for (uint32_t i = threadIdx.x; i < n; i += kBlockB) idx[R.b + i] = s_out[i];
+                if (threadIdx.x == 0) {
+                    if (nl == 1) o.child[2 * (size_t)R.k] = ~(int32_t)s_out[0];
+                    if (n - nl == 1) o.child[2 * (size_t)R.k + 1] = ~(int32_t)s_out[nl];
+                }
+                __syncthreads();
+            }
         }
-        if (threadIdx.x == 0) commit_batch(s_p, kBatch, o);
+        if (threadIdx.x == 0) commit_batch(s_p, batch, o);
         __syncthreads();
     }
 }
+__global__ void k_level_reset(uint32_t *n_cnt, int next) { n_cnt[next] = 0; n_cnt[4 + next] = 0; }
 __global__ __launch_bounds__(kBlockB) void k_flags(uint32_t T, const uint32_t *__restrict__ idx, const uint32_t *__restrict__ range_of, const float *__restrict__ lo, const float *__restrict__ hi,
                                                    const Range *__restrict__ ranges, const Split *__restrict__ splits, uint32_t *flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -372,7 +409,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
     const bool log = (l.log & 1u) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    auto t0 = now(); auto t1 = t0, t2 = t0; uint32_t levels = 0, widest = 0, n_small_host = 0;
+    auto t0 = now(); auto t1 = t0, t2 = t0; uint32_t levels = 0, widest = 0, n_small_host = 0; int idx_cur = 0;   // idx_cur: which of idx[] / range_of[] holds the leaves (a scatter flips it)
     Arena own; Arena &A = l.arena ? *l.arena : own;
     const size_t n_slots = (size_t)T / kMid + 2;
     auto body = [&]() -> hipError_t {
@@ -387,7 +424,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
         HIPQ(hipStreamSynchronize(s)); t1 = now();
         const uint32_t gT = (T + kBlockB - 1) / kBlockB;
         auto blocks = [](size_t items, uint32_t per_block, uint32_t cap) { size_t b = (items + per_block - 1) / per_block; return (uint32_t)(b < 1 ? 1 : (b > cap ? cap : b)); };
-        const uint32_t init[16] = {1u, 0u, 0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        const uint32_t init[16] = {1u, 0u, 0u, 0u, T > kMid ? 1u : 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // [0 / 1] open ranges of this / the next level, [2] small ranges, [4 / 5] ranges of more than kMid leaves
         HIPQ(hipMemcpyAsync(n_cnt, init, sizeof(init), hipMemcpyHostToDevice, s));
         const bool root_small = T <= kSmall;   // the whole scene is a small range
         k_iota<<<gT, kBlockB, 0, s>>>(T, idx[0], range_of[0], root_small ? kNone : 0u);
@@ -401,32 +438,39 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
         // The number of open ranges lives on the device (n_cnt[cur]: this level's, n_cnt[cur ^ 1]: the one k_choose counts up for the next); the range-indexed kernels
         // read it there, and the levels are launched four at a time without the host looking -- they are launch- and fence-bound (a dozen 5-50 us kernels between two
         // fences) -- the host asks only every fourth level whether anything is still open; levels behind the last one find no open range and do nothing.
-        uint32_t n = root_small ? 0u : 1u; int cur = 0;
+        uint32_t n = root_small ? 0u : 1u, n_big = T > kMid ? 1u : 0u; int cur = 0;   // n_cnt[4 + parity]: how many of a level's ranges have more than kMid leaves
         for (uint32_t level = 0; n > 0 && level < 4096; level++) {
-            HIPQ(hipMemsetAsync(n_cnt + (cur ^ 1), 0, 4, s));
+            k_level_reset<<<1, 1, 0, s>>>(n_cnt, cur ^ 1);
             const uint32_t n_up = (uint32_t)std::min<uint64_t>(1ull << std::min(level, 31u), max_ranges);   // at most this many ranges are open (a level doubles them at most)
-            const LevelOut lo_{splits, ranges[cur ^ 1], n_cnt + (cur ^ 1), small, n_cnt + 2, l.trav_child, l.trav_lo, l.trav_hi};
-            k_init_level<<<blocks(n_up, 1, 4096), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], bins);
-            k_bin<<<(T + kWin - 1) / kWin, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], bins);
-            k_choose<<<blocks(n_up, 1, 4096), 64, 0, s>>>(n_cnt + cur, ranges[cur], bins, lo_);
-            k_mid<<<blocks(n_up, kBatch, 32768), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], idx[cur], l.leaf_lo, l.leaf_hi, lo_);
-            k_flags<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, flags);
-            size_t tb = tmp_bytes;
-            HIPQ(rocprim::exclusive_scan(tmp, tb, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
-            k_scatter<<<gT, kBlockB, 0, s>>>(T, idx[cur], range_of[cur], ranges[cur], splits, flags, scan, idx[cur ^ 1], range_of[cur ^ 1]);
-            k_leaf_refs<<<blocks(n_up, 256, 2048), 256, 0, s>>>(n_cnt + cur, ranges[cur], splits, idx[cur ^ 1], l.trav_child);
+            if (n_big == 0) {   // every open range fits a block: the level is one launch, the leaves stay in idx[cur]
+                const LevelOut lo_{nullptr, ranges[cur ^ 1], n_cnt + (cur ^ 1), small, n_cnt + 2, l.trav_child, l.trav_lo, l.trav_hi, n_cnt + 4 + (cur ^ 1)};
+                k_mid<true><<<blocks(n_up, n_up <= 512 ? 1 : (n_up <= 4096 ? 2 : (n_up <= 16384 ? 4 : kBatch)), 32768), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], idx[idx_cur], l.leaf_lo, l.leaf_hi, lo_);
+            } else {
+                const LevelOut lo_{splits, ranges[cur ^ 1], n_cnt + (cur ^ 1), small, n_cnt + 2, l.trav_child, l.trav_lo, l.trav_hi, n_cnt + 4 + (cur ^ 1)};
+                k_init_level<<<blocks(n_up, 1, 4096), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], bins);
+                k_bin<<<(T + kWin - 1) / kWin, kBlockB, 0, s>>>(T, idx[idx_cur], range_of[idx_cur], l.leaf_lo, l.leaf_hi, ranges[cur], bins);
+                k_choose<<<blocks(n_up, 1, 4096), 64, 0, s>>>(n_cnt + cur, ranges[cur], bins, lo_);
+                k_mid<false><<<blocks(n_up, n_up <= 512 ? 1 : (n_up <= 4096 ? 2 : (n_up <= 16384 ? 4 : kBatch)), 32768), kBlockB, 0, s>>>(n_cnt + cur, ranges[cur], idx[idx_cur], l.leaf_lo, l.leaf_hi, lo_);
+                k_flags<<<gT, kBlockB, 0, s>>>(T, idx[idx_cur], range_of[idx_cur], l.leaf_lo, l.leaf_hi, ranges[cur], splits, flags);
+                size_t tb = tmp_bytes;
+                HIPQ(rocprim::exclusive_scan(tmp, tb, flags, scan, 0u, T, rocprim::plus<uint32_t>(), s));
+                k_scatter<<<gT, kBlockB, 0, s>>>(T, idx[idx_cur], range_of[idx_cur], ranges[cur], splits, flags, scan, idx[idx_cur ^ 1], range_of[idx_cur ^ 1]);
+                k_leaf_refs<<<blocks(n_up, 256, 2048), 256, 0, s>>>(n_cnt + cur, ranges[cur], splits, idx[idx_cur ^ 1], l.trav_child);
+                idx_cur ^= 1;
+            }
             cur ^= 1; levels++;
             if ((level & 3u) == 3u) {
-                uint32_t nn = 0;
-                HIPQ(hipMemcpyAsync(&nn, n_cnt + cur, 4, hipMemcpyDeviceToHost, s));
+                uint32_t nn[6] = {0, 0, 0, 0, 0, 0};
+                HIPQ(hipMemcpyAsync(nn, n_cnt, sizeof(nn), hipMemcpyDeviceToHost, s));
                 HIPQ(hipStreamSynchronize(s));
-                if (nn > max_ranges) return hipErrorUnknown;
-                n = nn; widest = n > widest ? n : widest;
+                if (nn[cur] > max_ranges) return hipErrorUnknown;
+                n = nn[cur]; widest = n > widest ? n : widest;
+                if (n_big) n_big = nn[4 + cur];   // (once zero it stays zero: a child is no larger than its parent)
             }
         }
         if (n != 0) return hipErrorUnknown;
         // everything the levels left: one thread per small range (idx[cur] holds the leaves of every range in its final interval)
-        k_small<<<blocks(max_small, 64, 16384), 64, 0, s>>>(n_cnt + 2, small, idx[cur], l.leaf_lo, l.leaf_hi, l.trav_child, l.trav_lo, l.trav_hi);
+        k_small<<<blocks(max_small, 64, 16384), 64, 0, s>>>(n_cnt + 2, small, idx[idx_cur], l.leaf_lo, l.leaf_hi, l.trav_child, l.trav_lo, l.trav_hi);
         if (log) { HIPQ(hipMemcpyAsync(&n_small_host, n_cnt + 2, 4, hipMemcpyDeviceToHost, s)); HIPQ(hipStreamSynchronize(s)); }
         t2 = now();
         HIPQ(hipGetLastError());
