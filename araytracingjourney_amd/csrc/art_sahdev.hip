@@ -1,19 +1,19 @@
 // The PREFER_FAST_TRACE traversal tree built on the device: a binned surface-area heuristic over the LBVH's leaves (one triangle per leaf, pre-order node
-// numbering: the left subtree follows its parent, the right one starts nl nodes on), level by level over ALL open ranges at once, and -- since round 3 -- one
-// thread per SMALL range (<= kSmall leaves) for everything below it.  Every node box is an exact min/max union of leaf boxes (unions go through an
-// order-preserving float <-> uint key, so the atomics are integer min / max), hence frames cannot depend on which builder ran.
+// numbering: the left subtree follows its parent, the right one starts nl nodes on), level by level over ALL open ranges at once, each range by the kernel
+// that fits its size.  Every node box is an exact min/max union of leaf boxes (unions go through an order-preserving float <-> uint key, so the atomics are
+// integer min / max), hence frames cannot depend on which builder ran.
 //
-// A level = a handful of launches over the T leaf positions:
-//   k_bin               per position -> its bin on the range's LONGEST axis (32 bins over the range's own box): leaf box + count, 7 atomics
-//   k_choose            per range    -> node box, best bin by SAH (or the median past the depth guard), the children's boxes -> their axis and domain;
-//                                       a child of <= kSmall leaves goes to the small list instead of the next level
-//   k_flags + scan + k_scatter       -> stable partition of every range at once (one exclusive scan over T flags)
-//   k_leaf_refs         per range    -> child references of one-leaf sides (known only after the partition)
-// Round 3 (profiles/README.md, "build"): the levels were bound by their atomics -- 21 a leaf for bins on all three axes plus 6 for the centroid bounds of the
-// range, 27 ms + 14 ms of the 62 ms of config 4.  The bins now cover one axis, the longest of the range's box (the rule of pbrt's SAH builder), and a child's
-// domain is its own box, which k_choose has at hand from the bins: no centroid pass at all below the root.  Ranges of <= kSmall leaves used to be most of the
-// open ranges of the deep levels (1.4 M of them at once for config 4, binned in windows of 128 k); now a thread sweeps each of them exactly -- every axis, every
-// position, leaves sorted by centroid -- which is a better split than 32 bins gave them and takes the deepest third of the levels out of the loop.
+//   a range of more than kMid leaves:   k_bin     windows of positions -> LDS histograms (64 bins x 3 axes over the range's domain) -> one atomic per touched word
+//                                       k_choose  a WAVE per range: a lane per bin, two scans, every plane's cost at once, wave arg-min
+//                                       k_flags + scan + k_scatter + k_leaf_refs: stable partition of every open range at once (these levels only)
+//   kSmall < leaves <= kMid:            k_mid     a block per range: bins in LDS, the plane chosen there; once no larger range is open, the level's only kernel --
+//                                                 it then partitions its range in place and writes the one-leaf sides
+//   2 .. kSmall leaves:                 k_small   (once, after the levels) a thread per range: the whole subtree by the exact sweep
+// A child's binning domain comes from the parent's bins (no centroid pass below the root); the children's places in the next level's / the small ranges' lists
+// are handed out a batch of ranges at a time; the levels are launched four at a time between fences; all temporaries come from the context's arena.
+// Round 3b (profiles/README.md): 11.8 -> 4.15 ms for config 2's 262 816 triangles, 62.5 -> 12.8 ms for config 4's 2.8 M, at +0.8 % of the ray rate.  The levels had
+// been one leaf-by-leaf pass: 21 atomics a leaf for the bins and 6 for the centroid bounds, 48 of config 4's 62 ms; bins on ONE axis (the longest side: pbrt's
+// rule) cost config 4 8.5 % of its ray rate and were dropped.
 #include "art_internal.h"
 #include <rocprim/rocprim.hpp>
 #include <chrono>
