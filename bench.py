@@ -42,7 +42,9 @@ def parse():
                                                 "textures) instead of the synthetic scene: loaded through art_scene_add_glb, set up like main.rs:23-66; the line then says data: \"real glb\". "
                                                 "Default: assets/*.glb if one is there (SURVEY.md 8d), else the synthetic scene")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="ring of per-frame streams / buffers like the reference's FrameData ring (renderer.rs:135, which keeps 3); "
-                                                                      "default 16 on one GPU (one hardware queue each), 12 launches when the frame is sharded")
+                                                                      "default on one GPU: 3 for a run of at most 32 steps (a fenced burst: the driver's --steps 20 makes 17 500 Mray/s through a ring of 3 -- the reference's own depth -- "
+                                                                      "and 16 200 through one of 16, whose sixteen frames fill and drain together), else 8 (19 650 over 1 000 steps; 16: 19 350; 3: 18 900: tools/ring_sweep.sh); "
+                                                                      "12 launches when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--watchdog-seconds", type=float, default=-1.0, help="if the run has not finished after this long, every rank prints its Python stack and exits 1 (0 = off; default: off "
@@ -136,7 +138,7 @@ def main():
         sc = scenes.sponza_like(args.detail)
         lights = scenes.sponza_lights(args.lights)
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (12 if world > 1 else 16)
+    F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (12 if world > 1 else (3 if args.steps <= 32 else 8))
     packed = world > 1 and args.gather == "packed"
     dedicated = world > 1 and args.compositor == "dedicated"
     G = world - 1 if dedicated else world           # shards of the frame = ranks that trace

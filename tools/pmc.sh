@@ -14,7 +14,7 @@ if [ -z "$PMC_SHORT" ]; then SETS+=("TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_
 SETS+=("FETCH_SIZE" "WRITE_SIZE")
 for C in "${SETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --plain --settle-seconds 0 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --plain --settle-seconds 0 --frames-in-flight 8 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections

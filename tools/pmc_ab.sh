@@ -14,7 +14,7 @@ for T in "$@"; do
   n=$((n+1)); i=0
   for C in "${SETS[@]}"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/t${n}p$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --plain --settle-seconds 0 --tuning "$T" > $OUT/t${n}p$i.log 2>&1 || echo "setting $n pass $i failed"
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/t${n}p$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --plain --settle-seconds 0 --frames-in-flight 8 --tuning "$T" > $OUT/t${n}p$i.log 2>&1 || echo "setting $n pass $i failed"
   done
 done
 python3 - "$@" <<PY
