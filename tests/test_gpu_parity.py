@@ -612,16 +612,15 @@ def test_residency_only_device_models_are_traced(R, get_scene):
     both.close(); only.close()
 
 
-@pytest.mark.parametrize("builder", ["sah-device", "sah-host", "ploc-device"])
-@pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12), ("sponza_like", 1.0)])
-def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail, builder):
-    """what makes the SAH rebuild invisible (DESIGN.md 1.1): every leaf of the canonical LBVH hangs in the traversal tree exactly once,
-    every node box is the exact min/max union of its children's boxes, the root is node 0, the depth stays inside the walks' stacks"""
-    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=builder == "ploc-device", tuning={"tree_builder": 1} if builder == "sah-host" else None)   # binned SAH on the device (default) / on the host threads / PLOC
+def _check_traversal_tree(r, same_as_karras_allowed=False):
+    """every leaf of the canonical LBVH hangs in the traversal tree exactly once, every node box is the exact min/max union of its children's boxes, the root is node 0
+    (pre-order: parents before children), the depth stays inside the walks' stacks"""
     lb, tr = r.get_lbvh(), r.get_traversal_tree()
     T = lb["leaf_gid"].size
     child = tr["child"]
-    assert child.shape == (T - 1, 2) and not np.array_equal(child, lb["child"])          # a different topology than Karras'
+    assert child.shape == (T - 1, 2)
+    if not same_as_karras_allowed:
+        assert not np.array_equal(child, lb["child"])                                    # a different topology than Karras'
     leaves = ~child[child < 0]
     assert np.array_equal(np.sort(leaves), np.arange(T))                                 # each leaf exactly once
     inner = child[child >= 0]
@@ -640,6 +639,47 @@ def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail, bui
                 assert c > n
                 depth[c] = depth[n] + 1
     assert depth.max() + 1 <= 80
+    return T
+
+
+@pytest.mark.parametrize("builder", ["sah-device", "sah-host", "ploc-device"])
+@pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12), ("sponza_like", 1.0)])
+def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail, builder):
+    """what makes the SAH rebuild invisible (DESIGN.md 1.1): every leaf of the canonical LBVH hangs in the traversal tree exactly once,
+    every node box is the exact min/max union of its children's boxes, the root is node 0, the depth stays inside the walks' stacks"""
+    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=builder == "ploc-device", tuning={"tree_builder": 1} if builder == "sah-host" else None)   # binned SAH on the device (default) / on the host threads / PLOC
+    _check_traversal_tree(r)
+    r.close()
+
+
+@pytest.mark.parametrize("n_tris", [16, 17, 18, 40, 300, 4096, 4097, 4200, 9000])
+def test_device_sah_at_the_sizes_where_its_kernels_change(R, orc, n_tris):
+    """The device builder takes each range by the kernel that fits its size (art_sahdev.hip: a thread per range of <= 16 leaves, a block per range of <= 4 096, bins in memory
+    above; a level is one fused kernel once no large range is open): scenes of exactly the sizes where that changes -- the whole scene one small range, one leaf more, a
+    range that just fits a block's LDS staging and one that does not, a root that is large with children that are not -- must give a valid tree of exact boxes, and ray
+    queries the oracle's answers bit for bit.  Degenerate on purpose: a quarter of the triangles are copies of their neighbours (equal centroids: flat domains, ties)."""
+    from araytracingjourney_amd import scenes
+    rng = np.random.default_rng(n_tris)
+    mb = scenes.MeshBuilder()
+    c = rng.uniform(-1.0, 1.0, (n_tris, 3)).astype(np.float32) * np.array([1.0, 0.3, 0.6], np.float32)
+    c[3::4] = c[2::4][: c[3::4].shape[0]]                                                 # duplicates
+    ext = max(0.05, 0.8 / np.sqrt(n_tris))
+    e = rng.uniform(-ext, ext, (n_tris, 2, 3)).astype(np.float32)
+    e[3::4] = e[2::4][: e[3::4].shape[0]]
+    for k in range(n_tris):
+        p0 = c[k]; p1 = c[k] + e[k, 0]; p2 = c[k] + e[k, 1]
+        mb.add([tuple(p0), tuple(p1), tuple(p2)], [(0, 0), (1, 0), (0, 1)], [(0, 0, -1)] * 3, [(1, 0, 0, 1)] * 3, [0, 1, 2])
+    sc = scenes.Scene("soup", [mb.finish(scenes.constant_texture((200, 180, 160)))], scenes.cornell().camera, scenes.cornell().lights)
+    S, L, nl = oracle_for(orc, sc)
+    rays = random_rays(6000, n_tris)
+    rtuv, rids, _, _ = S.trace_closest(rays)
+    r = R.renderer_for_scene(sc, (64, 48))
+    assert _check_traversal_tree(r, same_as_karras_allowed=True) == n_tris
+    tuv, ids = r.query_closest(rays)
+    assert np.array_equal(ids, rids) and np.array_equal(tuv.view(np.uint32)[:, :3], rtuv.view(np.uint32)[:, :3])
+    assert (ids[:, 0] >= 0).sum() > 20
+    r.prepare_first_frame()                                                               # a second build in the same context: the arena is reused
+    assert _check_traversal_tree(r, same_as_karras_allowed=True) == n_tris
     r.close()
 
 
