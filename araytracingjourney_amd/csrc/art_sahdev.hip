@@ -343,59 +343,66 @@ __global__ void k_iota(uint32_t T, uint32_t *idx, uint32_t *range_of, uint32_t f
 
 // One thread finishes a small range: the whole subtree under node k over the <= kSmall leaves idx[b, e), by the exact sweep -- on each axis the leaves sorted by
 // centroid, every position a candidate, cost = area(left) * n_left + area(right) * n_right -- iteratively with a stack of sub-ranges (pre-order numbering as above).
-// The leaves' boxes are copied into the thread's own memory once and stay where they are: what is sorted is a byte per leaf (its place in the order of the sub-range);
-// a sub-range left sorted on the winning axis is its own partition.
-__device__ __forceinline__ void small_sort(uint8_t *ord, uint32_t n, const float (*bl)[3], const float (*bh)[3], int a) {   // insertion sort by centroid on axis a, stable
+// The leaves' boxes are copied once and stay where they are: what is sorted is a byte per leaf (its place in the order of the sub-range); a sub-range left sorted on the
+// winning axis is its own partition.  The boxes, the order and the sweep's right-hand areas live in LDS, [index][lane] (the bank is the lane's, whatever the index: no
+// conflicts): as a thread's own arrays they were scratch memory behind per-lane indices, and the kernel waited on it -- 2.4 ms for config 4's 256 k small ranges.
+static_assert(kSmall <= 255, "k_small: a byte per leaf");
+struct SmallLds { float box[kSmall * 6][64]; float right_area[kSmall][64]; uint8_t ord[kSmall][64]; };
+#define SBOX(i, k) (L.box[(i) * 6 + (k)][lane])   /* k: 0..2 lo, 3..5 hi */
+__device__ __forceinline__ float small_centroid(const SmallLds &L, uint32_t lane, uint32_t o, int a) { return 0.5f * SBOX(o, a) + 0.5f * SBOX(o, 3 + a); }
+__device__ __forceinline__ void small_sort(SmallLds &L, uint32_t lane, uint32_t b, uint32_t n, int a) {   // insertion sort of ord[b, b + n) by centroid on axis a, stable
     for (uint32_t i = 1; i < n; i++) {
-        const uint8_t o = ord[i];
-        const float ck = 0.5f * bl[o][a] + 0.5f * bh[o][a];
+        const uint8_t o = L.ord[b + i][lane];
+        const float ck = small_centroid(L, lane, o, a);
         uint32_t j = i;
-        while (j > 0 && 0.5f * bl[ord[j - 1]][a] + 0.5f * bh[ord[j - 1]][a] > ck) { ord[j] = ord[j - 1]; j--; }
-        ord[j] = o;
+        while (j > 0) { const uint8_t p = L.ord[b + j - 1][lane]; if (!(small_centroid(L, lane, p, a) > ck)) break; L.ord[b + j][lane] = p; j--; }
+        L.ord[b + j][lane] = o;
     }
 }
+__device__ __forceinline__ void small_grow(Box &acc, const SmallLds &L, uint32_t lane, uint32_t o) { for (int k = 0; k < 3; k++) { acc.lo[k] = fminf(acc.lo[k], SBOX(o, k)); acc.hi[k] = fmaxf(acc.hi[k], SBOX(o, 3 + k)); } }
 __global__ __launch_bounds__(64) void k_small(const uint32_t *__restrict__ n_dev, const SmallRange *__restrict__ small, const uint32_t *__restrict__ idx, const float *__restrict__ lo, const float *__restrict__ hi,
                                               int32_t *child, float *nlo, float *nhi) {
+    __shared__ SmallLds L;
+    const uint32_t lane = threadIdx.x;
     const uint32_t n_small = *n_dev;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_small; s += gridDim.x * blockDim.x) {
         const SmallRange SR = small[s];
         const uint32_t n0 = SR.e - SR.b;
-        uint32_t leaf[kSmall]; float bl[kSmall][3], bh[kSmall][3]; uint8_t ord[kSmall];
-        for (uint32_t i = 0; i < n0; i++) { const uint32_t l = idx[SR.b + i]; leaf[i] = l; ord[i] = (uint8_t)i; for (int a = 0; a < 3; a++) { bl[i][a] = lo[3 * (size_t)l + a]; bh[i][a] = hi[3 * (size_t)l + a]; } }
+        uint32_t leaf[kSmall];
+        for (uint32_t i = 0; i < n0; i++) { const uint32_t l = idx[SR.b + i]; leaf[i] = l; L.ord[i][lane] = (uint8_t)i; for (int a = 0; a < 3; a++) { SBOX(i, a) = lo[3 * (size_t)l + a]; SBOX(i, 3 + a) = hi[3 * (size_t)l + a]; } }
         struct Sub { uint8_t b, n, depth; uint32_t k; } stack[kSmall];
         int sp = 0;
         stack[sp++] = Sub{0, (uint8_t)n0, 0, SR.k};
         while (sp > 0) {
             const Sub U = stack[--sp];
             const uint32_t b = U.b, n = U.n;
-            uint8_t *od = ord + b;
             Box node; box_empty(node);
-            for (uint32_t i = 0; i < n; i++) box_grow(node, bl[od[i]], bh[od[i]]);
+            for (uint32_t i = 0; i < n; i++) small_grow(node, L, lane, L.ord[b + i][lane]);
             for (int a = 0; a < 3; a++) { nlo[3 * (size_t)U.k + a] = node.lo[a]; nhi[3 * (size_t)U.k + a] = node.hi[a]; }
             uint32_t nl = n / 2; int best_axis = -1; double best_cost = INFINITY;
             if (n > 2 && U.depth < kSmallDepth && SR.depth + U.depth < kSahDepth) {
                 for (int a = 0; a < 3; a++) {
-                    small_sort(od, n, bl, bh, a);
-                    double right_area[kSmall];
+                    small_sort(L, lane, b, n, a);
                     Box acc; box_empty(acc);
-                    for (uint32_t i = n - 1; i > 0; i--) { box_grow(acc, bl[od[i]], bh[od[i]]); right_area[i] = half_area(acc); }
+                    for (uint32_t i = n - 1; i > 0; i--) { small_grow(acc, L, lane, L.ord[b + i][lane]); L.right_area[i][lane] = (float)half_area(acc); }
                     box_empty(acc);
                     for (uint32_t i = 1; i < n; i++) {   // i leaves on the left
-                        box_grow(acc, bl[od[i - 1]], bh[od[i - 1]]);
-                        const double cost = half_area(acc) * i + right_area[i] * (n - i);
+                        small_grow(acc, L, lane, L.ord[b + i - 1][lane]);
+                        const double cost = half_area(acc) * i + (double)L.right_area[i][lane] * (n - i);
                         if (cost < best_cost) { best_cost = cost; best_axis = a; nl = i; }
                     }
                 }
-                if (best_axis >= 0 && best_axis != 2) small_sort(od, n, bl, bh, best_axis);   // the sub-range is in z order now: once more on the winning axis
+                if (best_axis >= 0 && best_axis != 2) small_sort(L, lane, b, n, best_axis);   // the sub-range is in z order now: once more on the winning axis
             }
             const uint32_t nr = n - nl;
-            if (nl == 1) child[2 * (size_t)U.k] = ~(int32_t)leaf[od[0]];
+            if (nl == 1) child[2 * (size_t)U.k] = ~(int32_t)leaf[L.ord[b][lane]];
             else { child[2 * (size_t)U.k] = (int32_t)(U.k + 1); stack[sp++] = Sub{(uint8_t)b, (uint8_t)nl, (uint8_t)(U.depth + 1), U.k + 1}; }
-            if (nr == 1) child[2 * (size_t)U.k + 1] = ~(int32_t)leaf[od[nl]];
+            if (nr == 1) child[2 * (size_t)U.k + 1] = ~(int32_t)leaf[L.ord[b + nl][lane]];
             else { child[2 * (size_t)U.k + 1] = (int32_t)(U.k + nl); stack[sp++] = Sub{(uint8_t)(b + nl), (uint8_t)nr, (uint8_t)(U.depth + 1), U.k + nl}; }
         }
     }
 }
+#undef SBOX
 
 __global__ void k_sah_noop() {}
 } // namespace
