@@ -705,10 +705,18 @@ __global__ void k_build_noop() {}
 void build_prewarm(hipStream_t s) { k_build_noop<<<1, 1, 0, s>>>(); }
 
 void lbvh_free(Lbvh &l) {
-    hipFree(l.wide); hipFree(l.widef); hipFree(l.shade_tris);
-    hipFree(l.leaf_gid); hipFree(l.keys); hipFree(l.child); hipFree(l.node_lo); hipFree(l.node_hi); hipFree(l.leaf_lo); hipFree(l.leaf_hi);
-    hipFree(l.tris); hipFree(l.nodes); hipFree(l.tri_prim); hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi); hipFree(l.leaf_parent); hipFree(l.node_parent); hipFree(l.cbounds);
+    hipFree(l.wide); hipFree(l.widef); hipFree(l.leaf_parent); hipFree(l.node_parent);
+    if (l.trav_child != l.res_trav_child) { hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi); }   // (allocations of their own: no room was reserved)
+    hipFree(l.block);   // leaf_gid .. shade_tris, cbounds, res_trav_*
     l = Lbvh{};
+}
+hipError_t lbvh_claim_trav(Lbvh &l, uint32_t NI) {
+    if (l.trav_child) return hipSuccess;
+    if (l.res_trav_child) { l.trav_child = l.res_trav_child; l.trav_lo = l.res_trav_lo; l.trav_hi = l.res_trav_hi; return hipSuccess; }
+    hipError_t e = hipMalloc(&l.trav_child, (size_t)NI * 8);
+    if (e == hipSuccess) e = hipMalloc(&l.trav_lo, (size_t)NI * 12);
+    if (e == hipSuccess) e = hipMalloc(&l.trav_hi, (size_t)NI * 12);
+    return e;
 }
 
 hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node_boxes) {
@@ -733,13 +741,17 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
         cslots = A.take<uint32_t>(kCbSlots * 32); gid_in = A.take<uint32_t>(T); keys_in = A.take<uint64_t>(T);
         arrive = A.take<uint32_t>(NI); parent_int = A.take<int32_t>(NI); parent_leaf = A.take<int32_t>(T);
         tmp = A.take<char>(tmp_bytes ? tmp_bytes : 16);
-        HIPQ(hipMalloc(&out.cbounds, 32));
-        HIPQ(hipMalloc(&out.leaf_gid, (size_t)T * 4)); HIPQ(hipMalloc(&out.keys, (size_t)T * 8)); HIPQ(hipMalloc(&out.child, (size_t)NI * 8));
-        HIPQ(hipMalloc(&out.node_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&out.node_hi, (size_t)NI * 12));
-        HIPQ(hipMalloc(&out.leaf_lo, (size_t)T * 12)); HIPQ(hipMalloc(&out.leaf_hi, (size_t)T * 12));
-        HIPQ(hipMalloc(&out.tris, (size_t)T * sizeof(DevTri))); HIPQ(hipMalloc(&out.nodes, (size_t)NI * sizeof(DevNode)));
-        HIPQ(hipMalloc(&out.tri_prim, (size_t)T * 4));
-        HIPQ(hipMalloc(&out.shade_tris, (size_t)T * sizeof(DevShadeTri)));
+        {   // everything that outlives the build: one allocation (and room for the traversal tree some builder will make over these leaves)
+            const size_t sizes[15] = {(size_t)T * 4, (size_t)T * 8, (size_t)NI * 8, (size_t)NI * 12, (size_t)NI * 12, (size_t)T * 12, (size_t)T * 12, (size_t)T * sizeof(DevTri), (size_t)NI * sizeof(DevNode),
+                                      (size_t)T * 4, (size_t)T * sizeof(DevShadeTri), 32, (size_t)NI * 8, (size_t)NI * 12, (size_t)NI * 12};
+            size_t total = 0; for (size_t b : sizes) total += Arena::pad(b);
+            HIPQ(hipMalloc(&out.block, total));
+            char *p = out.block; auto cut = [&](size_t bytes) { char *q = p; p += Arena::pad(bytes); return q; };
+            out.leaf_gid = (uint32_t *)cut(sizes[0]); out.keys = (uint64_t *)cut(sizes[1]); out.child = (int32_t *)cut(sizes[2]); out.node_lo = (float *)cut(sizes[3]); out.node_hi = (float *)cut(sizes[4]);
+            out.leaf_lo = (float *)cut(sizes[5]); out.leaf_hi = (float *)cut(sizes[6]); out.tris = (DevTri *)cut(sizes[7]); out.nodes = (DevNode *)cut(sizes[8]); out.tri_prim = (uint32_t *)cut(sizes[9]);
+            out.shade_tris = (DevShadeTri *)cut(sizes[10]); out.cbounds = (uint32_t *)cut(sizes[11]);
+            out.res_trav_child = (int32_t *)cut(sizes[12]); out.res_trav_lo = (float *)cut(sizes[13]); out.res_trav_hi = (float *)cut(sizes[14]);
+        }
         k_cb_init<<<1, kCbSlots, 0, s>>>(cslots);
         HIPQ(hipMemsetAsync(arrive, 0, (size_t)NI * 4, s));
         const uint32_t B = 256, GT = (T + B - 1) / B;
@@ -884,7 +896,7 @@ hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out) {
         HIPQ(hipMalloc(&left_leaves, (size_t)NI * 4)); HIPQ(hipMalloc(&place, (size_t)NI * 4)); HIPQ(hipMalloc(&child_t, (size_t)NI * 8)); HIPQ(hipMalloc(&lo_t, (size_t)NI * 12)); HIPQ(hipMalloc(&hi_t, (size_t)NI * 12));
         HIPQ(hipMalloc(&nearest, (size_t)T * 4)); HIPQ(hipMalloc(&merge, (size_t)T * 4)); HIPQ(hipMalloc(&keep, (size_t)T * 4));
         HIPQ(hipMalloc(&merge_scan, (size_t)T * 4)); HIPQ(hipMalloc(&keep_scan, (size_t)T * 4)); HIPQ(hipMalloc(&st, sizeof(PlocState)));
-        if (!l.trav_child) { HIPQ(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPQ(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&l.trav_hi, (size_t)NI * 12)); }
+        HIPQ(lbvh_claim_trav(l, NI));
         HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, merge, merge_scan, 0u, T, rocprim::plus<uint32_t>(), s));
         HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
         HIPQ(hipMemcpyAsync(lo[0], l.leaf_lo, (size_t)T * 12, hipMemcpyDeviceToDevice, s));

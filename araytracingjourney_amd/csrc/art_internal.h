@@ -116,6 +116,9 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     uint32_t *node_parent;
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
+    char *block = nullptr;  // host: ONE allocation behind the arrays lbvh_build makes (leaf_gid .. shade_tris, cbounds) and room for the traversal tree's three (res_trav_*): two dozen
+                            // hipMalloc per build were 0.6-1 ms inside build_ms; lbvh_free frees the block, never its pieces
+    int32_t *res_trav_child = nullptr; float *res_trav_lo = nullptr, *res_trav_hi = nullptr;   // in the block, for whichever builder makes a traversal tree (trav_* stay null until one does)
     uint32_t *cbounds;      // [6] the bounds of the triangle-box centroids the Morton keys were made over, as order-preserving keys (lo xyz, hi xyz): the root domain of the SAH bins
 };
 // art_jpeg.hip: baseline JPEG -> RGB8 (channels 3) or R8 (1), row-major
@@ -147,6 +150,8 @@ void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide /*n
 hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s);
 struct TraceTune { uint32_t chunk, refill, blocks, leaf_batch; }; // overrides of the persistent per-ray tracer's presets (ArtTuning.trace_chunk / trace_refill / trace_blocks; 0 = the preset): they travel with every launch
 void lbvh_free(Lbvh &l);
+// the traversal tree's arrays: the room lbvh_build reserved for them, else allocations of their own (lbvh_free tells which by the block)
+hipError_t lbvh_claim_trav(Lbvh &l, uint32_t NI);
 
 // float32 -> unsigned small float (5 exponent bits, MB mantissa bits), round to nearest even; negatives -> 0, overflow -> +Inf
 template <int MB> __host__ __device__ inline uint32_t pack_ufloat(float f) {

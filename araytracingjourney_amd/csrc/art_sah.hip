@@ -251,9 +251,7 @@ hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s) {
     }
     auto t3 = now();
     HIPS(hipMemcpy(l.nodes, nodes.data(), (size_t)NI * sizeof(DevNode), hipMemcpyHostToDevice));
-    if (!l.trav_child) {
-        HIPS(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPS(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPS(hipMalloc(&l.trav_hi, (size_t)NI * 12));
-    }
+    HIPS(lbvh_claim_trav(l, NI));
     HIPS(hipMemcpy(l.trav_child, B.child.data(), (size_t)NI * 8, hipMemcpyHostToDevice));
     HIPS(hipMemcpy(l.trav_lo, B.nlo.data(), (size_t)NI * 12, hipMemcpyHostToDevice));
     HIPS(hipMemcpy(l.trav_hi, B.nhi.data(), (size_t)NI * 12, hipMemcpyHostToDevice));

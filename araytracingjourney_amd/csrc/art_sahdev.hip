@@ -427,7 +427,7 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
         bins = A.take<uint32_t>(n_slots * kAxes * kBins * 7); splits = A.take<Split>(max_ranges); small = A.take<SmallRange>(max_small);
         flags = A.take<uint32_t>(T); scan = A.take<uint32_t>(T); n_cnt = A.take<uint32_t>(16);   // n_cnt[0 / 1]: open ranges of this / the next level, [2]: small ranges
         tmp = A.take<char>(tmp_bytes ? tmp_bytes : 16);
-        if (!l.trav_child) { HIPQ(hipMalloc(&l.trav_child, (size_t)NI * 8)); HIPQ(hipMalloc(&l.trav_lo, (size_t)NI * 12)); HIPQ(hipMalloc(&l.trav_hi, (size_t)NI * 12)); }
+        HIPQ(lbvh_claim_trav(l, NI));
         HIPQ(hipStreamSynchronize(s)); t1 = now();
         const uint32_t gT = (T + kBlockB - 1) / kBlockB;
         auto blocks = [](size_t items, uint32_t per_block, uint32_t cap) { size_t b = (items + per_block - 1) / per_block; return (uint32_t)(b < 1 ? 1 : (b > cap ? cap : b)); };
