@@ -149,6 +149,8 @@ struct ArtContext {
     std::vector<uint32_t> h_first_tri; // first global triangle id of every primitive slot (ascending): gid -> (primitive, triangle) on the host
     Lbvh bvh{};
     Arena arena;              // the build phases' scratch, kept from build to build (art_internal.h)
+    std::vector<uint8_t> uploaded;   // which primitives' vertices / indices / texels are on the device, at the offsets a build over exactly this set computes (empty: nothing): a
+                              // build over the same set -- the rebuild behind the refit's cost rule, a change of tuning -- uploads only the primitive table
     uint32_t T = 0;
     // moving models (art_scene_set_model_matrix): versions of the structure, the primitive table as the next refit will upload it
     std::vector<AsVersion> as; uint32_t as_cur = 0; bool xform_dirty = false;
@@ -798,7 +800,7 @@ int32_t art_scene_add_primitive(ArtContext *c, const ArtVertex *verts, uint32_t 
     p.tw = tw; p.th = th;
     std::memcpy(p.o2w, model3x4, 48);
     affine_inverse(p.o2w, p.w2o);
-    c->prims.push_back(std::move(p));
+    c->prims.push_back(std::move(p)); c->uploaded.clear();
     c->built = false;
     if (out_id) *out_id = (uint32_t)c->prims.size() - 1;
     return ART_OK;
@@ -806,7 +808,7 @@ int32_t art_scene_add_primitive(ArtContext *c, const ArtVertex *verts, uint32_t 
 
 int32_t art_scene_clear(ArtContext *c) {
     if (!c) return fail(ART_E_INVALID, "art_scene_clear: null context");
-    c->prims.clear(); c->built = false;
+    c->prims.clear(); c->uploaded.clear(); c->built = false;
     return ART_OK;
 }
 
@@ -874,6 +876,10 @@ int32_t art_scene_build(ArtContext *c) {
     for (auto &p : c->prims) any = any || (p.enabled && p.n_indices >= 3);
     size_t nv = any ? 0 : 1, ib = any ? 0 : 16, nt = any ? 0 : 3; uint32_t T = 0;
     for (auto &p : c->prims) if (p.enabled) { nv += p.verts.size(); ib += (p.indices.size() + 15) & ~(size_t)15; nt += (size_t)3 * p.tw * p.th; }
+    std::vector<uint8_t> now_set(c->prims.size());
+    for (size_t k = 0; k < c->prims.size(); k++) now_set[k] = c->prims[k].enabled ? 1 : 0;
+    const bool resident = any && now_set == c->uploaded;   // the same primitives as the last upload, nothing added since: their data is where this build would put it
+    if (!resident) c->uploaded.clear();   // (an upload that fails half way leaves nothing to rely on)
     HIPC(c->d_verts.ensure(nv * 12)); HIPC(c->d_indices.ensure(ib)); HIPC(c->d_tex.ensure(nt));
     std::vector<DevPrim> dp(c->prims.size() + (any ? 0 : 1));
     std::vector<uint32_t> first(dp.size());
@@ -887,9 +893,11 @@ int32_t art_scene_build(ArtContext *c) {
         std::memcpy(d.o2w, p.o2w, 48); std::memcpy(d.w2o, p.w2o, 48);
         first[k] = T;
         if (!p.enabled) continue;
-        HIPC(hipMemcpy(c->d_verts.p + ov * 12, p.verts.data(), p.verts.size() * 48, hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(c->d_indices.p + oi, p.indices.data(), p.indices.size(), hipMemcpyHostToDevice));
-        HIPC(hipMemcpy(c->d_tex.p + ot, p.tex.data(), p.tex.size(), hipMemcpyHostToDevice));
+        if (!resident) {
+            HIPC(hipMemcpy(c->d_verts.p + ov * 12, p.verts.data(), p.verts.size() * 48, hipMemcpyHostToDevice));
+            HIPC(hipMemcpy(c->d_indices.p + oi, p.indices.data(), p.indices.size(), hipMemcpyHostToDevice));
+            HIPC(hipMemcpy(c->d_tex.p + ot, p.tex.data(), p.tex.size(), hipMemcpyHostToDevice));
+        }
         T += d.n_tri;
         ov += p.verts.size(); oi += (p.indices.size() + 15) & ~(size_t)15; ot += (size_t)3 * p.tw * p.th;
     }
@@ -907,6 +915,7 @@ int32_t art_scene_build(ArtContext *c) {
     HIPC(c->d_prims.ensure(dp.size())); HIPC(c->d_first_tri.ensure(first.size()));
     HIPC(hipMemcpy(c->d_prims.p, dp.data(), dp.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(c->d_first_tri.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+    c->uploaded = any ? now_set : std::vector<uint8_t>();
     c->h_first_tri = first;
     c->h_dev_prims = dp; c->masked_tris = 0;
     c->prim_moved.assign(dp.size(), 0);

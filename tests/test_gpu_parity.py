@@ -678,8 +678,10 @@ def test_device_sah_at_the_sizes_where_its_kernels_change(R, orc, n_tris):
     tuv, ids = r.query_closest(rays)
     assert np.array_equal(ids, rids) and np.array_equal(tuv.view(np.uint32)[:, :3], rtuv.view(np.uint32)[:, :3])
     assert (ids[:, 0] >= 0).sum() > 20
-    r.prepare_first_frame()                                                               # a second build in the same context: the arena is reused
+    r.prepare_first_frame()                                                               # a second build in the same context: the arena is reused, the scene's data is not uploaded again
     assert _check_traversal_tree(r, same_as_karras_allowed=True) == n_tris
+    tuv, ids = r.query_closest(rays)
+    assert np.array_equal(ids, rids) and np.array_equal(tuv.view(np.uint32)[:, :3], rtuv.view(np.uint32)[:, :3])
     r.close()
 
 
