@@ -11,7 +11,7 @@
 //   2 .. kSmall leaves:                 k_small   (once, after the levels) a thread per range: the whole subtree by the exact sweep
 // A child's binning domain comes from the parent's bins (no centroid pass below the root); the children's places in the next level's / the small ranges' lists
 // are handed out a batch of ranges at a time; the levels are launched four at a time between fences; all temporaries come from the context's arena.
-// Round 3b (profiles/README.md): 11.8 -> 4.0 ms for config 2's 262 816 triangles, 62.5 -> 11.4 ms for config 4's 2.8 M, at +0.8 % of the ray rate.  The levels had
+// Round 3b (profiles/README.md): 11.8 -> 3.3 ms for config 2's 262 816 triangles, 62.5 -> 11.1 ms for config 4's 2.8 M, at +0.8 % of the ray rate.  The levels had
 // been one leaf-by-leaf pass: 21 atomics a leaf for the bins and 6 for the centroid bounds, 48 of config 4's 62 ms; bins on ONE axis (the longest side: pbrt's
 // rule) cost config 4 8.5 % of its ray rate and were dropped.
 #include "art_internal.h"
