@@ -994,7 +994,12 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
         // one internal step for every lane standing on a node ...
         bool done = false;
         { uint64_t nm_ = __ballot(active && tr.cur >= 0); if (nm_) { TPROF(1, 1); TPROF(2, __popcll(nm_)); } }
-        if (active && tr.cur >= 0) {
+#ifndef ART_NODE_REPS
+#define ART_NODE_REPS 3   // node steps a lane may take per turn of the loop (the turn's ballots, refill test and branches are scalar work the wave pays per turn: config 5 19 000 -> 20 000 Mray/s at 3, 19 900 at 2, 19 000 at 6)
+#endif
+#pragma unroll
+        for (int rep_ = 0; rep_ < ART_NODE_REPS; rep_++)
+        if (active && !done && tr.cur >= 0) {
             if constexpr (WIDTH == 4) done = tr.step_internal(a.wide, lds, ovf);
             else done = tr.step_internal(a.nodes, lds, ovf);
         }
