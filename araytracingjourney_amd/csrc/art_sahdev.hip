@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t bin_slot(const Range &R) { return R.b / kMid
 __device__ __forceinline__ uint32_t fkey(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 __device__ __forceinline__ float centroid(const float *lo, const float *hi, uint32_t leaf, int a) { return 0.5f * lo[3 * (size_t)leaf + a] + 0.5f * hi[3 * (size_t)leaf + a]; }
-__device__ __forceinline__ int bin_of(float c, float c0, float sc) { int b = (int)((c - c0) * sc); return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b); }
+__device__ __forceinline__ int bin_of(float c, float c0, float sc) { return (int)fminf(fmaxf((c - c0) * sc, 0.0f), (float)(kBins - 1)); }   // (clamped as a float: the conversion of a NaN or of 1e30 is not defined)
 __device__ __forceinline__ int bin_in(const Range &R, int a, const float *lo, const float *hi, uint32_t leaf) { return R.hi[a] > R.lo[a] ? bin_of(centroid(lo, hi, leaf, a), R.lo[a], (float)kBins / (R.hi[a] - R.lo[a])) : 0; }   // a flat side: everything in bin 0, never chosen
 
 // bins: [slot][axis][bin][7] = lo xyz keys (initialised to ~0), hi xyz keys (0), count.  Only ranges of more than kMid leaves have bins in memory, and such ranges are
@@ -70,7 +70,7 @@ __device__ __forceinline__ void box_empty(Box &b) { for (int k = 0; k < 3; k++) 
 __device__ __forceinline__ void box_grow(Box &b, const uint32_t *w) { for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], fkey_inv(w[k])); b.hi[k] = fmaxf(b.hi[k], fkey_inv(w[3 + k])); } }
 __device__ __forceinline__ void box_grow(Box &b, const float *lo, const float *hi) { for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], lo[k]); b.hi[k] = fmaxf(b.hi[k], hi[k]); } }
 __device__ __forceinline__ double half_area(const Box &b) { double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2]; return dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
-// the axis a range is binned on and its domain: the longest side of its box (a flat box: c1 == c0, everything lands in bin 0 and the range is halved)
+// a range's domain (and, when only one axis is binned, which: the longest side); on a flat side everything lands in bin 0 and the side is never chosen
 __device__ __forceinline__ void set_domain(Range &R, const Box &b) {
     const float ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
     const int a = ex >= ey ? (ex >= ez ? 0 : 2) : (ey >= ez ? 1 : 2);
