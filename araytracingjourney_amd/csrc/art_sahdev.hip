@@ -37,7 +37,10 @@ constexpr uint32_t kBlockB = 256;
 #define ART_SAH_SMALL 16
 #endif
 constexpr uint32_t kSmall = ART_SAH_SMALL;    // a range of at most this many leaves is finished by one thread (k_small)
-constexpr uint32_t kMid = 4096;    // a range of at most this many leaves (and more than kSmall) is binned and split by one block in its LDS (k_mid); larger ones leaf by leaf (k_bin + k_choose)
+#ifndef ART_SAH_MID
+#define ART_SAH_MID 4096
+#endif
+constexpr uint32_t kMid = ART_SAH_MID;    // a range of at most this many leaves (and more than kSmall) is binned and split by one block in its LDS (k_mid); larger ones leaf by leaf (k_bin + k_choose)
 constexpr uint32_t kSmallDepth = 10; // ... whose exact sweep may chain at most this deep before it halves (a degenerate fan of 16 leaves would be 15 levels)
 
 #ifndef ART_SAH_AXES
