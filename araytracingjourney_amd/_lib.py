@@ -13,6 +13,7 @@ ART_FLAG_PACKED_TILES = 4  # sharded: the gather payload is the B10G11R11 colour
 ART_FLAG_DEVICE_TREE = 8  # the PREFER_FAST_TRACE tree by PLOC instead of the binned SAH (both built on the device)
 ART_FLAG_FIXED_WAVES = 16  # one wave per 8x8 block always (default: the adaptive wave plan of the fused frame)
 ART_FLAG_TILE_OUTPUT = 32  # compact tile buffer even for an unsharded frame (a one-rank art_mgpu job)
+ART_FLAG_DYNAMIC_SCENE = 64  # models will move / leave / re-enter: art_scene_build also makes the ring of structure versions (else the first moved frame does)
 ART_FLAG_FAST_BUILD = 2  # keep the LBVH topology in the traversal nodes (default: binned-SAH rebuild, PREFER_FAST_TRACE)
 
 
@@ -48,7 +49,7 @@ class ArtStats(C.Structure):
                 ("num_triangles", C.c_uint32), ("num_primitives", C.c_uint32), ("num_nodes", C.c_uint32), ("frame_launches", C.c_uint32),
                 ("build_ms", C.c_float), ("frame_ms", C.c_float), ("trace_primary_ms", C.c_float), ("shade_ms", C.c_float),
                 ("trace_shadow_ms", C.c_float), ("accumulate_ms", C.c_float), ("ao_ms", C.c_float), ("split_blocks", C.c_uint32),
-                ("refit_ms", C.c_float), ("refit_cost_ratio", C.c_float), ("refits", C.c_uint32), ("rebuilds", C.c_uint32)]
+                ("refit_ms", C.c_float), ("refit_cost_ratio", C.c_float), ("refits", C.c_uint32), ("rebuilds", C.c_uint32), ("first_move_ms", C.c_float), ("versions_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
@@ -63,7 +64,7 @@ class ArtGlbCopyInfo(C.Structure):
 class ArtTuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("frame_form", "tree_builder", "frame_waves", "packet_wide", "primary_walk", "shadow_walk", "ao_walk", "block_order", "fixed_waves",
                                           "split_fixed_steps", "split_min_steps")] + [("split_alpha", C.c_float)] + \
-               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder", "as_versions")] + [("refit_rebuild_ratio", C.c_float), ("trace_leaf_batch", C.c_uint32), ("beam_fat", C.c_float)]
+               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder", "as_versions")] + [("refit_rebuild_ratio", C.c_float), ("trace_leaf_batch", C.c_uint32), ("beam_fat", C.c_float), ("plan_moving_interval", C.c_uint32), ("refit_streams", C.c_uint32)]
 
 
 class ArtLayout(C.Structure):
@@ -161,6 +162,7 @@ PARITY_SYMBOLS = {
     "art_wait_external_event": (_I32, [_P, _P]),
     "art_trace_for_stream": (_I32, [_P, _P, _P]),
     "art_collect_timings": (_I32, [_P, _P, _P]),
+    "art_sample_wave_steps": (_I32, [_P, _P, _P, _U32, _P]),
     "art_read_color_tiles": (_I32, [_P, _P, _SZ]),
     "art_untile_gathered_strided": (_I32, [_P, _P, _U32, _U32, _P, _P]),
     "art_untile_gathered_frames": (_I32, [_P, _P, _U32, _U32, _U32, _P, _P]),

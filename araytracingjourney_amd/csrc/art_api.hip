@@ -2,6 +2,7 @@
 // Product code; gfx950 only; there is no CPU fallback anywhere in this file.
 #include "art_internal.h"
 #include <mutex>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -87,19 +88,26 @@ struct WavePlan {
     uint32_t fixed_steps = 0;          // ArtTuning.split_fixed_steps: a fixed target instead (tests, experiments)
     uint32_t in_flight = 1;            // min(frames in flight, hardware queues)
     std::vector<uint32_t> order;       // launch order of the 256-pixel blocks (setup_frame)
-    std::vector<uint8_t> level;        // per 8x8 block: 0 = one wave, 1 = four quadrant waves, 2 = sixteen cell waves
-    std::vector<uint2> items[2];       // host copies of the two device tables
+    // The plan is made ON THE DEVICE (k_plan, art_trace.hip) behind a sampled frame, on that frame's stream: every block's level lives there, the two tables alternate so that
+    // frames in flight keep theirs, and the host learns "a new table of n items" from eight pinned words once the event behind the launch has fired.  (Rounds 1-3: counts up, one
+    // host thread through 32 640 blocks, table down -- 0.3-0.9 ms inside an art_trace call now and then, ten frames' time; tools/camera_leg_probe.py, profiles/README.md round 4.)
     DevBuf<uint2> d_items[2]; uint32_t n_items[2] = {0, 0}; int cur = 0;
+    DevBuf<uint8_t> d_level, d_level_tmp; DevBuf<uint32_t> d_worst;
+    uint32_t *h_result = nullptr, *dh_result = nullptr;   // pinned: PlanArgs::result
+    uint32_t split1 = 0, split2 = 0;   // blocks the current table deals to four / sixteen waves
     hipEvent_t retire[2][kMaxFrames] = {}; bool retire_set[2] = {false, false}; // recorded on every frame stream when table i was left: it may be rewritten once they have all fired
-    uint32_t cap = 0;                  // items the cost buffers hold
-    uint32_t *h_cost = nullptr; size_t h_cost_n = 0; // pinned
-    hipEvent_t cost_ready = nullptr; bool pending = false; int pending_table = 0;
+    uint32_t cap = 0;                  // items a table (and the cost buffers) hold
+    hipEvent_t cost_ready = nullptr; bool pending = false; int pending_table = 0;   // behind the sampled frame's k_plan
+    hipStream_t plan_stream = nullptr; // k_plan runs here, behind the sampled frame's completion event: one workgroup for ~0.1 ms -- on the frame's own stream the slot's next frame stood behind it (5-10 % of a 20-frame burst)
     uint64_t next_sample = 0; uint32_t interval = 1;
+    uint64_t last_sample = 0;          // the frame that was sampled last
+    bool moved_since_poll = false;     // the view or the lights changed since the last plan came back: a new table is no reason to look again at once (the next one would differ too)
     uint32_t replans = 0;
     void release() {
-        d_items[0].release(); d_items[1].release();
-        if (h_cost) (void)hipHostFree(h_cost); h_cost = nullptr; h_cost_n = 0;
+        d_items[0].release(); d_items[1].release(); d_level.release(); d_level_tmp.release(); d_worst.release();
+        if (h_result) (void)hipHostFree(h_result); h_result = nullptr; dh_result = nullptr;
         if (cost_ready) (void)hipEventDestroy(cost_ready); cost_ready = nullptr;
+        if (plan_stream) { (void)hipStreamSynchronize(plan_stream); (void)hipStreamDestroy(plan_stream); } plan_stream = nullptr;
         for (int i = 0; i < 2; i++) for (uint32_t k = 0; k < kMaxFrames; k++) if (retire[i][k]) { (void)hipEventDestroy(retire[i][k]); retire[i][k] = nullptr; }
     }
 };
@@ -111,14 +119,15 @@ constexpr uint32_t kMaxAsVersions = 8;
 struct AsVersion {
     DevTri *tris = nullptr; DevNodeW *widef = nullptr; DevNode4 *wide = nullptr; DevPrim *prims = nullptr;
     bool owned = false;                  // version 0 aliases c->bvh.* and c->d_prims
-    DevPrim *h_prims = nullptr;          // pinned staging copy of the primitive table (the upload is a fully asynchronous copy on the frame's stream)
-    uint8_t *d_touched = nullptr, *h_touched = nullptr; // per primitive: moved since this version was written (device copy + pinned staging)
-    uint8_t *dirty = nullptr;            // per 4-wide node: a box below it changes in the refit under way; all zero between refits
+    // Pinned host memory the refit's kernels read and write IN PLACE (no copies in front of or behind the launches): the primitive table as of this refit, a byte per
+    // primitive (moved since this version was written), and the refit's result (cost sum, root half-area, start / end device stamps).  d*: the device's addresses of the same.
+    DevPrim *h_prims = nullptr, *dh_prims = nullptr; uint8_t *h_touched = nullptr, *dh_touched = nullptr; double *h_result = nullptr, *dh_result = nullptr;
+    uint32_t *mark = nullptr;            // per 4-wide node (art_build.hip k_retri): all zero between refits
+    double *acc = nullptr;               // 4 doubles of device scratch of the refit's last launch: zero between refits
     uint64_t used[kMaxFrameSlots] = {};  // frame number + 1 of the newest launch on each ring slot that read this version (0: none)
     bool aux[kMaxFrameSlots] = {};       // art_trace_ao / art_present ran behind that frame on the slot's stream
     hipEvent_t ready = nullptr; bool ready_known = true; uint32_t ready_slot = 0; // the refit that wrote it: recorded on ring slot ready_slot's stream
-    hipEvent_t t0 = nullptr, t1 = nullptr; bool timed = false;                     // that refit's device time
-    double *d_cost = nullptr, *h_cost = nullptr; hipEvent_t cost_ev = nullptr; bool cost_pending = false; // its surface-area cost, on its way to the host
+    bool result_pending = false;         // h_result is that refit's once `ready` has fired
     uint64_t epoch = 0;                  // which refit wrote it (0: the build)
 };
 
@@ -154,11 +163,15 @@ struct ArtContext {
     uint32_t T = 0;
     // moving models (art_scene_set_model_matrix): versions of the structure, the primitive table as the next refit will upload it
     std::vector<AsVersion> as; uint32_t as_cur = 0; bool xform_dirty = false;
+    // Refits run on streams of their own, one per ring slot (up to four): the refit in front of frame n of slot k then overlaps frame n - F, which still runs on that slot's
+    // stream, instead of queueing behind it -- the slot's chain is frame, frame, frame with the refits beside it, and the frame waits for its refit's event.  (On the frame's
+    // own stream a slot's cycle was refit + frame: a model moving every frame cost the ring a third of its depth, profiles/README.md round 4.)
+    hipStream_t refit_stream[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t n_refit_streams = 0;
     std::vector<DevPrim> h_dev_prims;          // host copy of d_prims (build order), matrices kept current
     std::vector<uint64_t> prim_moved;          // per primitive: the refit (as_epoch numbering) that first shows its latest move; 0: where the build put it
     int64_t masked_tris = 0;                   // triangles of primitives disabled since the build (still in the arrays, written "nowhere")
     uint64_t as_epoch = 0, binary_epoch = 0;   // refits so far; the refit the binary trees / node records reflect
-    double as_cost0 = 0.0; float refit_cost_ratio = 1.0f; uint32_t refits = 0, rebuilds = 0; float last_refit_ms = 0.f;
+    double as_cost0 = 0.0; float refit_cost_ratio = 1.0f; uint32_t refits = 0, rebuilds = 0; float last_refit_ms = 0.f, first_move_ms = 0.f, versions_ms = 0.f;
     ArtCamera camera{};
     uint32_t B = 1, read_b = 0;       // frames per launch of the fused frame (art_set_frames_per_launch); which of them the read / device-pointer calls refer to
     ArtCamera cam_more[kMaxBatch - 1] = {}; // cameras of frames 1.. of a launch (frame 0: camera)
@@ -176,6 +189,7 @@ struct ArtContext {
     uint64_t frame_no = 0, collected_upto = 0;
     hipEvent_t mark[2] = {nullptr, nullptr};   // art_timestamp_mark
     bool traced = false;
+    bool force_sample = false; // art_sample_wave_steps: the next fused frame counts its waves' steps whatever the plan's cadence
     bool graph_mode = false; // replay a captured hipGraph per slot instead of 5 launches + 6 event records (host-bound multi-GPU runs)
     uint32_t ao_spp = 0;
     ArtStats stats{};
@@ -249,6 +263,8 @@ int32_t ensure_wide(ArtContext *c, bool needed) {
 }
 
 int32_t sync_all(ArtContext *c) {
+    for (uint32_t i = 0; i < c->n_refit_streams; i++) HIPC(hipStreamSynchronize(c->refit_stream[i]));   // (a refit no frame has waited for yet)
+    if (c->plan.plan_stream && c->plan.pending) { for (uint32_t k = 0; k < c->F; k++) HIPC(hipStreamSynchronize(c->stream_of(k))); HIPC(hipStreamSynchronize(c->plan.plan_stream)); }   // (a plan behind a sampled frame)
     for (uint32_t k = 0; k < c->F; k++) HIPC(hipStreamSynchronize(c->stream_of(k)));
     return ART_OK;
 }
@@ -267,10 +283,9 @@ void as_release(ArtContext *c) {
         if (V.owned) { (void)hipFree(V.tris); (void)hipFree(V.widef); (void)hipFree(V.wide); (void)hipFree(V.prims); }
         if (V.h_prims) (void)hipHostFree(V.h_prims);
         if (V.h_touched) (void)hipHostFree(V.h_touched);
-        (void)hipFree(V.d_touched); (void)hipFree(V.dirty);
-        if (V.h_cost) (void)hipHostFree(V.h_cost);
-        (void)hipFree(V.d_cost);
-        for (hipEvent_t e : {V.ready, V.t0, V.t1, V.cost_ev}) if (e) (void)hipEventDestroy(e);
+        if (V.h_result) (void)hipHostFree(V.h_result);
+        (void)hipFree(V.mark); (void)hipFree(V.acc);
+        if (V.ready) (void)hipEventDestroy(V.ready);
     }
     c->as.clear(); c->as_cur = 0;
 }
@@ -280,57 +295,74 @@ void as_release(ArtContext *c) {
 int32_t as_create(ArtContext *c) {
     int32_t r = ensure_wide(c, true); if (r) return r;
     r = sync_all(c); if (r) return r;
-    const uint32_t K = c->tuning.as_versions ? std::min(c->tuning.as_versions, kMaxAsVersions) : 4u;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // (default: one more than the frames in flight, 4 at least and 8 at most -- with fewer versions than ring slots the host stands waiting for frame n - K in front of every refit)
+    const uint32_t K = c->tuning.as_versions ? std::min(c->tuning.as_versions, kMaxAsVersions) : std::min(std::max(c->F + 1u, 4u), kMaxAsVersions);
     const size_t np = c->h_dev_prims.size(), T = c->T, NW = c->bvh.n_wide;
     c->as.assign(K, AsVersion{});
+    hipStream_t s = c->main_stream();
     auto body = [&]() -> int32_t {
+        const uint32_t want = c->tuning.refit_streams == 0xFFFFFFFFu ? 0u : (c->tuning.refit_streams ? std::min(c->tuning.refit_streams, 4u) : std::min(c->F, 4u));
+        while (c->n_refit_streams < want) {   // (kept for the life of the context)
+            int lo = 0, hi = 0; HIPC(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi: the numerically smallest = the most urgent: a refit is a handful of small launches a whole frame waits for
+            HIPC(hipStreamCreateWithPriority(&c->refit_stream[c->n_refit_streams], hipStreamNonBlocking, hi)); c->n_refit_streams++;
+        }
+        while (c->n_refit_streams > want) { c->n_refit_streams--; (void)hipStreamSynchronize(c->refit_stream[c->n_refit_streams]); (void)hipStreamDestroy(c->refit_stream[c->n_refit_streams]); c->refit_stream[c->n_refit_streams] = nullptr; }
         if (!c->bvh.leaf_parent) { // who holds whom in the 4-wide tree: the marks of a refit go up along it
             HIPC(hipMalloc(&c->bvh.leaf_parent, T * 4)); HIPC(hipMalloc(&c->bvh.node_parent, NW * 4));
-            launch_wide_parents(c->bvh.n_wide, c->bvh.widef, c->bvh.leaf_parent, c->bvh.node_parent, c->main_stream());
+            launch_wide_parents(c->bvh.n_wide, c->bvh.widef, c->bvh.leaf_parent, c->bvh.node_parent, s);
             HIPC(hipGetLastError());
+            hipError_t e = refit_lists_build(c->bvh, c->T, s);   // the refit's work lists (a workgroup per batch of subtrees)
+            if (e != hipSuccess) return hipfail(e, "refit_lists_build");
         }
-        for (uint32_t v = 0; v < K; v++) {
+        for (uint32_t v = 0; v < K; v++) { // (everything on the context's first stream, asynchronously: one wait at the end)
             AsVersion &V = c->as[v];
             if (v == 0) { V.tris = c->bvh.tris; V.widef = c->bvh.widef; V.wide = c->bvh.wide; V.prims = c->d_prims.p; }
             else {
                 V.owned = true;
                 HIPC(hipMalloc(&V.tris, T * sizeof(DevTri))); HIPC(hipMalloc(&V.widef, NW * sizeof(DevNodeW))); HIPC(hipMalloc(&V.wide, NW * sizeof(DevNode4))); HIPC(hipMalloc(&V.prims, np * sizeof(DevPrim)));
-                HIPC(hipMemcpy(V.tris, c->bvh.tris, T * sizeof(DevTri), hipMemcpyDeviceToDevice)); HIPC(hipMemcpy(V.widef, c->bvh.widef, NW * sizeof(DevNodeW), hipMemcpyDeviceToDevice));
-                HIPC(hipMemcpy(V.wide, c->bvh.wide, NW * sizeof(DevNode4), hipMemcpyDeviceToDevice)); HIPC(hipMemcpy(V.prims, c->d_prims.p, np * sizeof(DevPrim), hipMemcpyDeviceToDevice));
+                HIPC(hipMemcpyAsync(V.tris, c->bvh.tris, T * sizeof(DevTri), hipMemcpyDeviceToDevice, s)); HIPC(hipMemcpyAsync(V.widef, c->bvh.widef, NW * sizeof(DevNodeW), hipMemcpyDeviceToDevice, s));
+                HIPC(hipMemcpyAsync(V.wide, c->bvh.wide, NW * sizeof(DevNode4), hipMemcpyDeviceToDevice, s)); HIPC(hipMemcpyAsync(V.prims, c->d_prims.p, np * sizeof(DevPrim), hipMemcpyDeviceToDevice, s));
             }
-            HIPC(hipHostMalloc((void **)&V.h_prims, np * sizeof(DevPrim), hipHostMallocDefault)); HIPC(hipHostMalloc((void **)&V.h_cost, 16, hipHostMallocDefault)); HIPC(hipMalloc(&V.d_cost, 16));
-            HIPC(hipHostMalloc((void **)&V.h_touched, np, hipHostMallocDefault)); HIPC(hipMalloc(&V.d_touched, np)); HIPC(hipMalloc(&V.dirty, NW)); HIPC(hipMemset(V.dirty, 0, NW));
-            HIPC(hipEventCreateWithFlags(&V.ready, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&V.cost_ev, hipEventDisableTiming));
-            HIPC(hipEventCreate(&V.t0)); HIPC(hipEventCreate(&V.t1));
+            HIPC(hipHostMalloc((void **)&V.h_prims, np * sizeof(DevPrim), hipHostMallocDefault)); HIPC(hipHostMalloc((void **)&V.h_touched, np, hipHostMallocDefault)); HIPC(hipHostMalloc((void **)&V.h_result, 32, hipHostMallocDefault));
+            HIPC(hipHostGetDevicePointer((void **)&V.dh_prims, V.h_prims, 0)); HIPC(hipHostGetDevicePointer((void **)&V.dh_touched, V.h_touched, 0)); HIPC(hipHostGetDevicePointer((void **)&V.dh_result, V.h_result, 0));
+            HIPC(hipMalloc(&V.mark, NW * 4)); HIPC(hipMemsetAsync(V.mark, 0, NW * 4, s)); HIPC(hipMalloc(&V.acc, 32)); HIPC(hipMemsetAsync(V.acc, 0, 32, s));
+            HIPC(hipEventCreateWithFlags(&V.ready, hipEventDisableTiming));
         }
         AsVersion &V0 = c->as[0];
-        launch_wide_cost(c->bvh.n_wide, V0.widef, nullptr, V0.d_cost, c->main_stream());
-        HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(c->main_stream()));
-        double h[2] = {0, 0};
-        HIPC(hipMemcpy(h, V0.d_cost, 16, hipMemcpyDeviceToHost));
-        c->as_cost0 = h[0]; c->refit_cost_ratio = 1.0f;
-        HIPC(hipDeviceSynchronize()); // (the copies above ran on the null stream; the frame streams are non-blocking)
+        launch_wide_cost(c->bvh.n_wide, V0.widef, nullptr, V0.acc, V0.dh_result, s);   // the cost of the tree as built
+        HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(s));
+        c->as_cost0 = V0.h_result[0]; c->refit_cost_ratio = 1.0f;
         return ART_OK;
     };
     r = body();
     if (r) as_release(c);
+    c->versions_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return r;
 }
 // the surface-area cost of the latest refit travels to the host behind it; once it has arrived it is what ArtStats.refit_cost_ratio and the rebuild rule go by
 void harvest_cost(ArtContext *c) {
     if (c->as.empty()) return;
     AsVersion &L = c->as[c->as_cur];
-    if (!L.cost_pending || hipEventQuery(L.cost_ev) != hipSuccess) return;
-    L.cost_pending = false;
-    if (c->as_cost0 > 0.0) c->refit_cost_ratio = (float)(L.h_cost[0] / c->as_cost0);
+    if (!L.result_pending || hipEventQuery(L.ready) != hipSuccess) return;
+    L.result_pending = false; L.ready_known = true;
+    if (c->as_cost0 > 0.0) c->refit_cost_ratio = (float)(L.h_result[0] / c->as_cost0);
+    const unsigned long long *st = reinterpret_cast<const unsigned long long *>(L.h_result);
+    c->last_refit_ms = (float)((double)(st[3] - st[2]) * 1e-5);   // wall_clock64: 100 MHz
 }
 // A model moved since the last launch: bring the NEXT version of the structure up to date on stream s, the stream of ring slot k whose frame is about to be
 // launched -- the frame is ordered behind the refit by the stream, frames on other streams by V.ready (art_trace).  Frames still reading the version about to be
 // written are waited for on the host, like the reference's per-frame fence (renderer.rs:451-466).
+// What the stream sees: three launches and one event record (round 3: two uploads, a launch per tree level, a clear, the cost's read-back and four event records --
+// twenty operations, 0.3 ms of issue in front of a 0.1 ms refit).
 int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
     if (!c->xform_dirty) return ART_OK;
     int32_t r;
-    if (c->as.empty()) { r = as_create(c); if (r) return r; }
+    if (c->as.empty()) { // (a host that announced its moves with ART_FLAG_DYNAMIC_SCENE paid this in art_scene_build)
+        const auto t_begin = std::chrono::steady_clock::now();
+        r = as_create(c); if (r) return r;
+        c->first_move_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
     {   // the cost of the latest refit, if it has arrived: past the threshold the tree is built again for where the models are now
         harvest_cost(c);
         const float thr = c->tuning.refit_rebuild_ratio > 0.0f ? c->tuning.refit_rebuild_ratio : (c->tuning.refit_rebuild_ratio < 0.0f ? INFINITY : 2.0f);
@@ -343,8 +375,10 @@ int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
     }
     const uint32_t K = (uint32_t)c->as.size(), next = (c->as_cur + 1) % K;
     AsVersion &V = c->as[next];
+    const bool beside = c->n_refit_streams != 0;   // the refit runs beside the slot's frames, on a stream of its own
+    if (beside) s = c->refit_stream[k % c->n_refit_streams];
     for (uint32_t j = 0; j < c->F; j++) {
-        if (j != k) { // (ring slot k's earlier work is ordered before the refit by its stream)
+        if (j != k || beside) { // (on the frame's own stream ring slot k's earlier work is ordered before the refit by that stream)
             if (V.aux[j]) HIPC(hipStreamSynchronize(c->stream_of(j)));
             else if (V.used[j]) {
                 const uint64_t f = V.used[j] - 1;
@@ -353,20 +387,20 @@ int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
         }
         V.used[j] = 0; V.aux[j] = false;
     }
-    if (V.cost_pending) { HIPC(hipEventSynchronize(V.cost_ev)); V.cost_pending = false; }
+    // the staging memory below is read by the kernels of the refit that wrote this version last: that refit has to be over before the host writes it again (it is, whenever the
+    // frames above were waited for -- they ran behind it -- but nothing else says so: a version no frame ever read, a ring slot that skipped its turn)
+    if (!V.ready_known) { HIPC(hipEventSynchronize(V.ready)); V.ready_known = true; }
+    V.result_pending = false;
     if (c->graph_mode) drop_graphs(c); // a captured frame holds the old version's pointers
     const size_t np = c->h_dev_prims.size();
     std::memcpy(V.h_prims, c->h_dev_prims.data(), np * sizeof(DevPrim));
     for (size_t p = 0; p < np; p++) V.h_touched[p] = (p < c->prim_moved.size() && c->prim_moved[p] > V.epoch) ? 1 : 0;   // what moved since THIS version was written (it may be several refits behind)
-    HIPC(hipEventRecord(V.t0, s));
-    HIPC(hipMemcpyAsync(V.prims, V.h_prims, np * sizeof(DevPrim), hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpyAsync(V.d_touched, V.h_touched, np, hipMemcpyHostToDevice, s));
-    launch_retri(c->T, c->bvh.shade_tris, V.prims, V.d_touched, c->bvh.leaf_parent, V.dirty, V.tris, s);
-    launch_wide_refit(c->bvh.wide_levels, V.tris, V.wide, V.widef, c->bvh.node_parent, V.dirty, V.d_cost, s);
-    HIPC(hipEventRecord(V.t1, s)); V.timed = true;
-    HIPC(hipMemcpyAsync(V.h_cost, V.d_cost, 16, hipMemcpyDeviceToHost, s));
-    HIPC(hipEventRecord(V.cost_ev, s)); V.cost_pending = true;
-    HIPC(hipEventRecord(V.ready, s)); V.ready_known = false; V.ready_slot = k;
+    RefitArgs ra{};
+    ra.T = c->T; ra.n_wide = c->bvh.n_wide; ra.n_prims = (uint32_t)np; ra.shade = c->bvh.shade_tris; ra.prims_host = V.dh_prims; ra.prims_dev = V.prims; ra.touched = V.dh_touched;
+    ra.sub_nodes = c->bvh.sub_nodes; ra.sub_leaves = c->bvh.sub_leaves; ra.sub_off = c->bvh.sub_off; ra.sub_batches = c->bvh.sub_batches; ra.sub_levels = c->bvh.sub_levels;
+    ra.leaf_parent = c->bvh.leaf_parent; ra.node_parent = c->bvh.node_parent; ra.mark = V.mark; ra.tris = V.tris; ra.wide = V.wide; ra.widef = V.widef; ra.acc = V.acc; ra.result = V.dh_result;
+    launch_refit(ra, s);
+    HIPC(hipEventRecord(V.ready, s)); V.ready_known = false; V.ready_slot = beside ? ~0u : k; V.result_pending = true;   // (~0: no frame stream is behind it by itself)
     HIPC(hipGetLastError());
     c->as_cur = next; V.epoch = ++c->as_epoch; c->xform_dirty = false; c->refits++;
     return ART_OK;
@@ -376,7 +410,7 @@ int32_t refresh_now(ArtContext *c) {
     int32_t r = sync_all(c); if (r) return r;
     if (!c->xform_dirty) return ART_OK;
     r = scene_refresh(c, 0, c->stream_of(0)); if (r) return r;
-    HIPC(hipStreamSynchronize(c->stream_of(0)));
+    r = sync_all(c); if (r) return r;   // (the refit may have run on a stream of its own)
     if (!c->as.empty()) c->as[c->as_cur].ready_known = true;
     return ART_OK;
 }
@@ -394,18 +428,12 @@ int32_t ensure_binary(ArtContext *c, bool needed) {
 
 
 // ---- wave plan of the fused frame ----------------------------------------------------------------------------------------------------
-static void plan_build_items(const WavePlan &P, const std::vector<uint32_t> &cost_of_block, std::vector<uint2> &out) {
+// the first table of a frame layout: every 8x8 block one wave, in the XCD-aware launch order (k_plan writes the later ones in the same layout)
+static void plan_first_items(const WavePlan &P, uint32_t n64, std::vector<uint2> &out) {
     out.clear();
-    std::vector<std::pair<uint32_t, uint32_t>> heavy; // (cost, block), split blocks
-    for (uint32_t b = 0; b < P.level.size(); b++) if (P.level[b]) heavy.push_back({cost_of_block.empty() ? 0u : cost_of_block[b], b});
-    std::stable_sort(heavy.begin(), heavy.end(), [](const std::pair<uint32_t, uint32_t> &x, const std::pair<uint32_t, uint32_t> &y) { return x.first > y.first; });
-    for (const auto &h : heavy) { // the long poles start first
-        if (P.level[h.second] == 1) { static const uint32_t quad[4] = {0x0033u, 0x00CCu, 0x3300u, 0xCC00u}; for (uint32_t q : quad) out.push_back(make_uint2(h.second, q)); }
-        else for (uint32_t cell = 0; cell < 16; cell++) out.push_back(make_uint2(h.second, 1u << cell));
-    }
-    while (out.size() & 3u) out.push_back(make_uint2(0, 0)); // whole workgroups: the blocks after them keep their place in a workgroup
     for (uint32_t blk : P.order)
-        for (uint32_t w = 0; w < 4; w++) { uint32_t b = blk * 4 + w; out.push_back(make_uint2(b, P.level[b] ? 0u : 0xFFFFu)); } // a split block leaves an idle wave behind: the XCD order of the rest is untouched
+        for (uint32_t w = 0; w < 4; w++) out.push_back(make_uint2(blk * 4 + w, 0xFFFFu));
+    (void)n64;
     // k_frame runs one wave per workgroup, and workgroup j lands on XCD j % 8 (round-robin dispatch): deal the items so that the four waves of launch
     // block 8g + x (a 256-pixel block the XCD-aware order gave to XCD x) stay on XCD x -- positions 32g + 8k + x, k = 0..3.  A permutation whatever the
     // hardware does; only the L2 locality depends on it.
@@ -424,83 +452,81 @@ static int32_t plan_reset(ArtContext *c) {
     const uint32_t hwq = t.hw_queues ? t.hw_queues : 4;   // HIP's default number of hardware queues per process; a host that raises GPU_MAX_HW_QUEUES says so in ArtTuning
     P.in_flight = std::max(1u, std::min(c->F, hwq));
     const uint32_t n64 = c->n_local / 64;
-    P.level.assign(n64, 0);
     P.cap = n64 + n64 / 2 + 64;       // at most half as many waves again
-    plan_build_items(P, {}, P.items[0]);
-    P.items[1].clear();
+    std::vector<uint2> first;
+    plan_first_items(P, n64, first);
     for (int i = 0; i < 2; i++) { HIPC(P.d_items[i].ensure(P.cap)); P.n_items[i] = 0; P.retire_set[i] = false; }
-    if (!P.items[0].empty()) HIPC(hipMemcpy(P.d_items[0].p, P.items[0].data(), P.items[0].size() * sizeof(uint2), hipMemcpyHostToDevice));
-    P.n_items[0] = (uint32_t)P.items[0].size(); P.cur = 0;
-    if (P.h_cost_n < P.cap) { if (P.h_cost) (void)hipHostFree(P.h_cost); P.h_cost = nullptr; HIPC(hipHostMalloc((void **)&P.h_cost, (size_t)P.cap * 4, hipHostMallocDefault)); P.h_cost_n = P.cap; }
+    if (!first.empty()) HIPC(hipMemcpy(P.d_items[0].p, first.data(), first.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    P.n_items[0] = (uint32_t)first.size(); P.cur = 0; P.split1 = P.split2 = 0;
+    HIPC(P.d_level.ensure(n64 ? n64 : 1)); HIPC(P.d_level_tmp.ensure(n64 ? n64 : 1)); HIPC(P.d_worst.ensure(n64 ? n64 : 1));
+    HIPC(hipMemset(P.d_level.p, 0, n64 ? n64 : 1)); HIPC(hipMemset(P.d_worst.p, 0, (size_t)(n64 ? n64 : 1) * 4));
+    if (!P.h_result) { HIPC(hipHostMalloc((void **)&P.h_result, 32, hipHostMallocDefault)); HIPC(hipHostGetDevicePointer((void **)&P.dh_result, P.h_result, 0)); }
+    std::memset(P.h_result, 0, 32);
     if (!P.cost_ready) HIPC(hipEventCreateWithFlags(&P.cost_ready, hipEventDisableTiming));
-    P.pending = false; P.next_sample = c->frame_no; P.interval = 1; P.replans = 0;
+    if (!P.plan_stream) { int lo = 0, hi = 0; HIPC(hipDeviceGetStreamPriorityRange(&lo, &hi)); HIPC(hipStreamCreateWithPriority(&P.plan_stream, hipStreamNonBlocking, lo)); }   // (the least urgent: nothing waits for it)
+    else HIPC(hipStreamSynchronize(P.plan_stream));
+    P.pending = false; P.next_sample = c->frame_no; P.interval = 1; P.replans = 0; P.last_sample = c->frame_no;
     return ART_OK;
 }
-// A sampled frame's wave times have arrived: decide every block's level, and if anything changed write the other table and switch to it.
+// the table the current one alternates with: free once every launch that read it has finished (the events recorded on all frame streams when it was left)
+static bool plan_other_free(ArtContext *c) {
+    WavePlan &P = c->plan;
+    const int other = P.cur ^ 1;
+    if (!P.retire_set[other]) return true;
+    for (uint32_t k = 0; k < c->F; k++) if (hipEventQuery(P.retire[other][k]) != hipSuccess) return false;
+    return true;
+}
+// behind a sampled frame, on its stream: the next plan from what its waves counted (k_plan writes the other table if a level changed that matters)
+static int32_t plan_launch(ArtContext *c, const FrameArgs &a, hipEvent_t frame_done) {
+    WavePlan &P = c->plan;
+    hipStream_t s = P.plan_stream;
+    HIPC(hipStreamWaitEvent(s, frame_done, 0));   // (a wait in the PLAN's stream: the frames' streams see nothing of it)
+    PlanArgs pa{};
+    pa.items_in = P.d_items[P.cur].p; pa.n_items_in = a.n_wave_items; pa.cost = a.wave_cost;
+    pa.level = P.d_level.p; pa.level_tmp = P.d_level_tmp.p; pa.n64 = c->n_local / 64; pa.worst = P.d_worst.p;
+    pa.order = c->d_block_order.p; pa.n256 = c->n_local / 256;
+    pa.items_out = P.d_items[P.cur ^ 1].p; pa.cap = P.cap;
+    constexpr float kWaveSlots = 256.0f * 32.0f; // CUs x waves per CU
+    pa.share = P.alpha * (float)c->B * (float)P.in_flight / kWaveSlots;   // (the counts are one frame's; a launch traces B frames)
+    pa.min_steps = P.min_steps; pa.fixed_steps = P.fixed_steps; pa.result = P.dh_result;
+    launch_plan(pa, s);
+    HIPC(hipEventRecord(P.cost_ready, s));
+    P.pending = true; P.pending_table = P.cur; P.last_sample = c->frame_no;
+    return ART_OK;
+}
+// The view or the lights changed: the heavy blocks are elsewhere, sooner or later.  The plan in use stays (a camera that moves like the reference's -- 0.002 units per
+// millisecond, main.rs:80-105 -- shifts them by a fraction of a pixel a frame) and the waves are looked at again within kMovingInterval frames of the last look: a camera
+// that moves every frame is sampled at that cadence, not at every frame (round 3 reset the interval to 1 here: every frame that found no sample in flight was a counting
+// frame and every other poll a new table).
+constexpr uint32_t kMovingInterval = 32;
+static uint32_t plan_moving_interval(const ArtContext *c) { return c->tuning.plan_moving_interval ? c->tuning.plan_moving_interval : kMovingInterval; }
+static void plan_hint_moved(ArtContext *c) {
+    WavePlan &P = c->plan;
+    const uint32_t mi = plan_moving_interval(c);
+    P.interval = std::min(P.interval, mi);
+    P.next_sample = std::min<uint64_t>(P.next_sample, P.last_sample + mi);
+    P.moved_since_poll = true;
+}
+
+// A sampled frame's plan has been made: if it wrote a new table, that one becomes the current one (the table being left stays in use until every frame stream has passed this point).
 static int32_t plan_poll(ArtContext *c) {
     WavePlan &P = c->plan;
     if (!P.pending || hipEventQuery(P.cost_ready) != hipSuccess) return ART_OK;
     P.pending = false;
-    const std::vector<uint2> &items = P.items[P.pending_table];
-    std::vector<uint32_t> worst(P.level.size(), 0); // slowest wave of each block in the sampled frame
-    for (size_t i = 0; i < items.size(); i++) if (items[i].y) worst[items[i].x] = std::max(worst[items[i].x], P.h_cost[i]);
-    uint64_t sum = 0;
-    for (size_t i = 0; i < items.size(); i++) if (items[i].y) sum += P.h_cost[i];
-    constexpr double kWaveSlots = 256.0 * 32.0; // CUs x waves per CU
-    uint32_t T = P.fixed_steps ? P.fixed_steps : std::max(P.min_steps, (uint32_t)(P.alpha * (double)sum * c->B * P.in_flight / kWaveSlots)); // sum: one frame's steps; a launch traces B frames
-    std::vector<uint8_t> next;
-    std::vector<uint32_t> est(P.level.size(), 0);
-    for (int attempt = 0; attempt < 8; attempt++, T += T / 2) {
-        next = P.level;
-        size_t extra = 0;
-        for (size_t b = 0; b < next.size(); b++) {
-            const uint32_t w = worst[b];
-            uint8_t lv = P.level[b];
-            // going down needs a clear margin (the parts of a split block share the top of their walks: n parts cost less than n times one part)
-            if (lv == 0) lv = w > 4 * T ? 2 : w > T ? 1 : 0;
-            else if (lv == 1) lv = w > T ? 2 : (w * 4 < T / 2 ? 0 : 1);
-            else lv = w * 4 < T / 2 ? 1 : 2;
-            next[b] = lv;
-            est[b] = P.level[b] == 0 ? w : P.level[b] == 1 ? w * 4 : w * 16;
-            extra += lv == 1 ? 4 : lv == 2 ? 16 : 0;
-        }
-        if (P.level.size() + (P.level.size() & 3u) + extra + 4 <= P.cap) break;
-        next = P.level; // does not fit: a more tolerant target
-    }
-    const bool changed = next != P.level;
+    const uint32_t *res = P.h_result;
     const int verbose = (c->tuning.log & 4u) ? 2 : ((c->tuning.log & 2u) ? 1 : 0);
-    if (verbose > 1) {
-        size_t d = 0; uint32_t mx = 0;
-        for (size_t b = 0; b < next.size(); b++) { d += next[b] != P.level[b]; mx = std::max(mx, worst[b]); }
-        std::fprintf(stderr, "[art] plan poll at frame %llu: table %d sampled, %zu blocks would change, slowest wave %u steps, target %u, interval %u\n", (unsigned long long)c->frame_no, P.pending_table, d, mx, T, P.interval);
-    }
-    if (changed) {
-        const int other = P.cur ^ 1;
-        if (P.retire_set[other]) { // every launch that used that table must have finished: the events recorded on all frame streams when it was left
-            bool done = true;
-            for (uint32_t k = 0; k < c->F && done; k++) done = hipEventQuery(P.retire[other][k]) == hipSuccess;
-            if (!done) { if (verbose > 1) std::fprintf(stderr, "[art] plan poll: the other table is still in use\n"); P.next_sample = c->frame_no + 2 * c->F; return ART_OK; } // ask again later, with a fresh sample
-        }
-        P.level = next;
-        plan_build_items(P, est, P.items[other]);
-        HIPC(hipMemcpy(P.d_items[other].p, P.items[other].data(), P.items[other].size() * sizeof(uint2), hipMemcpyHostToDevice));
-        P.n_items[other] = (uint32_t)P.items[other].size();
-        for (uint32_t k = 0; k < c->F; k++) { // the table being left: in use until every frame stream has passed this point
+    if (verbose > 1) std::fprintf(stderr, "[art] plan poll at frame %llu: table %d sampled, %s, slowest wave %u steps, target %u, interval %u\n", (unsigned long long)c->frame_no, P.pending_table, res[1] ? "a new table" : "the table stays", res[5], res[4], P.interval);
+    if (res[1]) {
+        for (uint32_t k = 0; k < c->F; k++) {
             if (!P.retire[P.cur][k]) HIPC(hipEventCreateWithFlags(&P.retire[P.cur][k], hipEventDisableTiming));
             HIPC(hipEventRecord(P.retire[P.cur][k], c->stream_of(k)));
         }
         P.retire_set[P.cur] = true;
-        P.cur = other; P.replans++;
-        if (verbose) {
-            size_t n1 = 0, n2 = 0;
-            for (size_t b = 0; b < P.level.size(); b++) { n1 += P.level[b] == 1; n2 += P.level[b] == 2; }
-            std::vector<uint32_t> w(worst); std::sort(w.begin(), w.end());
-            auto pc = [&](double q) { return w.empty() ? 0u : w[(size_t)(q * (w.size() - 1))]; };
-            std::fprintf(stderr, "[art] wave plan %u at frame %llu: %zu blocks in 4, %zu in 16, of %zu; steps of the sampled waves p50 %u p90 %u p99 %u max %u, target %u\n", P.replans,
-                         (unsigned long long)c->frame_no, n1, n2, P.level.size(), pc(0.5), pc(0.9), pc(0.99), pc(1.0), T);
-        }
-        P.interval = c->F + 1;        // let frames of the new plan come back before judging it
+        P.cur ^= 1; P.n_items[P.cur] = res[0]; P.split1 = res[2]; P.split2 = res[3]; P.replans++;
+        if (verbose) std::fprintf(stderr, "[art] wave plan %u at frame %llu: %u blocks in 4, %u in 16, of %u; slowest sampled wave %u steps, target %u\n", P.replans, (unsigned long long)c->frame_no, res[2], res[3], c->n_local / 64, res[5], res[4]);
+        P.interval = P.moved_since_poll ? plan_moving_interval(c) : c->F + 1;        // a still view: let frames of the new plan come back, then judge it; a moving one: at its cadence
     } else P.interval = P.interval < 128 ? P.interval * 2 : 256;
+    P.moved_since_poll = false;
     P.next_sample = c->frame_no + P.interval;
     return ART_OK;
 }
@@ -664,7 +690,7 @@ int32_t art::ring_rewind(ArtContext *c) {
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
     c->frame_no = 0; c->collected_upto = 0; c->last = 0;
-    c->plan.next_sample = 0; c->plan.pending = false;   // (a sample in flight has landed: everything is synchronised)
+    c->plan.next_sample = 0; c->plan.pending = false; c->plan.last_sample = 0;   // (a sample in flight has landed: everything is synchronised)
     return ART_OK;
 }
 
@@ -727,6 +753,7 @@ int32_t art_destroy(ArtContext *c) {
     (void)hipSetDevice(c->device);
     for (uint32_t k = 0; k < c->F; k++) if (c->stream_of(k)) (void)hipStreamSynchronize(c->stream_of(k));
     drop_graphs(c);
+    for (uint32_t i = 0; i < c->n_refit_streams; i++) if (c->refit_stream[i]) { (void)hipStreamSynchronize(c->refit_stream[i]); (void)hipStreamDestroy(c->refit_stream[i]); }
     as_release(c);
     lbvh_free(c->bvh); c->arena.release();
     c->d_verts.release(); c->d_indices.release(); c->d_tex.release(); c->d_prims.release(); c->d_first_tri.release(); c->d_ao_tab.release();
@@ -952,6 +979,8 @@ int32_t art_scene_build(ArtContext *c) {
     c->stats.build_ms = ms; c->stats.num_triangles = T; c->stats.num_primitives = (uint32_t)dp.size(); c->stats.num_nodes = c->kind_primary == 4 ? c->bvh.n_wide : (T > 1 ? T - 1 : 1);
     c->built = true;
     c->plan.next_sample = c->frame_no; c->plan.interval = 1; // a new scene: the heavy blocks are elsewhere
+    c->first_move_ms = 0.f; c->versions_ms = 0.f;
+    if (c->cfg.flags & ART_FLAG_DYNAMIC_SCENE) { r = as_create(c); if (r) return r; }   // the host said its models move: the ring of versions now, not in front of the first moved frame
     return ART_OK;
 }
 
@@ -959,7 +988,7 @@ int32_t art_set_camera(ArtContext *c, const ArtCamera *cam) {
     if (!c || !cam) return fail(ART_E_INVALID, "art_set_camera: null argument");
     if (!camera_finite(cam)) return fail(ART_E_INVALID, "art_set_camera: non-finite value in the camera block");
     if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) drop_graphs(c); // the camera block is a kernel argument
-    if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) { c->plan.next_sample = c->frame_no; c->plan.interval = 1; } // the heavy blocks move with the view
+    if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(ArtCamera)) != 0) plan_hint_moved(c); // the heavy blocks move with the view
     c->camera = *cam; c->have_camera = true;
     for (uint32_t i = 0; i + 1 < kMaxBatch; i++) c->cam_more[i] = *cam; // every frame of a launch, until art_set_camera_batch says otherwise
     return ART_OK;
@@ -1024,7 +1053,7 @@ int32_t art_set_lights(ArtContext *c, const ArtLight *lights, uint32_t n) {
     bool same = !resized && (n == 0 || std::memcmp(c->lights.data(), lights, (size_t)n * sizeof(ArtLight)) == 0);
     if (same) return ART_OK; // like VkLights' dirty flag (vk_lights.rs:81-139)
     c->lights.assign(lights, lights + n);
-    c->plan.next_sample = c->frame_no; c->plan.interval = 1; // the shadow walks change: look at the waves again
+    plan_hint_moved(c); // the shadow walks change: look at the waves again
     if (resized) { r = sync_all(c); if (r) return r; } // the per-frame buffers are resized with the light count
     drop_graphs(c); // the records are kernel arguments (FrameArgs::lights): nothing to upload, and frames in flight keep the ones they were launched with
     if (resized) c->frame_ready = false;
@@ -1146,17 +1175,13 @@ int32_t art_trace(ArtContext *c) {
     if (fused) { // one launch; its time is booked on the first stage
         HIPC(hipEventRecord(ev[0], s));
         WavePlan &P = c->plan;
-        const bool sample = P.enabled && !P.pending && c->frame_no >= P.next_sample && a.n_wave_items;
+        const bool sample = ((P.enabled && c->frame_no >= P.next_sample) || c->force_sample) && !P.pending && a.n_wave_items && plan_other_free(c);
         if (sample) a.wave_cost = S.d_wave_cost.p;
         const bool counted = a.n_local ? launch_frame(a, s) : false;
         HIPC(hipEventRecord(ev[4], s));
         S.done_alias = ev[4];           // also the frame's completion event (a record is a packet in the frame's queue: 1/8 share 33 -> 29 us)
         HIPC(hipGetLastError());
-        if (counted) { // now and then a frame counts its waves' packet steps and they go to the host
-            HIPC(hipMemcpyAsync(P.h_cost, S.d_wave_cost.p, (size_t)a.n_wave_items * 4, hipMemcpyDeviceToHost, s));
-            HIPC(hipEventRecord(P.cost_ready, s));
-            P.pending = true; P.pending_table = P.cur;
-        }
+        if (counted) { r = plan_launch(c, a, ev[4]); if (r) return r; } // now and then a frame counts its waves' packet steps: the next plan is made from them, behind the frame, on the device
         S.ao_valid = false; S.presented = false;
         c->last = k; c->frame_no++; c->traced = true;
         return ART_OK;
@@ -1178,6 +1203,27 @@ int32_t art_trace(ArtContext *c) {
     c->last = k;
     c->frame_no++;
     c->traced = true;
+    return ART_OK;
+}
+
+int32_t art_sample_wave_steps(ArtContext *c, uint32_t *items, uint32_t *steps, uint32_t cap, uint32_t *n) {
+    if (!c || !n) return fail(ART_E_INVALID, "art_sample_wave_steps: null argument");
+    int32_t r = use_device(c); if (r) return r;
+    r = sync_all(c); if (r) return r;
+    if (c->frame_ready) { r = plan_poll(c); if (r) return r; }   // a plan that has landed takes effect first
+    if (c->plan.pending) return fail(ART_E_STATE, "art_sample_wave_steps: a sample is still in flight");
+    c->force_sample = true;
+    r = art_trace(c);
+    c->force_sample = false;
+    if (r) return r;
+    r = sync_all(c); if (r) return r;
+    WavePlan &P = c->plan;
+    if (!P.pending) return fail(ART_E_STATE, "art_sample_wave_steps: this context's frames are not the fused frame (no step counts)");
+    *n = P.n_items[P.pending_table];
+    const uint32_t m = std::min(*n, cap);
+    if (items && m) HIPC(hipMemcpy(items, P.d_items[P.pending_table].p, (size_t)m * 8, hipMemcpyDeviceToHost));
+    if (steps && m) HIPC(hipMemcpy(steps, c->slot[c->last].d_wave_cost.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    if (!P.enabled) P.pending = false;   // nobody polls a plan that is switched off (k_plan ran all the same: its table is not adopted)
     return ART_OK;
 }
 
@@ -1505,10 +1551,8 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
         }
         c->stats.primary_rays = owned; c->stats.shadow_rays = cnt[0]; c->stats.hit_pixels = cnt[1];
         c->stats.frame_launches = (c->fused && c->kind_primary == 8 && c->kind_shadow == 8) ? 1u : 4u;
-        c->stats.split_blocks = 0;
-        for (uint8_t lv : c->plan.level) c->stats.split_blocks += lv != 0;
+        c->stats.split_blocks = c->plan.split1 + c->plan.split2;
         harvest_cost(c);
-        if (!c->as.empty() && c->as[c->as_cur].timed) { float rms = 0; if (hipEventElapsedTime(&rms, c->as[c->as_cur].t0, c->as[c->as_cur].t1) == hipSuccess) c->last_refit_ms = rms; }
         c->stats.ao_rays = (uint64_t)c->ao_spp * cnt[1];
         if (c->ao_spp && c->slot[c->last].ao_valid) { float ams = 0; if (hipEventElapsedTime(&ams, c->slot[c->last].ao_ev[0], c->slot[c->last].ao_ev[1]) == hipSuccess) c->stats.ao_ms = ams; } // (only a slot whose latest frame had its AO pass has recorded these events: asking others leaves an error behind for the next hipGetLastError)
         float ms = 0;
@@ -1524,6 +1568,7 @@ int32_t art_get_stats(ArtContext *c, ArtStats *out) {
             }
         }
     }
+    c->stats.first_move_ms = c->first_move_ms; c->stats.versions_ms = c->versions_ms;
     c->stats.refit_ms = c->last_refit_ms; c->stats.refit_cost_ratio = c->refit_cost_ratio; c->stats.refits = c->refits; c->stats.rebuilds = c->rebuilds;
     *out = c->stats;
     return ART_OK;

@@ -509,35 +509,30 @@ hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host) {
 
 // the version's triangle records from the object-space shading records (the vertices k_leaves gathered) and the version's object->world matrices: the very
 // operations of k_soup (transform) and k_leaves (edges, box), so a refit with unchanged matrices writes the bits that are there
-// Only what moved is made again: touched[primitive] says whose triangles (the primitives moved since this VERSION was last written), a rewritten triangle marks the
-// 4-wide node that holds it (dirty[]), and the level passes below go up from the marked nodes only -- a small model moving in a big scene costs its own share.
-__global__ __launch_bounds__(256) void k_retri(uint32_t T, const DevShadeTri *__restrict__ shade, const DevPrim *__restrict__ prims, const uint8_t *__restrict__ touched,
-                                               const uint32_t *__restrict__ leaf_parent, uint8_t *__restrict__ dirty, DevTri *__restrict__ tris) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= T) return;
+// Only what moved is made again: touched[primitive] says whose triangles (the primitives moved since this VERSION was last written).  The primitive table and
+// the touched bytes are read WHERE THE HOST WROTE THEM (pinned, device-visible memory: a few hundred bytes a wave touches once) -- round 3 uploaded both with two
+// copies in front of this launch; the launch also leaves the table's device copy for the frames behind it (their shading reads DevPrim).
+// A rewritten triangle marks the 4-wide node that holds it (mark[w] != 0: a box below w changes in this refit); the level passes below carry the marks upwards.
+__device__ __forceinline__ void retri_one(uint32_t p, const DevShadeTri *__restrict__ shade, const DevPrim *prims_host, const uint8_t *touched, const uint32_t *__restrict__ leaf_parent, uint32_t *mark, DevTri *tris) {
     const uint32_t prim = __float_as_uint(shade[p].f[34]);
     if (!touched[prim]) return;
-    if (prims[prim].masked) {   // out of the structure until it is enabled again: a point nowhere, no extent
-        DevTri t;
-        for (int k = 0; k < 3; k++) { t.f[k] = kNowhere; t.f[3 + k] = 0.f; t.f[6 + k] = 0.f; t.f[9 + k] = kNowhere; t.f[12 + k] = kNowhere; }
-        t.f[15] = tris[p].f[15];
-        tris[p] = t;
-        dirty[leaf_parent[p]] = 1;
-        return;
-    }
-    const float4 *sq = reinterpret_cast<const float4 *>(shade + p);
-    const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2];
-    const float *m = prims[prim].o2w;
-    const float3 w0 = xform_point(m, s0.x, s0.y, s0.z), w1 = xform_point(m, s0.w, s1.x, s1.y), w2 = xform_point(m, s1.z, s1.w, s2.x);
-    const float a[3] = {w0.x, w0.y, w0.z}, b[3] = {w1.x, w1.y, w1.z}, c[3] = {w2.x, w2.y, w2.z};
     DevTri t;
-    for (int k = 0; k < 3; k++) {
-        t.f[k] = a[k]; t.f[3 + k] = b[k] - a[k]; t.f[6 + k] = c[k] - a[k];
-        t.f[9 + k] = fminf(fminf(a[k], b[k]), c[k]); t.f[12 + k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+    if (prims_host[prim].masked) {   // out of the structure until it is enabled again: a point nowhere, no extent
+        for (int k = 0; k < 3; k++) { t.f[k] = kNowhere; t.f[3 + k] = 0.f; t.f[6 + k] = 0.f; t.f[9 + k] = kNowhere; t.f[12 + k] = kNowhere; }
+    } else {
+        const float4 *sq = reinterpret_cast<const float4 *>(shade + p);
+        const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2];
+        const float *m = prims_host[prim].o2w;
+        const float3 w0 = xform_point(m, s0.x, s0.y, s0.z), w1 = xform_point(m, s0.w, s1.x, s1.y), w2 = xform_point(m, s1.z, s1.w, s2.x);
+        const float a[3] = {w0.x, w0.y, w0.z}, b[3] = {w1.x, w1.y, w1.z}, c[3] = {w2.x, w2.y, w2.z};
+        for (int k = 0; k < 3; k++) {
+            t.f[k] = a[k]; t.f[3 + k] = b[k] - a[k]; t.f[6 + k] = c[k] - a[k];
+            t.f[9 + k] = fminf(fminf(a[k], b[k]), c[k]); t.f[12 + k] = fmaxf(fmaxf(a[k], b[k]), c[k]);
+        }
     }
     t.f[15] = tris[p].f[15]; // the global triangle id never changes
     tris[p] = t;
-    dirty[leaf_parent[p]] = 1;
+    mark[leaf_parent[p]] = 1u;
 }
 // which 4-wide node holds a leaf, which one a node (the root: ~0): made once per tree, when its first model moves
 __global__ __launch_bounds__(256) void k_wide_parents(uint32_t n_wide, const DevNodeW *__restrict__ widef, uint32_t *__restrict__ leaf_parent, uint32_t *__restrict__ node_parent) {
@@ -554,9 +549,9 @@ __global__ __launch_bounds__(256) void k_wide_parents(uint32_t n_wide, const Dev
 // One child box of one node of the 4-wide tree: a leaf child's box is its triangle's, an internal child's the union of that node's own child boxes (float min / max
 // are exact, so whatever the order the union is the box a build would find).  Four neighbouring lanes share a node; the pass is loads and min / max only -- the
 // quantised records are made afterwards, for all nodes at once (k_wide_requant): their double-precision arithmetic does not belong on the bottom-up critical path.
-__device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const DevTri *__restrict__ tris, DevNodeW *widef, const uint32_t *__restrict__ node_parent, uint8_t *dirty) {
-    if (!dirty[w]) return;                              // nothing below this node moved
-    if (i == 0) { const uint32_t up = node_parent[w]; if (up != ~0u) dirty[up] = 1; }   // its parent's box of it changes: a level further up, a launch (or a barrier) later
+__device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const DevTri *__restrict__ tris, DevNodeW *widef, const uint32_t *__restrict__ node_parent, uint32_t *mark) {
+    if (!mark[w]) return;                               // nothing below this node moved
+    if (i == 0) { const uint32_t up = node_parent[w]; if (up != ~0u) mark[up] = 1u; }   // its parent's box of it changes: a level further up, a launch (or a barrier) later
     const int32_t ch = widef[w].child[i];
     if (ch == kAbsentChild) return;
     float lo[3], hi[3];
@@ -576,32 +571,49 @@ __device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const D
     float *o = widef[w].box[i];
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
 }
-__global__ __launch_bounds__(256) void k_wide_refit(uint32_t first, uint32_t n, const DevTri *__restrict__ tris, DevNodeW *widef, const uint32_t *__restrict__ node_parent, uint8_t *dirty) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 4u * n) wide_union_child(first + (i >> 2), i & 3u, tris, widef, node_parent, dirty);
-}
-// the top of the tree: levels of at most 1024 nodes each, bottom-up in ONE workgroup (a launch per level would cost more than the levels)
-constexpr int kTopLevels = 16;
-struct TopLevels { uint32_t first[kTopLevels + 1]; int n; }; // level i = nodes [first[i], first[i + 1])
-__global__ __launch_bounds__(1024) void k_wide_refit_top(TopLevels L, const DevTri *__restrict__ tris, DevNodeW *widef, const uint32_t *__restrict__ node_parent, uint8_t *dirty) {
-    for (int lv = L.n - 1; lv >= 0; lv--) {
-        const uint32_t n = L.first[lv + 1] - L.first[lv];
-        for (uint32_t i = threadIdx.x; i < 4u * n; i += 1024u) wide_union_child(L.first[lv] + (i >> 2), i & 3u, tris, widef, node_parent, dirty);
+// The tree cut into BATCHES of whole subtrees of about kBatchNodes nodes (refit_lists_build) and the crown above them: ONE workgroup rewrites a batch's triangles and then refits
+// its nodes level by level, deepest first, with a workgroup barrier between levels -- everything a node of the batch depends on is the batch's own, written through the one L1
+// of the CU the workgroup runs on; a second launch of one large workgroup does the same for the crown (the few hundred nodes whose subtrees are larger than a batch).
+// Round 3 ran a launch per level of the whole tree (a dozen dependent launches in front of every frame of a moving model: among three frames' worth of waves each waits tens
+// of microseconds for its turn); round 4 first tried the marked nodes bottom-up in ONE launch with arrival counters -- release / atomic / acquire per node, k_refit's
+// protocol -- and measured 0.41 ms for that launch alone and 1.0 ms among frames: an agent-scope release on gfx950 writes the XCD's L2 back and every acquire invalidates
+// it, per node and level, where a workgroup barrier costs nothing of the kind.  profiles/README.md round 4.
+// sub_off: [0, nb + 1] node offsets of batches 0 .. nb (batch nb = the crown) | [nb + 2, 2 nb + 3] leaf offsets | then nb + 1 rows of (n_levels + 1) offsets into the batch's
+// node list, deepest level of the tree first.
+__global__ void k_refit_sub(uint32_t batch0, uint32_t nb1 /*batches + the crown*/, uint32_t n_levels, const uint32_t *__restrict__ sub_nodes, const uint32_t *__restrict__ sub_leaves, const uint32_t *__restrict__ sub_off,
+                            const DevShadeTri *__restrict__ shade, const DevPrim *prims_host, DevPrim *prims_dev, uint32_t n_prim_words, const uint8_t *touched,
+                            const uint32_t *__restrict__ leaf_parent, const uint32_t *__restrict__ node_parent, uint32_t *mark, DevTri *tris, DevNodeW *widef, unsigned long long *stamp, bool first_launch) {
+    const uint32_t b = batch0 + blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (first_launch) {
+        if (blockIdx.x == 0 && tid == 0) stamp[0] = wall_clock64();   // the refit's start (100 MHz): its device time travels to the host with its cost, no events
+        for (uint32_t i = blockIdx.x * nt + tid; i < n_prim_words; i += gridDim.x * nt) reinterpret_cast<uint32_t *>(prims_dev)[i] = reinterpret_cast<const uint32_t *>(prims_host)[i];   // the table's device copy, for the frames
+    }
+    for (uint32_t i = sub_off[nb1 + 1 + b] + tid; i < sub_off[nb1 + 2 + b]; i += nt) retri_one(sub_leaves[i], shade, prims_host, touched, leaf_parent, mark, tris);
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t *lv_off = sub_off + 2 * (nb1 + 1) + (size_t)b * (n_levels + 1), n0 = sub_off[b];
+    for (uint32_t lv = 0; lv < n_levels; lv++) {         // (the same trips for every thread of the workgroup)
+        const uint32_t lo = lv_off[lv], hi = lv_off[lv + 1];
+        if (hi == lo) continue;
+        for (uint32_t i = 4u * lo + tid; i < 4u * hi; i += nt) wide_union_child(sub_nodes[n0 + (i >> 2)], i & 3u, tris, widef, node_parent, mark);
         __threadfence_block();
-        __syncthreads(); // the level above reads these records
+        __syncthreads();   // the level above reads these records
     }
 }
 // after the boxes: every node's quantised record (the per-ray walks', DevNode4) from its float one, and the tree's surface-area cost while the boxes are at hand:
 // cost[0] += the half-areas of all child boxes (the measure of the rays that cross each box: what a walk pays for), cost[1] = half-area of the root's union.  A refit
 // can only keep or grow the sum against the same rays; a rebuild restores it.  The rule compares the plain sums: dividing by the root's area would reward a model
 // that flies off (the root grows faster than the sum) although the rays of a camera among the rest of the scene cross more boxes than before.
-__global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const DevNodeW *__restrict__ widef, DevNode4 *__restrict__ wide, uint8_t *dirty /*null: every node*/, double *cost) {
+// acc (device): [0] the running sum, [1] the root's half-area, [2] the refit's start stamp (k_retri), [3] exit ticket of this launch (as a 64-bit counter).  The last block
+// out writes {sum, root, start, end} to `out` -- pinned host memory when a refit's result travels to the host behind its `ready` event (no copy, no event of its
+// own), a device buffer otherwise -- and clears acc for the next launch.
+__global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const DevNodeW *__restrict__ widef, DevNode4 *__restrict__ wide, uint32_t *mark /*null: every node*/, double *acc, double *out) {
     __shared__ double s_part[4];
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     double a = 0.0;
     if (w < n_wide) {
-        const bool requant = wide && (!dirty || dirty[w]);   // the double-precision quantisation only where a box changed; the cost sums every node
-        if (dirty && dirty[w]) dirty[w] = 0;                  // (the marks are this version's: cleared for its next refit)
+        const bool requant = wide && (!mark || mark[w]);      // the double-precision quantisation only where a box changed; the cost sums every node
+        if (mark && mark[w]) mark[w] = 0;                      // (the marks are this version's: cleared for its next refit)
         const float4 *q = reinterpret_cast<const float4 *>(widef + w);
         const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
         const int4 ch = *reinterpret_cast<const int4 *>(&widef[w].child[0]);
@@ -621,41 +633,99 @@ __global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const Dev
             a += dx * dy + dy * dz + dz * dx;
             for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], lo[j][k]); rhi[k] = fmaxf(rhi[k], hi[j][k]); }
         }
-        if (w == 0) { double dx = (double)rhi[0] - rlo[0], dy = (double)rhi[1] - rlo[1], dz = (double)rhi[2] - rlo[2]; cost[1] = dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
+        if (w == 0) { double dx = (double)rhi[0] - rlo[0], dy = (double)rhi[1] - rlo[1], dz = (double)rhi[2] - rlo[2]; acc[1] = dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
     }
     for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
     if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) { double t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]); if (t != 0.0) atomicAdd(&cost[0], t); }
+    if (threadIdx.x == 0) {
+        double t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        if (t != 0.0) atomicAdd(&acc[0], t);
+        __threadfence();
+        unsigned long long *ticket = reinterpret_cast<unsigned long long *>(&acc[3]);
+        if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull) {   // every block's sum (and block 0's root area) is in
+            __threadfence();
+            out[0] = atomicAdd(&acc[0], 0.0); out[1] = *(volatile double *)&acc[1];
+            reinterpret_cast<unsigned long long *>(out)[2] = *(volatile unsigned long long *)&acc[2]; reinterpret_cast<unsigned long long *>(out)[3] = wall_clock64();
+            acc[0] = 0.0; acc[1] = 0.0; *ticket = 0ull;
+        }
+    }
 }
 
-void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, const uint8_t *touched, const uint32_t *leaf_parent, uint8_t *dirty, DevTri *tris, hipStream_t s) {
-    k_retri<<<(T + 255) / 256, 256, 0, s>>>(T, shade, prims, touched, leaf_parent, dirty, tris);
-}
 void launch_wide_parents(uint32_t n_wide, const DevNodeW *widef, uint32_t *leaf_parent, uint32_t *node_parent, hipStream_t s) {
     k_wide_parents<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, leaf_parent, node_parent);
 }
-void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, const uint32_t *node_parent, uint8_t *dirty, double *cost, hipStream_t s) {
-    const int n_levels = (int)levels.size() - 1;
-    if (n_levels <= 0) return;
-    int top = 0; // levels [0, top) go into the one-workgroup launch
-    while (top < n_levels && top < kTopLevels && levels[top + 1] - levels[top] <= 1024u) top++;
-    for (int lv = n_levels - 1; lv >= top; lv--) {
-        const uint32_t n = levels[lv + 1] - levels[lv];
-        k_wide_refit<<<(4 * n + 255) / 256, 256, 0, s>>>(levels[lv], n, tris, widef, node_parent, dirty);
-    }
-    if (top) {
-        TopLevels L{}; L.n = top;
-        for (int i = 0; i <= top; i++) L.first[i] = levels[i];
-        k_wide_refit_top<<<1, 1024, 0, s>>>(L, tris, widef, node_parent, dirty);
-    }
-    (void)hipMemsetAsync(cost, 0, 16, s);
-    k_wide_requant<<<((uint32_t)levels.back() + 255) / 256, 256, 0, s>>>((uint32_t)levels.back(), widef, wide, dirty, cost);
+// a refit in three launches whatever the tree's depth: the batches (their triangles + their nodes), the crown (its triangles + its levels), the quantised records of the marked
+// nodes + the tree's cost -> result[0..3] = cost sum, root half-area, start and end stamps (wall_clock64: 100 MHz)
+void launch_refit(const RefitArgs &r, hipStream_t s) {
+    unsigned long long *stamp = reinterpret_cast<unsigned long long *>(r.acc) + 2;
+    const uint32_t npw = r.n_prims * (uint32_t)(sizeof(DevPrim) / 4), nb1 = r.sub_batches + 1;
+    if (r.sub_batches) k_refit_sub<<<r.sub_batches, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true);
+    k_refit_sub<<<1, 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, r.sub_batches == 0);
+    k_wide_requant<<<(r.n_wide + 255) / 256, 256, 0, s>>>(r.n_wide, r.widef, r.wide, r.mark, r.acc, r.result);
 }
-// the quantised records (wide; null: leave them) and the cost (2 doubles) of the float records
-void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide, double *cost, hipStream_t s) {
-    (void)hipMemsetAsync(cost, 0, 16, s);
-    k_wide_requant<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, wide, nullptr, cost);
+// The refit's work lists, once per tree (host work on the parents read back: the topology never changes).  A node whose subtree has at most kBatchNodes nodes while its parent's
+// has more roots a batch subtree; runs of such roots (in index order) are dealt to batches of about kBatchNodes nodes; the nodes above them -- the crown: a few hundred for the
+// bench scenes -- are batch `nb`.  The numbering is breadth-first, so a larger index is never above a smaller one: a batch's nodes in descending order are deepest level first.
+hipError_t refit_lists_build(Lbvh &l, uint32_t T, hipStream_t s) {
+    constexpr uint32_t kBatchNodes = 768;
+    const std::vector<uint32_t> &levels = l.wide_levels;
+    const uint32_t NW = l.n_wide, n_levels = (uint32_t)levels.size() - 1;
+    std::vector<uint32_t> node_parent(NW), leaf_parent(T);
+    HIPQ(hipStreamSynchronize(s));
+    HIPQ(hipMemcpy(node_parent.data(), l.node_parent, (size_t)NW * 4, hipMemcpyDeviceToHost)); HIPQ(hipMemcpy(leaf_parent.data(), l.leaf_parent, (size_t)T * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> size(NW, 1);
+    for (uint32_t w = NW; w-- > 1;) size[node_parent[w]] += size[w];
+    // batch_of: ~0 = the crown; roots in index order fill batches
+    std::vector<uint32_t> batch_of(NW, ~0u);
+    uint32_t nb = 0, fill = 0;
+    for (uint32_t w = 1; w < NW; w++) {
+        if (size[w] > kBatchNodes) continue;                                   // crown
+        const uint32_t up = node_parent[w];
+        if (size[up] > kBatchNodes) {                                          // a batch root
+            if (nb == 0 || fill + size[w] > kBatchNodes + kBatchNodes / 2) { nb++; fill = 0; }
+            fill += size[w]; batch_of[w] = nb - 1;
+        } else batch_of[w] = batch_of[up];
+    }
+    const uint32_t nb1 = nb + 1;
+    auto slot = [&](uint32_t w) { return batch_of[w] == ~0u ? nb : batch_of[w]; };
+    std::vector<uint32_t> off(2 * (size_t)(nb1 + 1) + (size_t)nb1 * (n_levels + 1), 0), sub_nodes(NW), sub_leaves(T);
+    {   // node lists: counts -> offsets -> fill from the deepest level up; level offsets within each list
+        std::vector<uint32_t> cnt(nb1 + 1, 0);
+        for (uint32_t w = 0; w < NW; w++) cnt[slot(w) + 1]++;
+        for (uint32_t b = 0; b < nb1; b++) cnt[b + 1] += cnt[b];
+        for (uint32_t b = 0; b <= nb1; b++) off[b] = cnt[b];
+        std::vector<uint32_t> at(cnt.begin(), cnt.end() - 1);
+        uint32_t *lv_off = off.data() + 2 * (size_t)(nb1 + 1);
+        for (uint32_t lv = n_levels; lv-- > 0;) {          // deepest level first
+            for (uint32_t b = 0; b < nb1; b++) lv_off[(size_t)b * (n_levels + 1) + (n_levels - 1 - lv)] = at[b] - cnt[b];
+            for (uint32_t w = levels[lv + 1]; w-- > levels[lv];) sub_nodes[at[slot(w)]++] = w;
+        }
+        for (uint32_t b = 0; b < nb1; b++) lv_off[(size_t)b * (n_levels + 1) + n_levels] = at[b] - cnt[b];
+    }
+    {   // leaf lists
+        std::vector<uint32_t> cnt(nb1 + 1, 0);
+        for (uint32_t p = 0; p < T; p++) cnt[slot(leaf_parent[p]) + 1]++;
+        for (uint32_t b = 0; b < nb1; b++) cnt[b + 1] += cnt[b];
+        for (uint32_t b = 0; b <= nb1; b++) off[nb1 + 1 + b] = cnt[b];
+        std::vector<uint32_t> at(cnt.begin(), cnt.end() - 1);
+        for (uint32_t p = 0; p < T; p++) sub_leaves[at[slot(leaf_parent[p])]++] = p;
+    }
+    hipFree(l.sub_nodes); hipFree(l.sub_leaves); hipFree(l.sub_off); l.sub_nodes = l.sub_leaves = l.sub_off = nullptr;
+    HIPQ(hipMalloc(&l.sub_nodes, (size_t)NW * 4)); HIPQ(hipMalloc(&l.sub_leaves, (size_t)T * 4)); HIPQ(hipMalloc(&l.sub_off, off.size() * 4));
+    HIPQ(hipMemcpy(l.sub_nodes, sub_nodes.data(), (size_t)NW * 4, hipMemcpyHostToDevice)); HIPQ(hipMemcpy(l.sub_leaves, sub_leaves.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    HIPQ(hipMemcpy(l.sub_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    l.sub_batches = nb; l.sub_levels = n_levels;
+    if (l.log & 1u) {
+        uint32_t crown = 0, big = 0; for (uint32_t w = 0; w < NW; w++) crown += batch_of[w] == ~0u;
+        for (uint32_t b = 0; b < nb; b++) big = std::max(big, off[b + 1] - off[b]);
+        std::fprintf(stderr, "[art] refit lists: %u nodes in %u levels; %u batches (largest %u nodes), a crown of %u nodes\n", NW, n_levels, nb, big, crown);
+    }
+    return hipSuccess;
+}
+// the quantised records (wide; null: leave them) and the cost of the float records as they are: result[0..1] (acc: 4 zeroed doubles of scratch)
+void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide, double *acc, double *result, hipStream_t s) {
+    k_wide_requant<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, wide, nullptr, acc, result);
 }
 
 // The binary trees (the canonical LBVH of art_get_lbvh, the traversal tree of the per-ray / binary walks) after a refit: leaf boxes from the triangle records,
@@ -706,6 +776,7 @@ void build_prewarm(hipStream_t s) { k_build_noop<<<1, 1, 0, s>>>(); }
 
 void lbvh_free(Lbvh &l) {
     hipFree(l.wide); hipFree(l.widef); hipFree(l.leaf_parent); hipFree(l.node_parent);
+    hipFree(l.sub_nodes); hipFree(l.sub_leaves); hipFree(l.sub_off);
     if (l.trav_child != l.res_trav_child) { hipFree(l.trav_child); hipFree(l.trav_lo); hipFree(l.trav_hi); }   // (allocations of their own: no room was reserved)
     hipFree(l.block);   // leaf_gid .. shade_tris, cbounds, res_trav_*
     l = Lbvh{};

@@ -114,6 +114,9 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     DevShadeTri *shade_tris; // [T] leaf order
     uint32_t *leaf_parent;  // [T] the 4-wide node that holds a leaf, [n_wide] the one that holds a node (root: ~0): made with the first refit (launch_wide_parents), else null
     uint32_t *node_parent;
+    // the refit's work lists (refit_lists_build, made with the parents): the tree below its top levels is cut into batches of neighbouring subtrees, one workgroup each
+    uint32_t *sub_nodes = nullptr, *sub_leaves = nullptr, *sub_off = nullptr;   // device: batch b's nodes (deepest level first) / leaves; batch nb = the crown above the batches; sub_off: see k_refit_sub
+    uint32_t sub_batches = 0, sub_levels = 0;                                     // host: batches (without the crown); levels of the tree
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
     char *block = nullptr;  // host: ONE allocation behind the arrays lbvh_build makes (leaf_gid .. shade_tris, cbounds) and room for the traversal tree's three (res_trav_*): two dozen
@@ -142,11 +145,19 @@ void sah_prewarm(hipStream_t s);     // art_sahdev.hip
 // refit after a model moved (art_build.hip): the triangle records of a version of the acceleration structure from the shading records and that version's
 // primitive table; its 4-wide nodes bottom-up, level by level (l.wide_levels); the tree's surface-area cost (2 doubles: sum of child half-areas, root half-area);
 // the binary trees and node records from a version's triangles (on demand, synchronises)
-// touched: one byte per primitive (whose triangles to make again); dirty: one byte per 4-wide node, all zero between refits (marks go up from the rewritten triangles)
-void launch_retri(uint32_t T, const DevShadeTri *shade, const DevPrim *prims, const uint8_t *touched, const uint32_t *leaf_parent, uint8_t *dirty, DevTri *tris, hipStream_t s);
+// prims_host / touched: PINNED host memory the kernels read in place (the version's staging copies: one byte per primitive -- whose triangles to make again); mark: one word
+// per 4-wide node, all zero between refits; acc: 4 doubles of device scratch, zero between launches; result: 4 doubles, pinned host memory (cost sum, root half-area, start / end stamps)
+struct RefitArgs {
+    uint32_t T, n_wide, n_prims;
+    const uint32_t *sub_nodes, *sub_leaves, *sub_off; uint32_t sub_batches, sub_levels;
+    const DevShadeTri *shade; const DevPrim *prims_host; DevPrim *prims_dev; const uint8_t *touched;
+    const uint32_t *leaf_parent, *node_parent; uint32_t *mark;
+    DevTri *tris; DevNode4 *wide; DevNodeW *widef; double *acc, *result;
+};
+void launch_refit(const RefitArgs &r, hipStream_t s);
 void launch_wide_parents(uint32_t n_wide, const DevNodeW *widef, uint32_t *leaf_parent, uint32_t *node_parent, hipStream_t s);
-void launch_wide_refit(const std::vector<uint32_t> &levels, const DevTri *tris, DevNode4 *wide, DevNodeW *widef, const uint32_t *node_parent, uint8_t *dirty, double *cost, hipStream_t s); // boxes bottom-up from the marked nodes, then their quantised records + the cost
-void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide /*null: cost only*/, double *cost, hipStream_t s);
+hipError_t refit_lists_build(Lbvh &l, uint32_t T, hipStream_t s);   // after launch_wide_parents (synchronises: a one-off of the scene's first version ring)
+void launch_wide_cost(uint32_t n_wide, const DevNodeW *widef, DevNode4 *wide /*null: cost only*/, double *acc, double *result, hipStream_t s);
 hipError_t binary_refit(Lbvh &l, uint32_t T, const DevTri *tris, hipStream_t s);
 struct TraceTune { uint32_t chunk, refill, blocks, leaf_batch; }; // overrides of the persistent per-ray tracer's presets (ArtTuning.trace_chunk / trace_refill / trace_blocks; 0 = the preset): they travel with every launch
 void lbvh_free(Lbvh &l);
@@ -229,6 +240,19 @@ void launch_shadow(const FrameArgs &a, hipStream_t s);
 void launch_accumulate(const FrameArgs &a, hipStream_t s);
 bool launch_frame(const FrameArgs &a, hipStream_t s);      // the fused frame: primary + shade + shadow + accumulate in one launch; true: it also wrote a.wave_cost (a.wave_cost set and a counting instance exists)
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s); // out[0] += shadow rays, out[1] += hit pixels
+// The wave plan of the fused frame, made ON THE DEVICE behind a sampled frame (k_plan, art_trace.hip): from the steps every wave of that launch counted, every 8x8 block's level
+// (0 one wave | 1 four quadrant waves | 2 sixteen cell waves) and, if a level changed that matters, the next table of wave items.  result (pinned host memory, read once the
+// event behind the launch has fired): [0] items of the new table, [1] 1 = a new table was written, [2] blocks in four, [3] blocks in sixteen, [4] the step target, [5] slowest wave
+struct PlanArgs {
+    const uint2 *items_in; uint32_t n_items_in; const uint32_t *cost;   // the sampled launch: its table and what its waves counted
+    uint8_t *level, *level_tmp; uint32_t n64;                             // per 8x8 block (device, persistent) + scratch
+    uint32_t *worst;                                                      // [n64] scratch, zero between launches
+    const uint32_t *order; uint32_t n256;                                 // launch order of the 256-pixel blocks (FrameArgs::block_order)
+    uint2 *items_out; uint32_t cap;                                       // the table nobody reads at the moment
+    float share; uint32_t min_steps, fixed_steps;                         // target = max(min_steps, share * steps of the sampled frame), or fixed_steps
+    uint32_t *result;
+};
+void launch_plan(const PlanArgs &p, hipStream_t s);
 // ambient occlusion on the frame's depth/normal outputs; occl: n_local*spp bytes; lut: spp+1 output values; cursors at counters[64+512..] are reused (queries never overlap a frame)
 constexpr uint32_t kAoTableEntriesPerSample = 64 * 64;
 void launch_ao_table(uint32_t spp, float4 *tab, hipStream_t s); // tab: spp * kAoTableEntriesPerSample float4

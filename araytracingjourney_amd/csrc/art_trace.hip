@@ -178,6 +178,10 @@ template <bool ANY, int OVF> struct TravBase {
     // accept() of DESIGN.md 1.1 for the triangle in `cur`: exact triangle-AABB slab, then Moeller-Trumbore
     __device__ __forceinline__ bool step_leaf(const DevTri *__restrict__ tris, int *lds, int *ovf) {
         uint32_t pos = (uint32_t)~cur;
+        // the reference of an ABSENT child of a 4-wide node (kAbsentChild: no leaf sits at position 2^31 - 1).  Its inverted box is left before it is entered by every
+        // ray with a sign on every axis -- but a node scaled down to a point (a one-triangle tree, a node whose children were all masked) gives near == far on all three
+        // axes to a ray through that point, which passes: such a "triangle" is nothing
+        if (pos == 0x7FFFFFFFu) return pop(lds, ovf);
         const float4 *tq = reinterpret_cast<const float4 *>(tris + pos);
         float4 ta = tq[0], tb = tq[1], tc = tq[2], td = tq[3];   // v0 e1 e2 lo hi gid (DevTri)
         asm volatile("" : "+v"(td.x), "+v"(td.y), "+v"(td.z), "+v"(td.w), "+v"(tc.y), "+v"(tc.z), "+v"(tc.w)); // the box arrives with the vertices (else its load sinks below the triangle test: a second round trip for the lanes that pass it)
@@ -1372,6 +1376,89 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
 #endif
     if (COUNT && __lane_id() == 0) a.wave_cost[wid] = steps; // feedback for the next plan (art_api.hip plan_poll)
 }
+
+// ---- the wave plan, on the device ---------------------------------------------------------------------------------------------------------------------------------
+// Rounds 1-3 made it on the host: the step counts of a sampled frame travelled up, one thread went through 32 640 blocks and built the next table (0.3-0.9 ms inside an
+// art_trace call every few frames once the camera moves: frames are 0.16 ms), the table travelled down.  One workgroup does the same in ~20 us behind the sampled frame on
+// that frame's stream; the host only learns "a new table of n items is ready" from pinned memory once the event behind this launch has fired.
+// Table layout (what plan_build_items made): the split blocks' parts first -- sixteen cells each, then four quadrants each: the long poles start first -- padded to whole groups
+// of four, then every 256-pixel block of the launch order as four 8x8 items (mask 0: an idle wave where the block is split); finally the deal that keeps the four waves of
+// launch block 8g + x on XCD x (workgroup j runs on XCD j % 8): position 32g + 4x + k goes to 32g + 8k + x.
+__device__ __forceinline__ uint32_t plan_block_sum(uint32_t v, uint32_t *sh) {   // sum over the 1024 threads, in every thread (sh: 16 words)
+    for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (int i = 0; i < 16; i++) t += sh[i];
+    return t;
+}
+__device__ __forceinline__ uint32_t plan_deal(uint32_t j, uint32_t total) { const uint32_t g = j >> 5; return (g + 1u) * 32u <= total ? g * 32u + 8u * (j & 3u) + ((j & 31u) >> 2) : j; }
+__global__ __launch_bounds__(1024) void k_plan(PlanArgs p) {
+    __shared__ uint32_t sh[16], sc2[1024], sc1[1024];
+    __shared__ unsigned long long sh64[16];
+    const uint32_t tid = threadIdx.x;
+    // 1. the slowest wave of every block in the sampled frame, and the frame's steps
+    unsigned long long sum = 0;
+    for (uint32_t i = tid; i < p.n_items_in; i += 1024u) { const uint2 it = p.items_in[i]; if (it.y) { const uint32_t c = p.cost[i]; atomicMax(&p.worst[it.x], c); sum += c; } }
+    for (int off = 32; off >= 1; off >>= 1) sum += (unsigned long long)__shfl_xor((long long)sum, off);
+    if ((tid & 63u) == 0) sh64[tid >> 6] = sum;
+    __threadfence_block();
+    __syncthreads();
+    sum = 0;
+    for (int i = 0; i < 16; i++) sum += sh64[i];
+    uint32_t T = p.fixed_steps ? p.fixed_steps : max(p.min_steps, (uint32_t)(p.share * (float)sum));
+    // 2. every block's level; a block that has to be split is a wave that outlasts its launch, blocks that could be put together again only save a few steps (going down needs
+    //    a clear margin: the parts of a split block share the top of their walks)
+    const uint32_t per = (p.n64 + 1023u) / 1024u, b0 = min(tid * per, p.n64), b1 = min(b0 + per, p.n64);
+    uint32_t n1 = 0, n2 = 0, N1 = 0, N2 = 0, ups = 0, downs = 0, split = 0, wmax = 0;
+    for (int attempt = 0; attempt < 8; attempt++, T += T / 2) {
+        n1 = n2 = 0; uint32_t u = 0, d = 0, sp = 0;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t w = __hip_atomic_load(&p.worst[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by atomics of other waves of this workgroup)
+            const uint32_t old = p.level[b];
+            uint32_t lv = old;
+            if (old == 0) lv = w > 4u * T ? 2u : (w > T ? 1u : 0u);
+            else if (old == 1) lv = w > T ? 2u : (w * 4u < T / 2u ? 0u : 1u);
+            else lv = w * 4u < T / 2u ? 1u : 2u;
+            p.level_tmp[b] = (uint8_t)lv;
+            n1 += lv == 1u; n2 += lv == 2u; u += lv > old; d += lv < old; sp += old != 0u; wmax = max(wmax, w);
+        }
+        N1 = plan_block_sum(n1, sh); N2 = plan_block_sum(n2, sh); ups = plan_block_sum(u, sh); downs = plan_block_sum(d, sh); split = plan_block_sum(sp, sh);
+        if (p.n64 + (p.n64 & 3u) + 4u * N1 + 16u * N2 + 4u <= p.cap) break;
+        if (attempt == 7) { N1 = N2 = ups = downs = 0; for (uint32_t b = b0; b < b1; b++) p.level_tmp[b] = p.level[b]; n1 = n2 = 0; }   // (never seen: no target fits -- the plan stays)
+    }
+    for (int off = 32; off >= 1; off >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, off));
+    __syncthreads();
+    if ((tid & 63u) == 0) sh[tid >> 6] = wmax;
+    __syncthreads();
+    for (int i = 0; i < 16; i++) wmax = max(wmax, sh[i]);
+    for (uint32_t b = b0; b < b1; b++) p.worst[b] = 0u;   // clear for the next sample
+    const bool changed = p.fixed_steps ? (ups + downs) != 0u : (ups != 0u || downs > max(16u, split / 4u));
+    if (!changed) { if (tid == 0) { p.result[1] = 0u; p.result[4] = T; p.result[5] = wmax; } return; }
+    // 3. where every thread's split blocks go: exclusive scans of the per-thread counts
+    sc2[tid] = n2; sc1[tid] = n1;
+    __syncthreads();
+    uint32_t base2 = 0, base1 = 0;
+    for (uint32_t i = 0; i < tid; i++) { base2 += sc2[i]; base1 += sc1[i]; }   // (1024 LDS reads a thread: a microsecond)
+    const uint32_t heavy = 16u * N2 + 4u * N1, heavy_pad = (heavy + 3u) & ~3u, total = heavy_pad + p.n256 * 4u;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t lv = p.level_tmp[b];
+        p.level[b] = (uint8_t)lv;
+        if (lv == 2u) { for (uint32_t cell = 0; cell < 16u; cell++) p.items_out[plan_deal(16u * base2 + cell, total)] = make_uint2(b, 1u << cell); base2++; }
+        else if (lv == 1u) { const uint32_t quad[4] = {0x0033u, 0x00CCu, 0x3300u, 0xCC00u}; for (uint32_t q = 0; q < 4u; q++) p.items_out[plan_deal(16u * N2 + 4u * base1 + q, total)] = make_uint2(b, quad[q]); base1++; }
+    }
+    for (uint32_t j = heavy + tid; j < heavy_pad; j += 1024u) p.items_out[plan_deal(j, total)] = make_uint2(0u, 0u);
+    __threadfence_block();
+    __syncthreads();   // (level[] of other threads' blocks is read below)
+    // 4. the blocks in launch order; a split block leaves an idle wave behind: the XCD order of the rest is untouched
+    for (uint32_t r = tid; r < p.n256 * 4u; r += 1024u) {
+        const uint32_t b = p.order[r >> 2] * 4u + (r & 3u);
+        p.items_out[plan_deal(heavy_pad + r, total)] = make_uint2(b, p.level[b] ? 0u : 0xFFFFu);
+    }
+    if (tid == 0) { p.result[0] = total; p.result[1] = 1u; p.result[2] = N1; p.result[3] = N2; p.result[4] = T; p.result[5] = wmax; }
+}
+void launch_plan(const PlanArgs &p, hipStream_t s) { k_plan<<<1, 1024, 0, s>>>(p); }
 
 // art_get_stats for fused frames: shadow rays = set bits 16..31 of pix_bits, hit pixels = depth < miss depth; on demand only
 __global__ __launch_bounds__(kBlock) void k_frame_stats(FrameArgs a, uint32_t *out) {

@@ -552,6 +552,22 @@ def camera_path(scene: Scene, n: int):
     return out
 
 
+def camera_walk(scene: Scene, n: int, fps: float = 6000.0):
+    """n camera poses of the REFERENCE's own camera motion (bench.py --camera-walk): main.rs:80-105 moves the camera 0.002 units per millisecond of frame time along a view
+    axis while a key is down (2 units / s) and turns it 0.002 rad per mouse count (:112-124; a brisk hand makes ~1 000 counts / s: 2 rad / s).  At `fps` frames per second -- the
+    rate this library renders the scene at: what a render loop on top of it sees -- that is 2 / fps units and 2 / fps rad a frame.  A closed loop: n / 2 frames forward along the
+    view direction while turning about the up axis, n / 2 frames back.  Pose 0 is the scene's camera."""
+    p0, d0 = np.asarray(scene.camera["pos"], np.float64), np.asarray(_unit(scene.camera["dir"]), np.float64)
+    step, turn = 2.0 / fps, 2.0 / fps
+    out = []
+    for i in range(n):
+        k = min(i, n - i)
+        yaw = turn * k
+        d = np.array([d0[0] * math.cos(yaw) + d0[2] * math.sin(yaw), d0[1], -d0[0] * math.sin(yaw) + d0[2] * math.cos(yaw)])   # about the up axis (0, -1, 0) of vk_camera.rs:182-189
+        out.append(dict(scene.camera, pos=tuple(float(x) for x in (p0 + d0 * (step * k))), dir=_unit(d)))
+    return out
+
+
 def from_glb(path, lights=None, camera=None) -> Scene:
     """A .glb through the C++ reader (art_glb_*: GltfModelReader of gltf_model_reader.rs) as a Scene, set up like the reference's main.rs:23-66:
     model matrix = uniform scale 2 (:30-36), the renderer's default camera (renderer.rs:222-231), one directional light unless given.

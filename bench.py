@@ -42,8 +42,8 @@ def parse():
                                                 "textures) instead of the synthetic scene: loaded through art_scene_add_glb, set up like main.rs:23-66; the line then says data: \"real glb\". "
                                                 "Default: assets/*.glb if one is there (SURVEY.md 8d), else the synthetic scene")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="ring of per-frame streams / buffers like the reference's FrameData ring (renderer.rs:135, which keeps 3); "
-                                                                      "default on one GPU: 3 for a run of at most 32 steps (a fenced burst: the driver's --steps 20 makes 17 500 Mray/s through a ring of 3 -- the reference's own depth -- "
-                                                                      "and 16 200 through one of 16, whose sixteen frames fill and drain together), else 8 (19 650 over 1 000 steps; 16: 19 350; 3: 18 900: tools/ring_sweep.sh); "
+                                                                      "default on one GPU: 8 for every run (round 3 took 3 for runs of at most 32 steps: a still camera's 20-frame burst is 3 %% faster through 3 slots -- 0.164 against 0.169 ms a frame -- "
+                                                                      "but a camera or a model that moves costs 7-25 %% there and 1-3 %% here: tools/camera_leg_probe.py, profiles/README.md round 4; 1 000 steps: 19 650 with 8, 19 350 with 16, 18 900 with 3); "
                                                                       "12 launches when the frame is sharded")
     ap.add_argument("--ao", type=int, default=0, help="BASELINE config 5: N ray-traced AO rays per hit pixel after each frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,9 +56,11 @@ def parse():
     ap.add_argument("--plain", action="store_true", help="only the contract's timed region (profiling passes: no single-frame spans, no steady-state / camera-path legs, no CPU baseline)")
     ap.add_argument("--tuning", default="", help="A/B sweeps: ArtTuning fields for the benchmarked context, key=value[,key=value...] (include/art.h: frame_form, tree_builder, frame_waves, "
                                                  "block_order, split_alpha ...); the default -- none -- is the product")
-    ap.add_argument("--camera-path", type=int, default=8, help="N = 1 extra leg: the camera moves every frame along a closed path of this many poses (0 = skip); ray counts of every pose "
+    ap.add_argument("--camera-walk", type=int, default=64, help="N = 1 extra leg `camera_path`: the camera moves every frame the way the reference's does (main.rs:69-131: a key held down, a hand on the "
+                                                                "mouse) along a closed loop of this many poses (0 = skip); ray counts of every eighth pose are checked against the oracle's committed ones")
+    ap.add_argument("--camera-path", type=int, default=8, help="N = 1 extra leg `camera_jumps`: the camera JUMPS every frame along a closed path of this many poses 0.2 units / 15 degrees apart (0 = skip); ray counts of every pose "
                                                                "are checked against the oracle's committed ones")
-    ap.add_argument("--moving-model", type=int, default=8, help="N = 1 extra leg: one model of the scene (its last primitive) is moved and rotated before every frame along a closed path of this many "
+    ap.add_argument("--moving-model", type=int, default=64, help="N = 1 extra leg: one model of the scene (its last primitive) is moved and rotated before every frame along a closed path of this many "
                                                                 "poses (art_scene_set_model_matrix: a device refit in front of each frame, VkModel::set_model_matrix + the reference's per-frame TLAS); 0 = skip")
     ap.add_argument("--gather-launches", type=int, default=-1, help="N>1: ring slots (launches) per exchange; 0 = the whole ring (the slots are contiguous, so a group travels as one message "
                     "per peer); default: a quarter of the timed launches, at most the ring -- a run of a few launches then still overlaps its exchanges with its tracing "
@@ -95,8 +97,24 @@ def host_cores():
     return n
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started plainly (no launcher, no WORLD_SIZE): this process -- which has not touched the GPU and never will -- starts the N ranks the way the
+    driver does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`) as a CHILD process, relays its output
+    (rank 0's line is the job's) and leaves with its exit code.  (Never an exec: a process that initialised the GPU must not be replaced, and this one must not initialise it.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting the ranks as a child process: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     watchdog = args.watchdog_seconds if args.watchdog_seconds >= 0 else (300.0 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0.0)
     if watchdog > 0:
         import faulthandler
@@ -111,7 +129,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plainly: bench.py starts its own ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libart has no CPU fallback")
     if args.backend == "gloo":
@@ -138,7 +156,7 @@ def main():
         sc = scenes.sponza_like(args.detail)
         lights = scenes.sponza_lights(args.lights)
         sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-    F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (12 if world > 1 else (3 if args.steps <= 32 else 8))
+    F = max(1, min(22, args.frames_in_flight)) if args.frames_in_flight > 0 else (12 if world > 1 else 8)   # ONE depth for every one-GPU run, the driver's 20 steps and the long runs and the counter passes alike
     packed = world > 1 and args.gather == "packed"
     dedicated = world > 1 and args.compositor == "dedicated"
     G = world - 1 if dedicated else world           # shards of the frame = ranks that trace
@@ -350,19 +368,23 @@ def main():
         tag = {(1920, 1080, 1): "c2_sponza_like_1080p_1light", (3840, 2160, 4): "c3_sponza_like_2160p_4lights"}.get((W, H, args.lights)) if (args.scene == "sponza" and args.detail == 1.0 and not glb) else None
         if args.scene == "bistro" and args.detail == 1.0 and (W, H) == (1920, 1080) and not glb:
             tag = "c4_bistro_like_1080p_1light"
-        if extras and not args.ao and args.camera_path > 0:
-            poses = scenes.camera_path(sc, args.camera_path)
+        def camera_leg(poses, gold, every, protocol):
             cams = [renderer.Camera(p["pos"], p["dir"], W / H, p["fovy"], p["znear"], p["zfar"]) for p in poses]
-            gold_path = os.path.join(ROOT, "tests", "golden", f"{tag}.camera_path_{args.camera_path}.json") if tag else None
-            gold = json.load(open(gold_path)) if gold_path and os.path.exists(gold_path) else None
-            rays_pose = []
-            for i, cam in enumerate(cams):            # every pose once alone: its ray counts, against the oracle's committed ones
+            rays_pose, checked = [], 0
+            for i, cam in enumerate(cams):            # the poses once alone: their ray counts, against the oracle's committed ones (every `every`-th pose has one)
+                if i % every:
+                    rays_pose.append(None)
+                    continue
                 r._camera = cam
                 r.upload_state(); r.trace(); r.sync()
                 ps = r.stats()
                 if gold:
-                    assert (ps["shadow_rays"], ps["hit_pixels"]) == (gold["poses"][i]["shadow_rays"], gold["poses"][i]["hit_pixels"]), f"camera path pose {i}: GPU ray counts differ from the oracle's"
+                    g = gold["poses"][i // every]
+                    assert (ps["shadow_rays"], ps["hit_pixels"]) == (g["shadow_rays"], g["hit_pixels"]), f"camera pose {i}: GPU ray counts differ from the oracle's"
+                    checked += 1
                 rays_pose.append(ps["primary_rays"] + ps["shadow_rays"])
+            known = [x for x in rays_pose if x is not None]
+            rays_pose = [x if x is not None else sum(known) / len(known) for x in rays_pose]   # (poses in between: the mean of the counted ones -- they differ by a thousandth)
 
             def moving(n):
                 for i in range(n):
@@ -376,8 +398,25 @@ def main():
             fence()
             cwall = time.perf_counter() - c0
             rays_moved = sum(rays_pose[i % len(cams)] for i in range(args.steps))
-            campath = dict(poses=len(cams), value=rays_moved / cwall / 1e6, unit="Mray/s", ms_per_step=cwall * 1e3 / args.steps, rays_per_frame_min=min(rays_pose), rays_per_frame_max=max(rays_pose),
-                           ray_counts_checked_against_oracle=bool(gold), protocol="art_set_camera before every frame, fenced on both sides like `value`")
+            return dict(poses=len(cams), value=rays_moved / cwall / 1e6, unit="Mray/s", ms_per_step=cwall * 1e3 / args.steps, rays_per_frame_min=min(rays_pose), rays_per_frame_max=max(rays_pose),
+                        ray_counts_checked_against_oracle=checked, protocol=protocol)
+
+        def gold_of(name):
+            path = os.path.join(ROOT, "tests", "golden", f"{tag}.{name}.json") if tag else None
+            return json.load(open(path)) if path and os.path.exists(path) else None
+        camjumps = None
+        if extras and not args.ao and args.camera_walk > 0:
+            # camera_path: the reference's own camera motion (main.rs:69-131) -- a key held down and a hand on the mouse, at the frame rate this library renders at
+            campath = camera_leg(scenes.camera_walk(sc, args.camera_walk), gold_of(f"camera_walk_{args.camera_walk}"), 8,
+                                 "art_set_camera before every frame, fenced on both sides like `value`; the camera moves as the reference's does (main.rs:80-124: 0.002 units per ms of frame time along the view "
+                                 "direction, 0.002 rad per mouse count at 1 000 counts / s) at 6 000 frames / s -- 0.00033 units and 0.00033 rad a frame, a closed loop out and back")
+        if extras and not args.ao and args.camera_path > 0:
+            # camera_jumps: a pose 0.2 units and 15 degrees from the last one EVERY frame (round 1-3's camera_path): no frame in flight shares its heavy blocks with its neighbours -- a stress
+            # test of what depends on frame-to-frame coherence (the wave plan), not something a render loop does
+            camjumps = camera_leg(scenes.camera_path(sc, args.camera_path), gold_of(f"camera_path_{args.camera_path}"), 1,
+                                  "art_set_camera before every frame with a pose 0.2 units / 15 degrees away from the last (a closed path of 8 poses), fenced on both sides like `value`: a stress leg -- "
+                                  "nothing a frame learns about its heavy blocks holds for the next")
+        if campath or camjumps:
             r._camera = renderer.Camera(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
             r.upload_state()
 
@@ -386,7 +425,7 @@ def main():
         if extras and not args.ao and not glb and args.moving_model > 0 and len(sc.primitives) > 1:
             import math
             r.close()                     # the benchmarked context is done (its streams go back to the pool: two rings of 16 would share the 16 hardware queues)
-            mv = renderer.Renderer((W, H), device=local_rank, frames_in_flight=F, tuning=tuning)
+            mv = renderer.Renderer((W, H), device=local_rank, frames_in_flight=F, tuning=tuning, dynamic_scene=True)   # (the host says its models will move: the ring of structure versions is made by the build)
             mv.add_model(sc.primitives[:-1])
             mv.add_model(sc.primitives[-1:])
             cam = mv.camera_mut()
@@ -397,10 +436,11 @@ def main():
             mv.upload_state()
             base = np.vstack([np.asarray(sc.primitives[-1].model, np.float64).reshape(3, 4), [0, 0, 0, 1]])
             poses = []
-            for i in range(args.moving_model):   # a closed loop: rotation about y, a small orbit
-                a = 2 * math.pi * i / args.moving_model
+            for i in range(args.moving_model):   # a closed loop, out and back: the model is carried along x and turned about y at 2 units / s and 2 rad / s -- the speeds the reference's own
+                k = min(i, args.moving_model - i)  # controls move things at (main.rs:80-124) -- at the 6 000 frames / s this library renders the scene at: 0.00033 units and 0.00033 rad a frame
+                a = 2.0 / 6000.0 * k
                 ry = np.array([[math.cos(a), 0, math.sin(a), 0], [0, 1, 0, 0], [-math.sin(a), 0, math.cos(a), 0], [0, 0, 0, 1]])
-                t = np.eye(4); t[:3, 3] = (0.15 * math.cos(a) - 0.15, 0.05 * math.sin(2 * a), 0.15 * math.sin(a))
+                t = np.eye(4); t[:3, 3] = (2.0 / 6000.0 * k, 0.0, 0.0)
                 poses.append(np.ascontiguousarray((t @ ry @ base)[:3], np.float32))
             model = mv.models_mut()[1]
             rays_pose, refit_alone = [], []
@@ -432,7 +472,9 @@ def main():
             moving_model = dict(poses=len(poses), value=sum(rays_pose[i % len(poses)] for i in range(args.steps)) / mwall / 1e6, unit="Mray/s", ms_per_step=mwall * 1e3 / args.steps,
                                 refit_ms=refit_alone[len(refit_alone) // 2], refit_ms_max=refit_alone[-1], refits=ms_["refits"], rebuilds=ms_["rebuilds"], refit_cost_ratio=ms_["refit_cost_ratio"],
                                 moving_triangles=sc.primitives[-1].n_tris, build_ms=ms_["build_ms"], residency_change_ms=sorted(residency)[len(residency) // 2],
-                                protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, rotated and carried round a loop), fenced on both sides like `value`; "
+                                first_move_ms=ms_["first_move_ms"], versions_ms=ms_["versions_ms"],
+                                protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, 62 % of its triangles, carried and turned at 2 units / s and 2 rad / s -- 0.00033 a frame -- out and back), fenced on both sides like `value`; "
+                                         "versions_ms = host time of making the ring of structure versions (inside art_scene_build: ART_FLAG_DYNAMIC_SCENE; first_move_ms = what the first moved frame paid, 0 then); "
                                          "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses; "
                                          "residency_change_ms = the same for the model leaving / re-entering the structure (art_scene_set_primitive_enabled: no build)")
             mv.close()
@@ -560,11 +602,12 @@ def main():
                                          f"{counts['launches_per_gather'] * B} frames per exchange") + f", {F * B} frames in flight"},
             "frames_per_s": args.steps / wall, "rays_per_frame": rays_total, "frames_in_flight": F * B, "frames_per_launch": B,
             "steady_state": dict(steady, value=rays_total / (steady["ms_per_step"] * 1e-3) / 1e6, unit="Mray/s") if steady else None,
-            "camera_path": campath, "moving_model": moving_model, "refit_ms": moving_model["refit_ms"] if moving_model else None,
+            "camera_path": campath, "camera_jumps": camjumps, "moving_model": moving_model, "refit_ms": moving_model["refit_ms"] if moving_model else None,
             "stage_ms": stage, "frame_ms_one_frame_alone": alone, "build_ms": st["build_ms"], "settle_frames": settle_launches * B,
             "tuning": tuning, "gathered_frame_equals_single_gpu_frame": frame_ok, "gathers": counts["gathers"] if counts else None,
             **({("value_rank0_root" if other["placement"] == "rank0" else "value_spread_roots"): other.get("value"), "other_placement": other} if other else {}),
             "roofline": roof, "cpu_baseline": cpu,
+            "degraded": bool(bailing), "value_placement": (main_pl if world > 1 else None),   # degraded: the second placement was given up (its stacks are on stderr) -- `value` is then value_placement's, whatever --roots asked for
         }
         print(json.dumps(line), flush=True)
         if world > 1 and not bailing:
@@ -576,11 +619,44 @@ def main():
     order = placements if world == 1 else sorted(placements, key=lambda p_: p_ != "rank0")
     jobs = {}
 
-    def bail(pl_):
+    # Whether the second placement is given up is AGREED between the ranks, through a small key-value store of the job's own (rank 0 serves it): a rank that finishes its second
+    # placement says so and waits until every rank has said so -- or until one has bailed, then it bails too -- before it enters any later collective; a rank whose timer fires
+    # says "bailed" first.  (Round 3: every rank decided by its own timer; one that finished a moment before its peers' timers fired went on into a collective they had left.)
+    store = None
+    if world > 1 and len(order) > 1 and args.second_placement_seconds > 0:
+        from datetime import timedelta
+        store = dist.TCPStore("127.0.0.1", int(os.environ.get("MASTER_PORT", "29500")) + 17, world, rank == 0, timeout=timedelta(seconds=30))
+
+    def bail(pl_):   # (a timer thread, or the main thread of a rank that learns of a peer's bail)
+        try:
+            if store is not None:
+                store.add("bailed", 1)
+        except Exception:
+            pass
+        import faulthandler
+        print(f"[bench] rank {rank}: placement '{pl_}' did not finish within {args.second_placement_seconds:.0f} s; this rank's threads:", file=sys.stderr, flush=True)
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)   # where every rank stood: the cause is read from these stacks, never from a retry
         if rank == 0:
             finish(order[0], dict(placement=pl_, error=f"did not finish within {args.second_placement_seconds:.0f} s: this line is the other placement's alone"), bailing=True)
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        os._exit(0)   # rank 0 has printed a valid line that says "degraded": true and whose placement `value` is; a non-zero code on any rank would make the launcher fail the
+                      # whole job and the driver drop that measurement with it (the stacks above are the diagnosis)
+
+    def agree_done(pl_):   # every rank finished the second placement, or all give it up together
+        if store is None:
+            return
+        try:
+            store.add("done", 1)
+            while True:
+                if int(store.add("bailed", 0)) > 0:
+                    bail(pl_)
+                if int(store.add("done", 0)) >= world:
+                    return
+                time.sleep(0.05)
+        except SystemExit:
+            raise
+        except Exception:      # the store went away with rank 0: it bailed
+            bail(pl_)
     for i_, pl in enumerate(order):
         guard = None
         if i_ > 0 and args.second_placement_seconds > 0:
@@ -591,6 +667,7 @@ def main():
         jobs[pl] = run_job(pl)
         if guard:
             guard.cancel()
+            agree_done(pl)
 
     def describe(o_, pl_):
         return dict(placement=pl_, value=o_["value"], unit="Mray/s", ms_per_step=o_["ms_per_step"], gathered_frame_equals_single_gpu_frame=o_["frame_ok"], gathers=o_["counts"]["gathers"],

@@ -88,6 +88,8 @@ typedef struct ArtConfig {
                                   * geometry) are dealt to 4 or 16 waves in the following frames.  The image does not depend on it. */
 #define ART_FLAG_TILE_OUTPUT 32u /* write the compact tile buffer even when the frame is not sharded (shard_count <= 1: one shard owning every tile): a job of ONE rank
                                   * then runs the whole art_mgpu_* path -- gather from itself, un-tile -- which is how the RCCL transport is exercised on a one-GPU machine */
+#define ART_FLAG_DYNAMIC_SCENE 64u /* the host will move models (art_scene_set_model_matrix) or switch them in and out (art_scene_set_primitive_enabled): art_scene_build also makes the
+                                   * ring of structure versions a refit writes into (ArtStats.first_move_ms otherwise falls into the first frame after the first move) */
 #define ART_FLAG_KEEP_DEBUG 1u /* keep per-pixel hit records / shadow bits readable (art_read_hits, art_read_shadow_bits: include/art_parity.h) */
 
 typedef struct ArtStats {
@@ -107,6 +109,8 @@ typedef struct ArtStats {
     float refit_ms;             /* last refit after art_scene_set_model_matrix, device time (triangle records + every box above them) */
     float refit_cost_ratio;     /* surface-area cost of the refitted tree over the cost of the tree as built (the latest refit whose figure has arrived); 1 = as built */
     uint32_t refits, rebuilds;  /* refits since art_create; builds art_trace started by itself because refit_cost_ratio passed ArtTuning.refit_rebuild_ratio (include/art_parity.h; default 2) */
+    float first_move_ms;        /* host time art_trace spent making the ring of structure versions at the first move of a built scene (0 with ART_FLAG_DYNAMIC_SCENE: art_scene_build made it, inside versions_ms) */
+    float versions_ms;          /* host time of making that ring, wherever it was made */
 } ArtStats;
 
 typedef struct ArtContext ArtContext;

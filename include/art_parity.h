@@ -43,6 +43,8 @@ typedef struct ArtTuning {
     float refit_rebuild_ratio;  /* art_trace rebuilds instead of refitting once ArtStats.refit_cost_ratio exceeds this (0 = 2.0; negative: never) */
     uint32_t trace_leaf_batch;  /* persistent per-ray tracer: lanes that must be waiting for a triangle test before the wave runs one, 1..64 (0 = presets: 1, AO rays 8) */
     float beam_fat;             /* beam node steps: a shadow packet whose ray origins spread further than this along an axis (world units) asks every ray instead (0 = 0.25; negative: never) */
+    uint32_t plan_moving_interval; /* wave plan: frames between two looks at the waves while the camera / the lights change every frame (0 = 32) */
+    uint32_t refit_streams;     /* moving models: streams of their own the refits run on, beside the frames of the ring slot they precede (0 = min(frames in flight, 4); 0xFFFFFFFF: none -- every refit on its frame's stream, in front of it) */
 } ArtTuning;
 int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
 /* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */
@@ -108,6 +110,10 @@ int32_t art_timestamp_elapsed(ArtContext *ctx, float *ms);
 /* device time per stage (HIP events on the context's stream) summed over the frames traced since the previous call
  * (at most the last 128): sums_ms = primary, shade, shadow, accumulate, whole frame */
 int32_t art_collect_timings(ArtContext *ctx, float sums_ms[5], uint32_t *n_frames);
+/* traces ONE frame with the step-counting instance of the fused frame, waits for it and returns what every wave of that launch did:
+ * items[2*i] = 8x8 pixel block (local pixel id / 64), items[2*i+1] = mask over its sixteen 2x2 cells (0: an idle wave), steps[i] = packet steps
+ * (nodes + triangles visited, all walks of the wave).  *n = waves of the launch; at most cap are copied.  (tools/step_hist.py) */
+int32_t art_sample_wave_steps(ArtContext *ctx, uint32_t *items, uint32_t *steps, uint32_t cap, uint32_t *n);
 
 
 /* groups of launches of an ArtMgpu whose exchange has not been submitted yet (their frames may still run) and launches of the group that is still open.

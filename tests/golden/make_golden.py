@@ -43,6 +43,20 @@ def main():
         out = render(c, n, n, c.lights, packets=True)
         np.savez_compressed(os.path.join(HERE, f"cornell_{n}.npz"), color=out["color"], depth=out["depth"], normal=out["normal"])
         json.dump(out["stats"], open(os.path.join(HERE, f"cornell_{n}.stats.json"), "w"), indent=1)
+    if "--camera-walk" in sys.argv:   # bench.py --camera-walk 64 on config 2: the ray counts of every eighth pose of the reference's camera motion (the GPU's must equal them)
+        s = scenes.sponza_like()
+        S2 = orc.Scene(s.primitives, morton_bits=30)
+        L2 = scenes.sponza_lights(1)
+        poses = []
+        for i, cp in enumerate(scenes.camera_walk(s, 64)):
+            if i % 8:
+                continue
+            cam = orc.camera_from_params(cp["pos"], cp["dir"], 1920 / 1080, cp["fovy"], cp["znear"], cp["zfar"])
+            st = S2.render(cam, orc.make_lights(L2), 1, 1920, 1080, threads=8)["stats"]
+            poses.append(dict(index=i, pos=cp["pos"], dir=cp["dir"], **{k: st[k] for k in ("primary_rays", "shadow_rays", "hit_pixels", "nonfinite_pixels")}))
+        json.dump(dict(config="c2_sponza_like_1080p_1light", every=8, poses=poses), open(os.path.join(HERE, "c2_sponza_like_1080p_1light.camera_walk_64.json"), "w"), indent=1)
+        print("camera walk", [(p["index"], p["shadow_rays"], p["hit_pixels"]) for p in poses])
+        return
     if "--full" in sys.argv:
         s = scenes.sponza_like()
         for tag, (w, h), lights in (("c2_sponza_like_1080p_1light", (1920, 1080), scenes.sponza_lights(1)),

@@ -250,3 +250,17 @@ def test_rust_binding_is_generated_from_the_header_and_complete():
     for name, size in (("ArtVertex", 48), ("ArtLight", 80), ("ArtCamera", 268), ("ArtConfig", 36)):
         assert f"size_of::<{name}>() == {size})" in rs
     assert "#[repr(C, packed)] #[derive(Clone, Copy)]\npub struct ArtCamera" in rs
+
+
+def test_bench_started_plainly_spawns_its_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver starts its one-GPU run): the parent starts torch.distributed.run with two fresh children
+    as a CHILD process and relays its exit code -- here, without a GPU, both ranks get as far as "needs an MI355X" (libart has no CPU fallback), which is the proof that both ran"""
+    import subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU box runs this as tests/test_mgpu.py::test_eight_ranks_with_the_drivers_arguments_through_both_placements")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "starting the ranks as a child process" in out.stderr
+    assert out.stderr.count("bench.py needs an MI355X") >= 2, out.stderr[-3000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -20,7 +20,7 @@ a = ap.parse_args()
 sc = scenes.bistro_like(1.0) if a.scene == "bistro" else scenes.sponza_like(1.0)
 lights = sc.lights if a.scene == "bistro" else scenes.sponza_lights(1)
 j = a.mover % len(sc.primitives)
-r = renderer.Renderer((a.width, a.height), frames_in_flight=a.frames_in_flight, tuning={"as_versions": a.versions, "refit_rebuild_ratio": -1.0})
+r = renderer.Renderer((a.width, a.height), frames_in_flight=a.frames_in_flight, tuning={"as_versions": a.versions, "refit_rebuild_ratio": -1.0, "log": 1})
 r.add_model([p for i, p in enumerate(sc.primitives) if i != j]); r.add_model([sc.primitives[j]])
 cam = r.camera_mut()
 cam.set_pos(sc.camera["pos"]); cam.set_dir(sc.camera["dir"]); cam.set_fovy(sc.camera["fovy"]); cam.set_znear(sc.camera["znear"]); cam.set_zfar(sc.camera["zfar"])
