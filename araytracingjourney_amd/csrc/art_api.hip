@@ -450,7 +450,9 @@ static int32_t plan_reset(ArtContext *c) {
     P.fixed_steps = t.split_fixed_steps;
     P.alpha = t.split_alpha > 0.f ? t.split_alpha : 0.7f;
     const uint32_t hwq = t.hw_queues ? t.hw_queues : 4;   // HIP's default number of hardware queues per process; a host that raises GPU_MAX_HW_QUEUES says so in ArtTuning
-    P.in_flight = std::max(1u, std::min(c->F, hwq));
+    // (at most 4: a ring of 8 hides a straggler while it stays full, but a run's last frames drain without neighbours -- over the driver's 20 steps a plan made for 3-4 launches
+    //  in flight is worth 4 %, over 1 000 steps it costs 1 %: profiles/README.md round 4)
+    P.in_flight = std::max(1u, std::min(std::min(c->F, hwq), 4u));
     const uint32_t n64 = c->n_local / 64;
     P.cap = n64 + n64 / 2 + 64;       // at most half as many waves again
     std::vector<uint2> first;

@@ -258,7 +258,7 @@ def test_bench_started_plainly_spawns_its_ranks():
     import subprocess, sys
     import torch
     if torch.cuda.is_available():
-        pytest.skip("a GPU box runs this as tests/test_mgpu.py::test_eight_ranks_with_the_drivers_arguments_through_both_placements")
+        pytest.skip("a GPU box runs this as tests/test_mgpu.py::test_many_ranks_with_the_drivers_arguments_through_both_placements")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode != 0 and "starting the ranks as a child process" in out.stderr

@@ -219,22 +219,23 @@ def test_a_second_placement_that_hangs_still_leaves_the_first_ones_line():
 
 
 @pytest.mark.gpu
-def test_eight_ranks_with_the_drivers_arguments_through_both_placements():
-    """the driver's own `--gpus 8 --steps 20 --warmup 5`, started PLAINLY (bench.py spawns its ranks): 4 frames per launch, 5 timed launches, one launch per exchange, so a
-    group's frames fall to ranks 0-3 or 4-7 in turn (nf_cap = 1: the corner of art_mgpu.hip:112-128 no smaller job reaches) -- eight child processes sharing the one GPU (six at
-    most may hold it at once on the test box and this test process is one of them, so the job runs with FIVE ranks there unless ART_TEST_RANKS says otherwise: 4 frames
-    per launch over 5 ranks is the same corner), the exchange through the gloo hook, BOTH placements, every assembling rank checking the
-    newest frame it holds against an unsharded render bit for bit"""
-    ranks = int(os.environ.get("ART_TEST_RANKS", "5"))
+@pytest.mark.parametrize("extra", [[], ["--frames-per-launch", "2"]], ids=["4-frames-per-launch", "2-frames-per-launch-roots-alternate"])
+def test_many_ranks_with_the_drivers_arguments_through_both_placements(extra):
+    """the driver's own `--gpus N --steps 20 --warmup 5`, started PLAINLY (bench.py spawns its ranks): one launch per exchange, so a rank roots at most ONE frame of a group
+    (nf_cap = 1, art_mgpu.hip:112-128); with 2 frames per launch over 4 ranks a group's frames fall to ranks 0-1 and 2-3 in turn -- what 4 frames per launch do to ranks 0-3 and
+    4-7 of the driver's eight (the corner no smaller job reaches).  Four child processes share the one GPU: six processes at most may hold it at once on the test box, and this
+    test process and the launcher are two of them (ART_TEST_RANKS overrides: 8 on a box without that guard).  The exchange goes through the gloo hook, BOTH placements are timed,
+    every assembling rank checks the newest frame it holds against an unsharded render bit for bit"""
+    ranks = int(os.environ.get("ART_TEST_RANKS", "4"))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="4")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "20", "--warmup", "5", "--backend", "gloo", "--no-cpu-baseline", "--detail", "0.12",
-           "--width", "640", "--height", "360", "--settle-seconds", "0.05", "--watchdog-seconds", "250"]
+           "--width", "640", "--height", "360", "--settle-seconds", "0.05", "--watchdog-seconds", "250"] + extra
     out = _run_job(cmd, env, 420)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-6000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == ranks and line["steps"] == 20 and line["warmup"] == 5 and line["frames_per_launch"] == 4 and line["degraded"] is False and line["value_placement"] == "spread"
+    assert line["n_gpus"] == ranks and line["steps"] == 20 and line["warmup"] == 5 and line["frames_per_launch"] == (2 if extra else 4) and line["degraded"] is False and line["value_placement"] == "spread"
     assert line["gathered_frame_equals_single_gpu_frame"] is True and line["other_placement"]["gathered_frame_equals_single_gpu_frame"] is True
     assert line["gathers"] >= 5 and line["other_placement"]["gathers"] >= 5 and line["value"] > 0 and line["value_rank0_root"] > 0
     assert "starting the ranks as a child process" in out.stderr
