@@ -10,7 +10,6 @@ LIB_PATH = os.environ.get("ART_LIB_PATH") or os.path.join(_HERE, "libart.so")   
 ART_OK, ART_E_INVALID, ART_E_STATE, ART_E_NO_DEVICE, ART_E_HIP, ART_E_NOMEM = 0, -1, -2, -3, -4, -5
 ART_FLAG_KEEP_DEBUG = 1
 ART_FLAG_PACKED_TILES = 4  # sharded: the gather payload is the B10G11R11 colour (4 B per pixel)
-ART_FLAG_DEVICE_TREE = 8  # the PREFER_FAST_TRACE tree by PLOC instead of the binned SAH (both built on the device)
 ART_FLAG_FIXED_WAVES = 16  # one wave per 8x8 block always (default: the adaptive wave plan of the fused frame)
 ART_FLAG_TILE_OUTPUT = 32  # compact tile buffer even for an unsharded frame (a one-rank art_mgpu job)
 ART_FLAG_DYNAMIC_SCENE = 64  # models will move / leave / re-enter: art_scene_build also makes the ring of structure versions (else the first moved frame does)
@@ -62,9 +61,9 @@ class ArtGlbCopyInfo(C.Structure):
 
 
 class ArtTuning(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("frame_form", "tree_builder", "frame_waves", "packet_wide", "primary_walk", "shadow_walk", "ao_walk", "block_order", "fixed_waves",
+    _fields_ = [(n, C.c_uint32) for n in ("frame_form", "tree_builder", "packet_wide", "primary_walk", "shadow_walk", "ao_walk", "block_order", "fixed_waves",
                                           "split_fixed_steps", "split_min_steps")] + [("split_alpha", C.c_float)] + \
-               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder", "as_versions")] + [("refit_rebuild_ratio", C.c_float), ("trace_leaf_batch", C.c_uint32), ("beam_fat", C.c_float), ("plan_moving_interval", C.c_uint32), ("refit_streams", C.c_uint32)]
+               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder", "as_versions")] + [("refit_rebuild_ratio", C.c_float), ("trace_leaf_batch", C.c_uint32), ("plan_moving_interval", C.c_uint32), ("refit_streams", C.c_uint32)]
 
 
 class ArtLayout(C.Structure):

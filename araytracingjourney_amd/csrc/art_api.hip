@@ -142,12 +142,10 @@ struct ArtContext {
     bool built = false, have_camera = false, frame_ready = false;
     // which of the equivalent forms this context runs: the defaults are the product, the others are reachable through art_set_tuning only (nothing reads the environment)
     ArtTuning tuning{};
-    int frame_waves = 8;      // occupancy target of the fused frame kernel's instance (6 | 7 | 8)
-    bool fused = true;        // packet frames run as ONE launch (k_frame); frame_form 1: the four staged launches
-    int tree_builder = 3;     // with fast_trace: 3 = binned SAH on the device (art_sahdev.hip), 1 = the same on the host threads (art_sah.hip), 2 = PLOC on the device (art_build.hip)
+    bool fused = true;        // the frame is ONE launch of packet walks (k_frame); frame_form 2: four staged launches, every ray by itself
+    int tree_builder = 3;     // with fast_trace: 3 = binned SAH on the device (art_sahdev.hip), 1 = the same on the host threads (art_sah.hip)
     bool fast_trace = true;   // rebuild the traversal tree with the binned SAH after the LBVH (ART_FLAG_FAST_BUILD: keep the Karras tree)
     bool packet_wide = true;  // packets walk the 128-byte 4-wide float nodes (half the dependent node fetches); false: the 64-byte binary nodes
-    bool packet_beam = false; // the fused frame's node steps test the packet's beam (art_trace.hip beam_walk); ArtTuning.packet_wide 3
     int kind_primary = 8, kind_shadow = 8, kind_ao = 4; // 8 = packet walk over the binary nodes (coherent rays: primary, shadow); per-ray walks (AO, queries): 2 binary, 4 wide quantised (measured: profiles/README.md)
     uint32_t macro = 2;       // XCD-aware launch order: macro-blocks of macro x macro tiles (0: identity)
     bool ao_entry = true;     // AO rays start at the per-pixel entry node (k_ao_entry)
@@ -743,7 +741,6 @@ int32_t art_create(const ArtConfig *cfg, ArtContext **out) {
     // the fused packet frame is the default at every ring depth (one frame at a time: 0.575 ms against 0.669 ms for the staged per-ray
     // kernels, profiles/README.md r1h); art_set_tuning selects the other forms
     c->fast_trace = !(cfg->flags & ART_FLAG_FAST_BUILD);
-    if (cfg->flags & ART_FLAG_DEVICE_TREE) c->tree_builder = 2;
     build_prewarm(c->main_stream()); sah_prewarm(c->main_stream());   // the builders' code objects are loaded here, once a process, not inside the first art_scene_build
     (void)hipGetLastError();
     *out = c;
@@ -775,9 +772,10 @@ int32_t art_destroy(ArtContext *c) {
 
 int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     if (!c || !t) return fail(ART_E_INVALID, "art_set_tuning: null argument");
-    auto walk_ok = [](uint32_t k) { return k == 0 || k == 2 || k == 4 || k == 8; };
-    if (t->frame_form > 2 || t->tree_builder > 1 || (t->frame_waves != 0 && (t->frame_waves < 6 || t->frame_waves > 8)) || !walk_ok(t->primary_walk) || !walk_ok(t->shadow_walk) || !walk_ok(t->ao_walk))
-        return fail(ART_E_INVALID, "art_set_tuning: frame_form 0..2, tree_builder 0..1, frame_waves 0|6|7|8, walks 0|2|4|8");
+    auto walk_ok = [](uint32_t k) { return k == 0 || k == 2 || k == 4; };
+    if ((t->frame_form != 0 && t->frame_form != 2) || t->tree_builder > 1 || t->packet_wide > 2 || !walk_ok(t->primary_walk) || !walk_ok(t->shadow_walk) || !walk_ok(t->ao_walk))
+        return fail(ART_E_INVALID, "art_set_tuning: frame_form 0|2, tree_builder 0..1, packet_wide 0..2, walks 0|2|4");
+    if (t->frame_form == 0 && (t->primary_walk || t->shadow_walk)) return fail(ART_E_INVALID, "art_set_tuning: the fused frame's rays are packets (primary_walk / shadow_walk choose the per-ray walks of frame_form 2)");
     if (t->as_versions > kMaxAsVersions || !(t->refit_rebuild_ratio == t->refit_rebuild_ratio)) return fail(ART_E_INVALID, "art_set_tuning: as_versions 0..8, refit_rebuild_ratio a number");
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
@@ -789,10 +787,8 @@ int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     if (t->shadow_walk) c->kind_shadow = (int)t->shadow_walk;
     if (t->ao_walk) c->kind_ao = (int)t->ao_walk;
     c->fast_trace = !(c->cfg.flags & ART_FLAG_FAST_BUILD);
-    c->tree_builder = (c->cfg.flags & ART_FLAG_DEVICE_TREE) ? 2 : (t->tree_builder == 1 ? 1 : 3);
-    c->frame_waves = t->frame_waves ? (int)t->frame_waves : 8;
-    c->packet_wide = t->packet_wide != 2;   // 0: the default (4-wide), 1: 4-wide, 2: binary, 3: 4-wide walked by the packet's beam
-    c->packet_beam = t->packet_wide >= 3 && t->packet_wide <= 5;   // 4: primary rays only, 5: shadow rays only
+    c->tree_builder = t->tree_builder == 1 ? 1 : 3;
+    c->packet_wide = t->packet_wide != 2;   // 0: the default (4-wide), 1: 4-wide, 2: binary
     c->macro = t->block_order == 0 ? 2u : (t->block_order == 1 ? 0u : t->block_order);
     c->ao_entry = t->ao_entry_off == 0;
     c->wide_on_host = t->wide_builder == 1;
@@ -959,13 +955,7 @@ int32_t art_scene_build(ArtContext *c) {
     if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "lbvh_build"); }
     if (c->fast_trace) { // PREFER_FAST_TRACE (vk_model.rs:968): the traversal nodes get a SAH-driven topology over the same leaves
         bool done = false;
-        if (c->tree_builder == 2) { // on the device (PLOC); a tree deeper than the walks' stacks allow (never seen) is rebuilt on the host
-            uint32_t depth = 0;
-            e = ploc_build(c->bvh, T, c->main_stream(), &depth);
-            if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "ploc_build"); }
-            done = depth <= 80;
-        }
-        if (!done && c->tree_builder == 3) { // the binned SAH on the device
+        if (c->tree_builder == 3) { // the binned SAH on the device
             e = sah_build_device(c->bvh, T, c->main_stream());
             if (e != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return hipfail(e, "sah_build_device"); }
             done = true;
@@ -1106,9 +1096,9 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S, uint32_t version) 
     FrameArgs a{};
     static_assert(sizeof(CameraArg) == sizeof(ArtCamera), "camera block layout");
     std::memcpy(&a.cam, &c->camera, sizeof(ArtCamera));
-    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p; a.fold_counters = c->kind_primary == 8 && c->kind_shadow == 8 && c->n_local != 0;
+    a.W = c->W; a.H = c->H; a.tile_list = c->d_tile_list.p; a.n_tiles_owned = (uint32_t)c->tile_list.size(); a.tiles_x = c->tiles_x; a.n_local = c->n_local; a.block_order = c->d_block_order.p;
     const AsPtrs as = as_ptrs(c, version); // the version of the acceleration structure this launch reads
-    a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.packet_beam = c->packet_beam; a.beam_primary = c->tuning.packet_wide != 5; a.beam_shadow = c->tuning.packet_wide != 4; a.beam_fat = c->tuning.beam_fat > 0.0f ? c->tuning.beam_fat : (c->tuning.beam_fat < 0.0f ? INFINITY : 0.25f); a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.tune = TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
+    a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.tune = TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
     a.n_lights = (uint32_t)c->lights.size();
     if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
     for (uint32_t i = 0; i < a.n_lights; i++) directional_constants(a.lights[i]);
@@ -1116,7 +1106,7 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S, uint32_t version) 
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
     a.color_tiles = c->tiled() ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)
     a.shadow_bits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) ? S.d_shadow_bits.p : nullptr;
-    a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0; a.frame_waves = c->frame_waves;
+    a.pix_bits = S.d_shadow_bits.p; a.keep_hits = (c->cfg.flags & ART_FLAG_KEEP_DEBUG) != 0;
     a.batch = c->B; a.tiles_stride = c->padded_tiles * kTilePixels;
     for (uint32_t i = 0; i + 1 < kMaxBatch; i++) std::memcpy(&a.cam_more[i], &c->cam_more[i], sizeof(ArtCamera));
     a.tile_xy = c->d_tile_xy.p; a.wave_items = c->plan.d_items[c->plan.cur].p; a.n_wave_items = c->plan.n_items[c->plan.cur]; a.wave_cost = nullptr; // art_trace sets it for the frames the wave plan samples
@@ -1151,14 +1141,14 @@ int32_t art_trace(ArtContext *c) {
     FrameArgs a = make_frame_args(c, S, ver);
     if (c->tiled()) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
-    if (c->B > 1 && (!fused || c->frame_waves < 8)) return fail(ART_E_STATE, "art_trace: several frames per launch need the default fused frame");
+    if (c->B > 1 && !fused) return fail(ART_E_STATE, "art_trace: several frames per launch need the default fused frame");
     hipEvent_t *ev = c->ev[c->frame_no % ArtContext::kRing];
     c->ev_fused[c->frame_no % ArtContext::kRing] = fused;
     if (c->graph_mode && !fused && S.ext_ring_n < 2) { // a fused frame is a single launch: nothing for a graph to save; alternating tile buffers change a kernel argument
         if (!S.graph) { // capture the frame once per slot; stage events are not part of it
             hipGraph_t g = nullptr;
             HIPC(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            hipError_t e = (a.fold_counters || fused) ? hipSuccess : hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s);
+            hipError_t e = fused ? hipSuccess : hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s);
             if (e == hipSuccess && a.n_local) { if (fused) launch_frame(a, s); else { launch_primary(a, s); launch_shade(a, s); launch_shadow(a, s); launch_accumulate(a, s); } e = hipGetLastError(); }
             hipError_t e2 = hipStreamEndCapture(s, &g);
             if (e != hipSuccess || e2 != hipSuccess) { if (g) (void)hipGraphDestroy(g); return hipfail(e != hipSuccess ? e : e2, "art_trace: graph capture"); }
@@ -1189,7 +1179,7 @@ int32_t art_trace(ArtContext *c) {
         return ART_OK;
     }
     S.done_alias = nullptr;
-    if (!a.fold_counters) HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s));
+    HIPC(hipMemsetAsync(S.d_counters.p, 0, kCounterWords * 4, s));   // the staged frame's work cursors and count slots
     HIPC(hipEventRecord(ev[0], s));
     if (a.n_local) launch_primary(a, s);
     HIPC(hipEventRecord(ev[1], s));

@@ -848,168 +848,12 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
 }
 
 
-// ---- PLOC: the PREFER_FAST_TRACE traversal tree built on the device ------------------------------------------------
-// Parallel locally-ordered clustering (Meister & Bittner 2018) over the LBVH's leaves, which are already in Morton order: every
-// cluster looks kPlocRadius neighbours to each side for the partner with the smallest merged surface area, mutual nearest
-// neighbours merge into a node, the survivors are compacted in order, until one cluster is left.  Node indices are handed out
-// from the top down (the last merge is node 0, the root), each round's nodes contiguous and in Morton order.  Node boxes are exact
-// min/max unions, so the frames are those of any other tree.
-constexpr int kPlocRadius = 16;
-struct PlocState { uint32_t n; uint32_t next_node; uint32_t max_depth; uint32_t pad; };
-
-__device__ __forceinline__ float merged_half_area(const float *lo, const float *hi, uint32_t a, uint32_t b) {
-    float dx = fmaxf(hi[3 * (size_t)a], hi[3 * (size_t)b]) - fminf(lo[3 * (size_t)a], lo[3 * (size_t)b]);
-    float dy = fmaxf(hi[3 * (size_t)a + 1], hi[3 * (size_t)b + 1]) - fminf(lo[3 * (size_t)a + 1], lo[3 * (size_t)b + 1]);
-    float dz = fmaxf(hi[3 * (size_t)a + 2], hi[3 * (size_t)b + 2]) - fminf(lo[3 * (size_t)a + 2], lo[3 * (size_t)b + 2]);
-    return dx * dy + dy * dz + dz * dx;
-}
-// nearest neighbour of every cluster inside the window (ties: the lower index, so that "mutual" is well defined)
-__global__ __launch_bounds__(256) void k_ploc_nearest(const PlocState *st, uint32_t radius, const float *__restrict__ lo, const float *__restrict__ hi, uint32_t *__restrict__ nearest) {
-    const uint32_t n = st->n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t b = i > radius ? i - radius : 0u, e = i + radius + 1 < n ? i + radius + 1 : n;
-    float best = 3.0e38f; uint32_t bj = i;
-    for (uint32_t j = b; j < e; j++) {
-        if (j == i) continue;
-        float d = merged_half_area(lo, hi, i, j);
-        if (d < best) { best = d; bj = j; }
-    }
-    nearest[i] = bj;
-}
-// flags: merge[i] = 1 when i starts a merged pair (i < nearest[i], mutual); keep[i] = 0 for the pair's second member
-__global__ __launch_bounds__(256) void k_ploc_flags(const PlocState *st, const uint32_t *__restrict__ nearest, uint32_t *__restrict__ merge, uint32_t *__restrict__ keep) {
-    const uint32_t n = st->n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t j = nearest[i];
-    bool mutual = j != i && nearest[j] == i;
-    merge[i] = mutual && i < j ? 1u : 0u;
-    keep[i] = mutual && i > j ? 0u : 1u;
-}
-// create the nodes, move the surviving clusters (merged or untouched) to their compacted places in the other buffer
-__global__ __launch_bounds__(256) void k_ploc_merge(PlocState *st, const uint32_t *__restrict__ nearest, const uint32_t *__restrict__ merge_scan, const uint32_t *__restrict__ keep_scan,
-                                                    const uint32_t *__restrict__ merge, const uint32_t *__restrict__ keep,
-                                                    const float *__restrict__ lo, const float *__restrict__ hi, const int32_t *__restrict__ ref, const uint32_t *__restrict__ depth, const uint32_t *__restrict__ cnt,
-                                                    float *__restrict__ lo2, float *__restrict__ hi2, int32_t *__restrict__ ref2, uint32_t *__restrict__ depth2, uint32_t *__restrict__ cnt2,
-                                                    int32_t *__restrict__ child, float *__restrict__ node_lo, float *__restrict__ node_hi, uint32_t *__restrict__ left_leaves) {
-    const uint32_t n = st->n, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !keep[i]) return;
-    const uint32_t dst = keep_scan[i];
-    if (merge[i]) {
-        const uint32_t j = nearest[i];
-        const uint32_t node = st->next_node - 1u - merge_scan[i]; // indices run downwards: the last merge of the build is node 0
-        float l[3], h[3];
-        for (int k = 0; k < 3; k++) { l[k] = fminf(lo[3 * (size_t)i + k], lo[3 * (size_t)j + k]); h[k] = fmaxf(hi[3 * (size_t)i + k], hi[3 * (size_t)j + k]); }
-        child[2 * (size_t)node] = ref[i]; child[2 * (size_t)node + 1] = ref[j];
-        for (int k = 0; k < 3; k++) { node_lo[3 * (size_t)node + k] = l[k]; node_hi[3 * (size_t)node + k] = h[k]; lo2[3 * (size_t)dst + k] = l[k]; hi2[3 * (size_t)dst + k] = h[k]; }
-        ref2[dst] = (int32_t)node;
-        uint32_t d = (depth[i] > depth[j] ? depth[i] : depth[j]) + 1u;
-        depth2[dst] = d; cnt2[dst] = cnt[i] + cnt[j];
-        left_leaves[node] = cnt[i]; // leaves under the first child: places the second child in the depth-first layout
-        atomicMax(&st->max_depth, d);
-    } else {
-        for (int k = 0; k < 3; k++) { lo2[3 * (size_t)dst + k] = lo[3 * (size_t)i + k]; hi2[3 * (size_t)dst + k] = hi[3 * (size_t)i + k]; }
-        ref2[dst] = ref[i]; depth2[dst] = depth[i]; cnt2[dst] = cnt[i];
-    }
-}
-// after the scans: the round's totals (last element + its flag) become the next round's state
-__global__ void k_ploc_advance(PlocState *st, const uint32_t *merge_scan, const uint32_t *keep_scan, const uint32_t *merge, const uint32_t *keep) {
-    uint32_t n = st->n;
-    uint32_t merged = merge_scan[n - 1] + merge[n - 1], kept = keep_scan[n - 1] + keep[n - 1];
-    st->next_node -= merged;
-    st->n = kept;
-}
-__global__ __launch_bounds__(256) void k_ploc_init(uint32_t T, int32_t *__restrict__ ref, uint32_t *__restrict__ depth, uint32_t *__restrict__ cnt) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T) { ref[i] = ~(int32_t)i; depth[i] = 0; cnt[i] = 1; }
-}
-// Depth-first layout (a node, then its whole first subtree, then the second): a walk that goes down the first child reads the next
-// 64 bytes.  place[node] is known for a round's nodes once the later rounds (their parents) are done: the first child sits at
-// place + 1, the second at place + (leaves under the first child).
-__global__ __launch_bounds__(256) void k_ploc_place(uint32_t first, uint32_t count, const int32_t *__restrict__ child, const uint32_t *__restrict__ left_leaves, uint32_t *__restrict__ place) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    uint32_t node = first + i, at = place[node];
-    int32_t c0 = child[2 * (size_t)node], c1 = child[2 * (size_t)node + 1];
-    if (c0 >= 0) place[c0] = at + 1u;
-    if (c1 >= 0) place[c1] = at + left_leaves[node];
-}
-__global__ __launch_bounds__(256) void k_ploc_permute(uint32_t NI, const uint32_t *__restrict__ place, const int32_t *__restrict__ child, const float *__restrict__ lo, const float *__restrict__ hi,
-                                                      int32_t *__restrict__ child2, float *__restrict__ lo2, float *__restrict__ hi2) {
-    uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= NI) return;
-    uint32_t at = place[n];
-    int32_t c0 = child[2 * (size_t)n], c1 = child[2 * (size_t)n + 1];
-    child2[2 * (size_t)at] = c0 >= 0 ? (int32_t)place[c0] : c0;
-    child2[2 * (size_t)at + 1] = c1 >= 0 ? (int32_t)place[c1] : c1;
-    for (int k = 0; k < 3; k++) { lo2[3 * (size_t)at + k] = lo[3 * (size_t)n + k]; hi2[3 * (size_t)at + k] = hi[3 * (size_t)n + k]; }
-}
-
 void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s) { // traversal records from l.trav_child / trav_lo / trav_hi
     const uint32_t NI = T - 1;
     k_emit_nodes<<<(NI + 255) / 256, 256, 0, s>>>(T, l.trav_child, l.trav_lo, l.trav_hi, l.leaf_lo, l.leaf_hi, l.nodes);
 }
 
-// returns hipSuccess with *depth_out = the tree's depth (the caller falls back to another builder when it exceeds the walks' stacks)
-hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out) {
-    *depth_out = 0;
-    if (T < 3) return hipSuccess;
-    const uint32_t NI = T - 1, B = 256;
-    const uint32_t radius = kPlocRadius; // radius 2 .. 128 all measured within 15.4-15.9 Gray/s (profiles/README.md)
-    float *lo[2] = {nullptr, nullptr}, *hi[2] = {nullptr, nullptr};
-    int32_t *ref[2] = {nullptr, nullptr};
-    uint32_t *cnt[2] = {nullptr, nullptr}, *left_leaves = nullptr, *place = nullptr; int32_t *child_t = nullptr; float *lo_t = nullptr, *hi_t = nullptr;
-    std::vector<std::pair<uint32_t, uint32_t>> rounds; // (first node, count) created per round
-    uint32_t *depth[2] = {nullptr, nullptr}, *nearest = nullptr, *merge = nullptr, *keep = nullptr, *merge_scan = nullptr, *keep_scan = nullptr;
-    PlocState *st = nullptr; void *tmp = nullptr; size_t tmp_bytes = 0;
-    hipError_t err = hipSuccess;
-    auto body = [&]() -> hipError_t {
-        for (int k = 0; k < 2; k++) { HIPQ(hipMalloc(&lo[k], (size_t)T * 12)); HIPQ(hipMalloc(&hi[k], (size_t)T * 12)); HIPQ(hipMalloc(&ref[k], (size_t)T * 4)); HIPQ(hipMalloc(&depth[k], (size_t)T * 4)); HIPQ(hipMalloc(&cnt[k], (size_t)T * 4)); }
-        HIPQ(hipMalloc(&left_leaves, (size_t)NI * 4)); HIPQ(hipMalloc(&place, (size_t)NI * 4)); HIPQ(hipMalloc(&child_t, (size_t)NI * 8)); HIPQ(hipMalloc(&lo_t, (size_t)NI * 12)); HIPQ(hipMalloc(&hi_t, (size_t)NI * 12));
-        HIPQ(hipMalloc(&nearest, (size_t)T * 4)); HIPQ(hipMalloc(&merge, (size_t)T * 4)); HIPQ(hipMalloc(&keep, (size_t)T * 4));
-        HIPQ(hipMalloc(&merge_scan, (size_t)T * 4)); HIPQ(hipMalloc(&keep_scan, (size_t)T * 4)); HIPQ(hipMalloc(&st, sizeof(PlocState)));
-        HIPQ(lbvh_claim_trav(l, NI));
-        HIPQ(rocprim::exclusive_scan(nullptr, tmp_bytes, merge, merge_scan, 0u, T, rocprim::plus<uint32_t>(), s));
-        HIPQ(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-        HIPQ(hipMemcpyAsync(lo[0], l.leaf_lo, (size_t)T * 12, hipMemcpyDeviceToDevice, s));
-        HIPQ(hipMemcpyAsync(hi[0], l.leaf_hi, (size_t)T * 12, hipMemcpyDeviceToDevice, s));
-        k_ploc_init<<<(T + B - 1) / B, B, 0, s>>>(T, ref[0], depth[0], cnt[0]);
-        PlocState h0{T, NI, 0, 0};
-        HIPQ(hipMemcpyAsync(st, &h0, sizeof(h0), hipMemcpyHostToDevice, s));
-        uint32_t n = T, next_node = NI; int cur = 0;
-        for (int round = 0; n > 1 && round < 4096; round++) {
-            const uint32_t g = (n + B - 1) / B;
-            k_ploc_nearest<<<g, B, 0, s>>>(st, radius, lo[cur], hi[cur], nearest);
-            k_ploc_flags<<<g, B, 0, s>>>(st, nearest, merge, keep);
-            size_t tb = tmp_bytes;
-            HIPQ(rocprim::exclusive_scan(tmp, tb, merge, merge_scan, 0u, n, rocprim::plus<uint32_t>(), s));
-            tb = tmp_bytes;
-            HIPQ(rocprim::exclusive_scan(tmp, tb, keep, keep_scan, 0u, n, rocprim::plus<uint32_t>(), s));
-            k_ploc_merge<<<g, B, 0, s>>>(st, nearest, merge_scan, keep_scan, merge, keep, lo[cur], hi[cur], ref[cur], depth[cur], cnt[cur], lo[cur ^ 1], hi[cur ^ 1], ref[cur ^ 1], depth[cur ^ 1], cnt[cur ^ 1],
-                                         child_t, lo_t, hi_t, left_leaves);
-            k_ploc_advance<<<1, 1, 0, s>>>(st, merge_scan, keep_scan, merge, keep);
-            PlocState hs;
-            HIPQ(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, s));
-            HIPQ(hipStreamSynchronize(s));
-            if (hs.n >= n) return hipErrorUnknown; // every round merges at least the globally closest pair
-            rounds.push_back({hs.next_node, next_node - hs.next_node});
-            n = hs.n; next_node = hs.next_node; cur ^= 1; *depth_out = hs.max_depth;
-        }
-        // parents before children: the rounds backwards
-        HIPQ(hipMemsetAsync(place, 0, 4, s)); // the root (node 0) stays first
-        for (size_t r = rounds.size(); r-- > 0;)
-            if (rounds[r].second) k_ploc_place<<<(rounds[r].second + B - 1) / B, B, 0, s>>>(rounds[r].first, rounds[r].second, child_t, left_leaves, place);
-        k_ploc_permute<<<(NI + B - 1) / B, B, 0, s>>>(NI, place, child_t, lo_t, hi_t, l.trav_child, l.trav_lo, l.trav_hi);
-        HIPQ(hipGetLastError());
-        k_emit_nodes<<<(NI + B - 1) / B, B, 0, s>>>(T, l.trav_child, l.trav_lo, l.trav_hi, l.leaf_lo, l.leaf_hi, l.nodes);
-        HIPQ(hipGetLastError());
-        HIPQ(hipStreamSynchronize(s));
-        return hipSuccess;
-    };
-    err = body();
-    for (int k = 0; k < 2; k++) { hipFree(lo[k]); hipFree(hi[k]); hipFree(ref[k]); hipFree(depth[k]); hipFree(cnt[k]); }
-    hipFree(left_leaves); hipFree(place); hipFree(child_t); hipFree(lo_t); hipFree(hi_t);
-    hipFree(nearest); hipFree(merge); hipFree(keep); hipFree(merge_scan); hipFree(keep_scan); hipFree(st); hipFree(tmp);
-    return err;
-}
+// (Rounds 2 and 3 also built the traversal tree by parallel locally-ordered clustering over the Morton-ordered leaves -- ART_FLAG_DEVICE_TREE: 15 / 44 ms builds at 96-97 % of
+// the SAH tree's ray rate -- until the binned SAH itself ran on the device in 3 / 11 ms (art_sahdev.hip); removed in round 4 with the other forms that lost.)
 
 } // namespace art

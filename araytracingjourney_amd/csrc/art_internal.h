@@ -133,8 +133,6 @@ hipError_t lbvh_build(const BuildInputs &in, Lbvh &out, hipStream_t s, bool node
 hipError_t wide_build(Lbvh &l, uint32_t T, hipStream_t s, bool on_host = false); // level by level on the device, or the one-thread host loop (A/B)
 // PREFER_FAST_TRACE: rebuilds l.nodes as a binned-SAH tree over the same leaves (host threads); frames are unchanged by construction
 hipError_t sah_build(Lbvh &l, uint32_t T, hipStream_t s);
-// the same purpose on the device: parallel locally-ordered clustering over the Morton-ordered leaves; *depth_out = depth of the tree
-hipError_t ploc_build(Lbvh &l, uint32_t T, hipStream_t s, uint32_t *depth_out);
 // the binned SAH of sah_build, level by level on the device (art_sahdev.hip)
 hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s);
 void launch_emit_nodes(Lbvh &l, uint32_t T, hipStream_t s);
@@ -202,10 +200,8 @@ struct FrameArgs {
     const uint32_t *block_order; // [n_local / 256] launch block -> 256-pixel block (XCD-aware order, art_api.hip setup_frame)
     const DevNode *nodes; const DevNode4 *wide; const DevNodeW *widef; const DevTri *tris; const DevShadeTri *shade_tris; const DevPrim *prims; const uint32_t *tex_pool;
     bool packet_wide;          // packet walks use the 128-byte 4-wide nodes (else the binary nodes)
-    bool packet_beam;          // ... and the fused frame's node steps test the packet's beam (interval bounds on 32 lanes) instead of every ray against every box
-    bool beam_primary, beam_shadow; float beam_fat;   // which walks take the beam form; the largest spread of a shadow packet's origins (world units) that still does
     bool pipelined;            // several frames in flight (throughput-tuned launch) or one (latency-tuned)
-    int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (binary nodes), per-ray: 2 binary, 4 wide quantised
+    int trace_kind[3];         // how primary / shadow / AO rays are traced: 8 packet walk (the fused frame only), per-ray: 2 binary nodes, 4 quantised 4-wide nodes
     TraceTune tune;            // host: the context's overrides of the persistent tracer's presets
     // the light records travel BY VALUE with every launch, like the camera block: a frame in flight can never see a later art_set_lights
     // (a device-side table, however it is double-buffered, is overwritten while launches queued 16 frames ago still hold its address)
@@ -214,15 +210,12 @@ struct FrameArgs {
     float4 *contrib;           // [n_lights][n_local]
     float4 *shadow_rays;       // [2 * n_lights * n_local] dense per (light, pixel): o.xyz,tmax (<=0: none) | d.xyz,-
     uint32_t *counters;        // kCounterWords, zeroed every frame
-    bool fold_counters;        // packet walks use no work cursors: the last launch of the frame folds the count slots into counters[0..1] and clears them for the
-                               // slot's next frame, instead of a memset launch in front of every frame
     float4 *color; float *depth; float4 *normal; // full frame, row-major
     float4 *color_tiles;       // compact tile buffer (sharded mode) or nullptr: [n_local] RGB32F texels, 12 B each (the colour's alpha is the constant 1) ...
     bool tiles_packed;         // ... or B10G11R11 words (4 B per pixel, the reference's output image format)
     uint32_t *shadow_bits;     // debug, [n_local] or nullptr
     uint32_t *pix_bits;        // fused frame: [n_local] shadowed / traced bits per pixel (always written)
     bool keep_hits;            // fused frame: also store the hit records (art_read_hits)
-    int frame_waves;           // fused frame: occupancy target of the instance to launch (ART_FRAME_WAVES, default 8)
     // fused frame: what each wave of the launch traces.  x = 8x8 pixel block (local pixel id / 64), y = which of its sixteen 2x2 cells
     // (bit = (y/2)*4 + x/2).  A block whose packet crawls (dense distant geometry: up to 0.5 ms for one wave) is dealt to 4 or 16 waves.
     const uint2 *wave_items; uint32_t n_wave_items;

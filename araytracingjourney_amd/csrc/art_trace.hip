@@ -279,8 +279,6 @@ template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
 // still tests its own ray against both child boxes with its own t_best.  A lane that would accept a triangle passes the slab
 // test of every enclosing box (monotone slab), so the packet finds exactly the per-ray answer, bit for bit.
 constexpr int kPacketStack = 288; // shared stack of node references per wave: >= 3 pending siblings per level * 95 levels // a shared stack of node references per wave; the radix tree is at most 95 levels deep
-enum { PK_PRIMARY = 0, PK_SHADOW = 1, PK_AO = 2 };
-struct PacketArgs { const uint8_t *dummy; uint32_t spp; float ao_radius; uint8_t *occl; const float4 *ao_pix, *ao_tab; }; // AO extras (per-pixel records of k_ao_pixels, sample table of k_ao_table)
 __device__ __forceinline__ bool ao_slot_decode(uint32_t slot, uint32_t spp, uint32_t &p, uint32_t &j);
 __device__ __forceinline__ V3 ao_dir(V3 N, float tx, float ty, float tz);
 
@@ -324,6 +322,10 @@ struct ConstQuads {
 };
 template <class T> __device__ __forceinline__ ConstQuads const_quads(const T *p) { ConstQuads q; q.p = (__attribute__((address_space(4))) const ConstQuads::Quad *)(uintptr_t)p; return q; }
 
+// (Rounds 3 and 4 measured two uses of the packet's BEAM -- interval bounds of its rays against a node's four boxes on half a wave, 9 vector instructions -- and kept neither:
+// as the node step itself its weaker culling bought 38 % more triangle steps (round 3b), as a FILTER in front of the per-ray box tests it left the launch's vector instructions
+// where they were -- 124.98 M -> 124.86 M: what the filtered-out box tests save goes into the beam's set-up, its 9 instructions a step and the boxes it passes needlessly --
+// and added 36 % scalar instructions and 13 % wave cycles: config 2 19 370 -> 17 250 Mray/s, frames bit-equal.  profiles/README.md round 4, profiles/round4_filter_*.)
 #ifdef ART_PACKET_PROF
 // profiling build only (make EXTRA=-DART_PACKET_PROF; tools/packet_prof.py): what the packet walks of k_frame are made of, summed over all waves since the last reset.
 // [0..11] closest-hit (primary) walks, [12..23] any-hit (shadow) walks: walks, node steps, triangle steps, triangle steps that came off the stack, triangle steps in
@@ -440,283 +442,25 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
 #endif
 }
 
-// ---- the beam walk: a node step on the lanes of ONE quarter-wave instead of 64 rays x 4 boxes ---------------------------------------------------------
-// A packet enters a child when ANY of its rays passes the child's box.  The walks above ask every ray (4 boxes x 13 vector instructions a node step, and
-// 2.65 of the 4 boxes are passed by no ray at all); this one asks the packet's BEAM: per axis the interval [min, max] over the rays of 1 / d and o / d,
-// the largest t_best.  Interval arithmetic on the very expression of slab() gives a lower bound of every ray's entry distance and an upper bound of every
-// ray's exit distance; a child whose bounds do not overlap is passed by no ray (the bounds are widened by 2^-20 relative -- sixteen times the roundings
-// they have to cover, see below), a child whose bounds overlap is entered, needed or not.  The walk visits a SUPERSET of the nodes the per-ray tests
-// visit, and the triangle step is the same accept() per lane as ever: by DESIGN.md 1.1 the answers are those of the other walks bit for bit.
-//
-// Lane j (mod 32) of the wave owns one number of the node: child c = j / 8, and within the child's eight lanes 0..2 the near plane of x, y, z, 3 tmin,
-// 4..6 the far plane of x, y, z, 7 t_limit.  One 4-byte vector load per lane fetches the 24 planes (the octant says which of lo / hi is near), then
-//     value = min(q * A, q * B) - C        q = plane - O
-// with per-lane constants made once per walk: near lanes get a lower bound of the entry distance, far lanes MINUS an upper bound of the exit distance,
-// lanes 3 / 7 (A = B = 0) tmin / -t_limit.  Two quad-wide maxima (DPP) leave max(near) in the child's lanes 0..3 and -min(far) in 4..7; the child is
-// entered iff the first is <= minus the second: one mirrored read, one compare, one ballot.  9 vector instructions a node step instead of 61.
-//   common origin (primary rays):   slab's t = fma(p, i, -RN(o * i)) = [(p - o) * i - o * i * d1] * (1 + d2), |d| <= 2^-24.  Bound: q = RN(p - o),
-//       min(q * Alo, q * Ahi) - Cs with [Alo, Ahi] = [min i, max i] widened by 2^-20 relative and Cs = 2^-20 * |o| * max |i|.
-//   general (shadow rays):          t = RN(p * i - ood).  Bound: min(p * Alo, p * Ahi) - Chi, Chi = max ood widened likewise (far lanes: the mirror image).
-// Every rounding in sight is 2^-24 relative to a term that was widened by 2^-20, so the computed bound stays on the safe side of every lane's computed t.
-template <int CTRL> __device__ __forceinline__ float dpp_read(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
-constexpr int kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140; // quad_perm [1,0,3,2], [2,3,0,1]; lane i <-> 7 - i of 8; i <-> 15 - i of 16
-__device__ __forceinline__ float wave_min_f(float v) { // every lane returns the minimum over the wave (no NaNs in, none out)
-    v = fminf(v, dpp_read<kDppQuadSwap1>(v)); v = fminf(v, dpp_read<kDppQuadSwap2>(v)); v = fminf(v, dpp_read<kDppRowHalfMirror>(v)); v = fminf(v, dpp_read<kDppRowMirror>(v));
-    v = fminf(v, __shfl_xor(v, 16)); return fminf(v, __shfl_xor(v, 32));
-}
-__device__ __forceinline__ float wave_max_f(float v) { return -wave_min_f(-v); }
-// max over a quad, in every lane of it: two v_max_f32 whose first operand comes through DPP (fmaxf on a DPP read costs a move and a quieting v_max besides; the values here
-// are results of arithmetic).  s_nop 1: a DPP operand written by the instruction before needs two wait states, and the compiler does not look into the asm.
-__device__ __forceinline__ float quad_max_f(float v) {
-    float a, b;
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(v));
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(b) : "v"(a));
-    return b;
-}
-struct Beam { float O, A, B, C; uint32_t boff; bool lim_lane; }; // per-lane constants of value = min(q * A, q * B) - C, byte offset of the lane's plane in a DevNodeW
-constexpr float kBeamEps = 9.5367431640625e-07f; // 2^-20
-// Both kinds of packet in one form: with c the origin of the packet's first ray, slab's t = p * i - o * i = (p - c) * i - (o - c) * i in the reals.  The first
-// term is bounded by q * [Alo, Ahi] (q = RN(p - c)), the second is a per-lane number r = RN(RN(o - c) * i) whose [min, max] over the rays is reduced like i's
-// (primary rays: all zero, COMMON skips it).  Roundings: slab's own are 2^-24 of |p * i| + |o * i| <= (|q| + 2|c| + e) * |i|, e the origins' spread; ours are 2^-24
-// of |q * i| and |r|.  Widening [Alo, Ahi] and [rlo, rhi] by 2^-20 relative covers the terms in |q * i| and |r|; Cs = 2^-20 * (2|c| + e) * max|i| the rest.
-// Returns the beam's fatness: the largest spread of the ray origins along an axis, in world units (0 for a common origin).
-template <bool COMMON, bool UNIFORM_DIR>
-__device__ __forceinline__ float beam_setup(V3 ro, V3 rinv, float tmin, bool on, float tbest, int oct, Beam &b) {   // (the ray's fields by value: selects between fields of a struct behind a reference become indexed loads from a stack copy)
-    const uint32_t j = __lane_id() & 31u, c = j >> 3, s = j & 7u, k = s & 3u;
-    const bool far = s >= 4u, scalar_lane = k == 3u;
-    const bool neg = ((oct >> k) & 1) != 0;                        // the octant's sign on this lane's axis
-    b.boff = 4u * (c * 6u + (scalar_lane ? 0u : k + ((far != neg) ? 3u : 0u)));   // near plane: lo (hi when the rays go down the axis); far plane: the other
-    b.lim_lane = s == 7u;
-    const float kInf = INFINITY;
-    const int first = (int)__builtin_ctzll(ballot64(on));          // the caller made sure some lane is on
-    float lo, hi;
-    {
-        if (UNIFORM_DIR) {   // every ray has the direction of the first (a directional light)
-            const float ix = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rinv.x), first)), iy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rinv.y), first)),
-                        iz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rinv.z), first));
-            lo = hi = k == 0u ? ix : (k == 1u ? iy : iz);
-        }
-        else {
-            float ilo[3], ihi[3];
-            ilo[0] = wave_min_f(on ? rinv.x : kInf); ihi[0] = wave_max_f(on ? rinv.x : -kInf);
-            ilo[1] = wave_min_f(on ? rinv.y : kInf); ihi[1] = wave_max_f(on ? rinv.y : -kInf);
-            ilo[2] = wave_min_f(on ? rinv.z : kInf); ihi[2] = wave_max_f(on ? rinv.z : -kInf);
-            lo = k == 0u ? ilo[0] : (k == 1u ? ilo[1] : ilo[2]); hi = k == 0u ? ihi[0] : (k == 1u ? ihi[1] : ihi[2]);
-        }
-    }
-    lo = fmaf(-kBeamEps, fabsf(lo), lo); hi = fmaf(kBeamEps, fabsf(hi), hi);
-    const float mag = fmaxf(fabsf(lo), fabsf(hi));
-    const float cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ro.x), first)), cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ro.y), first)),
-                cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ro.z), first));
-    const float ck = k == 0u ? cx : (k == 1u ? cy : cz);
-    float C, fat = 0.0f;
-    if (COMMON) C = 2.0f * kBeamEps * fabsf(ck) * mag;
-    else {
-        const float dx = ro.x - cx, dy = ro.y - cy, dz = ro.z - cz;
-        const float ex = wave_max_f(on ? fabsf(dx) : 0.0f), ey = wave_max_f(on ? fabsf(dy) : 0.0f), ez = wave_max_f(on ? fabsf(dz) : 0.0f);
-        fat = fmaxf(fmaxf(ex, ey), ez);
-        const float rx = dx * rinv.x, ry = dy * rinv.y, rz = dz * rinv.z;
-        float rlo[3], rhi[3];
-        rlo[0] = wave_min_f(on ? rx : kInf); rhi[0] = wave_max_f(on ? rx : -kInf);
-        rlo[1] = wave_min_f(on ? ry : kInf); rhi[1] = wave_max_f(on ? ry : -kInf);
-        rlo[2] = wave_min_f(on ? rz : kInf); rhi[2] = wave_max_f(on ? rz : -kInf);
-        float ol = k == 0u ? rlo[0] : (k == 1u ? rlo[1] : rlo[2]), oh = k == 0u ? rhi[0] : (k == 1u ? rhi[1] : rhi[2]);
-        ol = fmaf(-kBeamEps, fabsf(ol), ol); oh = fmaf(kBeamEps, fabsf(oh), oh);
-        const float ek = k == 0u ? ex : (k == 1u ? ey : ez);
-        C = (far ? -ol : oh) + kBeamEps * (2.0f * fabsf(ck) + 2.0f * ek) * mag;   // near: t >= min(q * i) - max r;  far: -t >= min(-q * i) + min r
-    }
-    b.O = scalar_lane ? 0.0f : ck;
-    b.A = far ? -lo : lo; b.B = far ? -hi : hi;
-    const float tlim = wave_max_f(tbest);   // lanes without a ray carry -1
-    if (scalar_lane) { b.A = 0.0f; b.B = 0.0f; C = far ? tlim : -tmin; }   // value = -t_limit / tmin
-    b.C = C;
-    return fat;
-}
-// oct (wave-uniform, 0..7) is a run-time value here: it only picks each lane's plane (boff) and the order of the children, so one copy of the walk serves the eight
-// octants; the triangle's own box runs through the general slab (for the lanes that passed Moeller-Trumbore: a handful of instructions more than the octant's).
-template <bool ANY, bool COUNT = false>
-__device__ __forceinline__ void beam_walk(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps, int oct, Beam &b) {
-    int cur = 0, sp = 0; // wave-uniform
-    constexpr int kPop = kAbsentChild;
-#ifdef ART_PACKET_PROF
-    unsigned long long pp_[10] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0}; bool from_stack_ = false;
-#endif
-    for (;;) {
-#ifdef ART_PACKET_PROF
-        const unsigned long long tk0_ = __builtin_amdgcn_s_memtime(); const bool was_node_ = cur >= 0;
-#endif
-        if (COUNT) steps++;
-        if (cur >= 0) {
-            const char *nb = reinterpret_cast<const char *>(a.widef + cur);
-            const float p = *reinterpret_cast<const float *>(nb + b.boff);           // one plane per lane: global_load_dword v, v_off, s[node]
-            ConstQuads nq = const_quads(a.widef + cur);
-            const float4 w6 = nq[6], w7 = nq[7];                                     // the child references and the sort axis stay wave-uniform (scalar loads, in flight beside the planes)
-            const int c0 = __float_as_int(w6.x), c1 = __float_as_int(w6.y), c2 = __float_as_int(w6.z), c3 = __float_as_int(w6.w);
-            const float q = p - b.O;
-            float v = fminf(q * b.A, q * b.B) - b.C;
-            v = quad_max_f(v);                                                                    // lanes 0..3 of a child: max(near planes, tmin); 4..7: -min(far planes, t_limit)
-            const float nf = dpp_read<kDppRowHalfMirror>(v);                                     // lane 0 of a child reads its lane 7
-            const uint32_t m = (uint32_t)ballot64(v <= -nf);
-            const bool m0 = (m & 0x1u) != 0u, m1 = (m & 0x100u) != 0u, m2 = (m & 0x10000u) != 0u, m3 = (m & 0x1000000u) != 0u;
-#ifdef ART_PACKET_PROF
-            pp_[1]++; pp_[6] += (int)m0 + (int)m1 + (int)m2 + (int)m3; from_stack_ = false;
-#endif
-            const uint32_t ax = __float_as_uint(w7.y);
-            const bool rev = ((oct >> ax) & 1) != 0;
-            const bool lane0 = (threadIdx.x & 63u) == 0;
-            int next = kPop;
-            if (!rev) { // near -> far = 0,1,2,3: stack the far ones first
-                if (m3) next = c3;
-                if (m2) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c2; }
-                if (m1) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c1; }
-                if (m0) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c0; }
-            } else {
-                if (m0) next = c0;
-                if (m1) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c1; }
-                if (m2) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c2; }
-                if (m3) { if (next != kPop) { if (lane0) stk[min(sp, kPacketStack - 1)] = next; sp = min(sp + 1, kPacketStack); } next = c3; }
-            }
-            cur = next;
-        } else {
-            uint32_t pos = (uint32_t)~cur;
-            ConstQuads tq = const_quads(a.tris + pos);
-            float4 ta = tq[0], tb = tq[1], tc = tq[2], td = tq[3];   // v0 e1 e2 lo hi gid: one 64-byte scalar load (DevTri)
-            float te = 0.f, t = 0.f, u = 0.f, v = 0.f;
-            bool acc = moller_trumbore_flat(r, mk(ta.x, ta.y, ta.z), mk(ta.w, tb.x, tb.y), mk(tb.z, tb.w, tc.x), t, u, v) && on;
-            if (acc) acc = slab(r, tc.y, tc.z, tc.w, td.x, td.y, td.z, tbest, te);
-            if (ANY) { bpos = acc ? pos : bpos; on = on && !acc; tbest = acc ? -1.0f : tbest; } // first accepted triangle: this lane is done
-            else {
-                float teff;
-                asm("v_max_f32 %0, %1, %2" : "=v"(teff) : "v"(t), "v"(te));
-                uint32_t gid = __float_as_uint(td.w);
-                bool better = acc & ((teff < tbest) | ((teff == tbest) & (gid < bgid)));
-                tbest = better ? teff : tbest; bu = better ? u : bu; bv = better ? v : bv; bpos = better ? pos : bpos; bgid = better ? gid : bgid;
-                if (ballot64(better) != 0ull) { const float tl = wave_max_f(tbest); b.C = b.lim_lane ? tl : b.C; }   // some ray's range shrank: so may the beam's
-            }
-#ifdef ART_PACKET_PROF
-            { uint64_t am_ = ballot64(acc); pp_[2]++; pp_[3] += from_stack_; pp_[4] += am_ != 0ull; pp_[5] += __popcll(am_); }
-#endif
-            cur = kPop;
-            if (ANY && ballot64(on) == 0ull) break; // every ray of the packet is occluded
-        }
-        if (cur == kPop) {
-            if (sp == 0) break;
-            sp--;
-            cur = __builtin_amdgcn_readfirstlane(stk[sp]);
-#ifdef ART_PACKET_PROF
-            from_stack_ = true;
-#endif
-        }
-#ifdef ART_PACKET_PROF
-        pp_[was_node_ ? 8 : 9] += __builtin_amdgcn_s_memtime() - tk0_;
-#endif
-    }
-#ifdef ART_PACKET_PROF
-    for (int i = 0; i < 10; i++) PPROF(i, pp_[i]);
-#endif
-}
-
 // one packet through the walk that fits its rays' direction signs
-template <bool ANY, int WIDE, bool COUNT = false>
-__device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps, bool uniform_dir = false) {
+template <bool ANY, bool WIDE, bool COUNT = false>
+__device__ __forceinline__ void walk_dispatch(const FrameArgs &a, const Ray &r, bool &on, int *stk, float &tbest, float &bu, float &bv, uint32_t &bpos, uint32_t &bgid, uint32_t &steps) {
     uint64_t act = ballot64(on);
     if (act == 0ull) return;
     // direction signs per axis: all set, none set, or mixed over the packet's rays
     uint64_t nx = ballot64(on && r.inv.x < 0.0f), ny = ballot64(on && r.inv.y < 0.0f), nz = ballot64(on && r.inv.z < 0.0f);
     bool uniform = (nx == 0ull || nx == act) && (ny == 0ull || ny == act) && (nz == 0ull || nz == act);
     int oct = !uniform ? 8 : (nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0);
-    if constexpr (WIDE == 2) {
-        // the beam walk where the packet is a beam: one octant, and (shadow rays) origins that lie together -- a packet across a depth edge would sweep everything between
-        // its two surfaces; it asks every ray as before.  uniform_dir: the rays share ONE direction (a directional light; the caller knows)
-        if (uniform && (ANY ? a.beam_shadow : a.beam_primary)) {
-            Beam b; float fat;
-#ifdef ART_PACKET_PROF
-            const unsigned long long ts0_ = __builtin_amdgcn_s_memtime();
-#endif
-            if (!ANY) fat = beam_setup<true, false>(r.o, r.inv, r.tmin, on, tbest, oct, b);
-            else if (uniform_dir) fat = beam_setup<false, true>(r.o, r.inv, r.tmin, on, tbest, oct, b);
-            else fat = beam_setup<false, false>(r.o, r.inv, r.tmin, on, tbest, oct, b);
-#ifdef ART_PACKET_PROF
-            PPROF(10, __builtin_amdgcn_s_memtime() - ts0_);
-#endif
-            if (fat <= a.beam_fat) { beam_walk<ANY, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps, oct, b); return; }
-#ifdef ART_PACKET_PROF
-            PPROF(7, 1);   // a fat beam: the packet asks every ray
-#endif
-        }
-    }
     switch (oct) {
-    case 0: packet_walk<ANY, WIDE != 0, 0, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 1: packet_walk<ANY, WIDE != 0, 1, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 2: packet_walk<ANY, WIDE != 0, 2, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 3: packet_walk<ANY, WIDE != 0, 3, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 4: packet_walk<ANY, WIDE != 0, 4, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 5: packet_walk<ANY, WIDE != 0, 5, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 6: packet_walk<ANY, WIDE != 0, 6, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    case 7: packet_walk<ANY, WIDE != 0, 7, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    default: packet_walk<ANY, WIDE != 0, 8, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
-    }
-}
-
-// MODE PK_PRIMARY: slot = local pixel (a wave = one 8x8 block), closest hit -> hits[].
-// MODE PK_SHADOW:  slot = light * n_local + local pixel (the dense shadow-ray slots of k_shade: the same 8x8 block, rays towards
-//                  one light), any hit -> the slot's contribution keeps 0.05.  A lane leaves the packet at its first hit.
-// MODE PK_AO:      the AO launch's slots (ao_slot_decode): a wave = sixteen neighbouring pixels x the four samples of one azimuth quadrant, any hit -> occl[].
-template <int MODE, bool WIDE>
-__global__ __launch_bounds__(kBlock) void k_packet(FrameArgs a, PacketArgs x) {
-    constexpr bool ANY = MODE != PK_PRIMARY;
-    __shared__ int wstack[(kBlock / 64) * kPacketStack];
-    int *stk = &wstack[(threadIdx.x >> 6) * kPacketStack];
-    const uint32_t total = MODE == PK_PRIMARY ? a.n_local : (MODE == PK_SHADOW ? a.n_local * a.n_lights : (a.n_local / 16u) * (((x.spp + 3u) >> 2) * 64u));
-    // primary / shadow: the launch order of the 256-pixel blocks is XCD-aware (a.block_order); shadow slots are [light][pixel]
-    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (MODE != PK_AO) {
-        const uint32_t per_light = a.n_local / kBlock, light = blockIdx.x / per_light;
-        slot = (light * per_light + a.block_order[blockIdx.x - light * per_light]) * kBlock + threadIdx.x;
-    }
-    bool on = false;
-    Ray r;
-    if (MODE == PK_PRIMARY) {
-        uint32_t px = 0, py = 0;
-        on = slot < total && local_to_xy(slot, a.tile_list, a.tiles_x, a.W, a.H, px, py);
-        float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-        float dx = (fx / (float)a.W) * 2.0f - 1.0f, dy = (fy / (float)a.H) * 2.0f - 1.0f;
-        V3 org = mat4_mul(a.cam.view_inv, 0.f, 0.f, 0.f, 1.f);
-        V3 tgt = nrm3(mat4_mul(a.cam.proj_inv, dx, dy, 1.f, 1.f));
-        V3 dir = mat4_mul(a.cam.view_inv, tgt.x, tgt.y, tgt.z, 0.f);
-        ray_init(r, org, dir, 0.001f, 10000.0f);
-    } else if (MODE == PK_SHADOW) {
-        float4 r0 = slot < total ? ld_nt(&a.shadow_rays[2 * (size_t)slot]) : make_float4(0.f, 0.f, 0.f, -1.f);
-        on = r0.w > 0.0f;
-        float4 r1 = on ? ld_nt(&a.shadow_rays[2 * (size_t)slot + 1]) : make_float4(0.f, 0.f, 1.f, 0.f);
-        ray_init(r, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z), 0.01f, on ? r0.w : 1.0f);
-    } else {
-        uint32_t p = 0, smp = 0;   // smp: the sample's rank in the pixel's azimuth order (k_ao_table)
-        const bool real = slot < total && ao_slot_decode(slot, x.spp, p, smp);
-        float4 po = real ? x.ao_pix[2 * (size_t)p] : make_float4(0.f, 0.f, 0.f, __int_as_float((int)0x80000000));
-        on = __float_as_int(po.w) != (int)0x80000000;   // kAoNothingNear: a padding slot, a miss pixel, nothing within the radius
-        V3 o = mk(po.x, po.y, po.z), d = mk(0.f, 0.f, 1.f);
-        if (on) { float4 pn = x.ao_pix[2 * (size_t)p + 1]; float4 t = x.ao_tab[smp * (64u * 64u) + __float_as_uint(pn.w)]; d = ao_dir(mk(pn.x, pn.y, pn.z), t.x, t.y, t.z); }
-        ray_init(r, o, d, x.ao_radius * 0.01f, x.ao_radius);
-    }
-    const bool traced = on;
-    on = on && ray_finite(r.o, r.d);
-    float tbest = on ? r.tmax : -1.0f, bu = 0.f, bv = 0.f; // -1: below every tmin, no box test passes (lanes without a ray, occluded lanes)
-    uint32_t bpos = kNoHit, bgid = kNoHit;
-    uint32_t steps = 0;
-    walk_dispatch<ANY, WIDE>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps);
-    if (MODE == PK_PRIMARY) {
-        if (slot < total) st_nt(&a.hits[slot], bpos != kNoHit ? make_float4(tbest, bu, bv, __uint_as_float(bpos)) : make_float4(10000.0f, 0.f, 0.f, __uint_as_float(kNoHit)));
-    } else if (MODE == PK_SHADOW) {
-        if (traced && bpos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
-            float4 c = ld_nt(&a.contrib[slot]);
-            st_nt(&a.contrib[slot], make_float4(c.x * 0.05f, c.y * 0.05f, c.z * 0.05f, c.w));
-            if (a.shadow_bits) { uint32_t i = slot / a.n_local; if (i < 16) atomicOr(&a.shadow_bits[slot - i * a.n_local], 1u << i); }
-        }
-        uint64_t tm = ballot64(traced);
-        if ((threadIdx.x & 63u) == 0 && tm) atomicAdd(&a.counters[kShadowSlots + ((blockIdx.x * 4u + (threadIdx.x >> 6)) % kSlotCount) * kSlotStride], (uint32_t)__popcll(tm));
-    } else {
-        if (slot < total) x.occl[slot] = (traced && bpos != kNoHit) ? 1 : 0;
+    case 0: packet_walk<ANY, WIDE, 0, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 1: packet_walk<ANY, WIDE, 1, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 2: packet_walk<ANY, WIDE, 2, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 3: packet_walk<ANY, WIDE, 3, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 4: packet_walk<ANY, WIDE, 4, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 5: packet_walk<ANY, WIDE, 5, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 6: packet_walk<ANY, WIDE, 6, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    case 7: packet_walk<ANY, WIDE, 7, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
+    default: packet_walk<ANY, WIDE, 8, COUNT>(a, r, on, stk, tbest, bu, bv, bpos, bgid, steps); break;
     }
 }
 
@@ -1284,8 +1028,8 @@ __device__ __forceinline__ uint64_t tick(float &dep) { uint64_t t; asm volatile(
 #else
 #define PHASE(i, dep)
 #endif
-template <int WIDE, int WAVES, bool ONE_LIGHT, bool COUNT = false, bool BATCH = false>   // WIDE: 0 binary nodes, 1 4-wide nodes (every ray tests every box), 2 4-wide nodes walked by the packet's beam
-__global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void k_frame(FrameArgs a) {
+template <bool WIDE, bool ONE_LIGHT, bool COUNT = false, bool BATCH = false>   // WIDE: the 128-byte 4-wide nodes (the default) | the 64-byte binary nodes
+__global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_frame(FrameArgs a) {
     // One wave per workgroup: the waves of a frame are independent (nothing is shared, no barrier), and a workgroup of four held its LDS and its place
     // in the dispatcher's books until its slowest wave was done -- packets differ 25x in steps.  Single-wave groups: +2.5 % rays/s (profiles/README.md r2).
     __shared__ int wstack[kPacketStack];
@@ -1350,7 +1094,7 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(WAV
         PHASE(3, sr.inv.x)
         float st = son ? sr.tmax : -1.0f, su = 0.f, sv = 0.f;
         uint32_t spos = kNoHit, sgid = kNoHit;
-        walk_dispatch<true, WIDE, COUNT>(a, sr, son, stk, st, su, sv, spos, sgid, steps, a.lights[i].type == 2u);
+        walk_dispatch<true, WIDE, COUNT>(a, sr, son, stk, st, su, sv, spos, sgid, steps);
         PHASE(4, st)
         if (want && spos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
             c4 = make_float4(c4.x * 0.05f, c4.y * 0.05f, c4.z * 0.05f, c4.w);
@@ -1486,12 +1230,6 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(FrameArgs a) {
             float4 c = ld_nt(&a.contrib[(size_t)i * a.n_local + p]);
             rx += c.x * c.w; ry += c.y * c.w; rz += c.z * c.w;
         }
-    if (a.fold_counters && blockIdx.x == 0 && threadIdx.x < 64) { // every count of this frame is final (earlier launches): total them, clear the slots
-        uint32_t sh = a.counters[kShadowSlots + threadIdx.x * kSlotStride], hp = a.counters[kHitSlots + threadIdx.x * kSlotStride];
-        a.counters[kShadowSlots + threadIdx.x * kSlotStride] = 0; a.counters[kHitSlots + threadIdx.x * kSlotStride] = 0;
-        for (int off = 32; off >= 1; off >>= 1) { sh += (uint32_t)__shfl_xor((int)sh, off); hp += (uint32_t)__shfl_xor((int)hp, off); }
-        if (threadIdx.x == 0) { a.counters[0] = sh; a.counters[1] = hp; }
-    }
     float4 o = make_float4(rx, ry, rz, 1.0f);
     if (in) st_nt(&a.color[(size_t)y * a.W + x], o);
     if (a.color_tiles) { // compact tile buffer for the gather: row-major inside each 32x32 tile
@@ -1557,8 +1295,7 @@ template <int MODE> static void launch_trace(TraceArgs &a, int kind, bool pipeli
     if (kind == 4) k_trace<MODE, 4><<<nb, kTraceBlock, 0, s>>>(a);
     else k_trace<MODE, 2><<<nb, kTraceBlock, 0, s>>>(a);
 }
-void launch_primary(const FrameArgs &f, hipStream_t s) {
-    if (f.trace_kind[0] == 8) { if (f.packet_wide) k_packet<PK_PRIMARY, true><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); else k_packet<PK_PRIMARY, false><<<blocks_for(f.n_local), kBlock, 0, s>>>(f, PacketArgs{}); return; } // packet walk over the binary nodes
+void launch_primary(const FrameArgs &f, hipStream_t s) {   // staged frames: the persistent per-ray tracer
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local; a.cursors = f.counters + 64; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.hits = f.hits;
@@ -1567,33 +1304,25 @@ void launch_primary(const FrameArgs &f, hipStream_t s) {
 void launch_shade(const FrameArgs &a, hipStream_t s) { k_shade<<<blocks_for(a.n_local), kBlock, 0, s>>>(a); }
 void launch_shadow(const FrameArgs &f, hipStream_t s) {
     if (f.n_lights == 0) return;
-    if (f.trace_kind[1] == 8) { if (f.packet_wide) k_packet<PK_SHADOW, true><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); else k_packet<PK_SHADOW, false><<<blocks_for(f.n_local * f.n_lights), kBlock, 0, s>>>(f, PacketArgs{}); return; }
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = f.n_local * f.n_lights; a.cursors = f.counters + 64 + 8 * kCursorStride; a.count = f.counters + kShadowSlots;
     a.rays = f.shadow_rays; a.contrib = f.contrib; a.n_local = f.n_local; a.shadow_bits = f.shadow_bits;
     launch_trace<MODE_SHADOW>(a, f.trace_kind[1], f.pipelined, f.tune, s);
 }
-template <int WIDE, bool ONE_LIGHT> static void launch_frame_form(const FrameArgs &a, uint32_t g, bool count, hipStream_t s) {
+template <bool WIDE, bool ONE_LIGHT> static void launch_frame_form(const FrameArgs &a, uint32_t g, bool count, hipStream_t s) {
     if (a.batch > 1) { // several frames per launch
         const dim3 gb(g, a.batch);
-        if (count) k_frame<WIDE, 8, ONE_LIGHT, true, true><<<gb, kFrameBlock, 0, s>>>(a); else k_frame<WIDE, 8, ONE_LIGHT, false, true><<<gb, kFrameBlock, 0, s>>>(a);
-    } else if (count) k_frame<WIDE, 8, ONE_LIGHT, true><<<g, kFrameBlock, 0, s>>>(a);
-    else k_frame<WIDE, 8, ONE_LIGHT><<<g, kFrameBlock, 0, s>>>(a);
+        if (count) k_frame<WIDE, ONE_LIGHT, true, true><<<gb, kFrameBlock, 0, s>>>(a); else k_frame<WIDE, ONE_LIGHT, false, true><<<gb, kFrameBlock, 0, s>>>(a);
+    } else if (count) k_frame<WIDE, ONE_LIGHT, true><<<g, kFrameBlock, 0, s>>>(a);
+    else k_frame<WIDE, ONE_LIGHT><<<g, kFrameBlock, 0, s>>>(a);
 }
 bool launch_frame(const FrameArgs &a, hipStream_t s) { // returns whether the launch wrote a.wave_cost
-    const int waves = a.frame_waves; // every instance fits 64 registers without spills
     const uint32_t g = a.n_wave_items;   // one workgroup per wave item
     if (g == 0) return false;
     const bool one = a.n_lights == 1;
-    if (!a.packet_wide && waves < 8 && a.batch <= 1) { // A/B forms: the binary walk held to 7 or 6 waves per SIMD (ArtTuning.frame_waves)
-        if (waves == 7) { if (one) k_frame<0, 7, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<0, 7, false><<<g, kFrameBlock, 0, s>>>(a); }
-        else { if (one) k_frame<0, 6, true><<<g, kFrameBlock, 0, s>>>(a); else k_frame<0, 6, false><<<g, kFrameBlock, 0, s>>>(a); }
-        return false;
-    }
     const bool count = a.wave_cost != nullptr && a.n_lights > 0; // a sampled frame of the wave plan: the step-counting instances
-    if (a.packet_wide && a.packet_beam) { if (one) launch_frame_form<2, true>(a, g, count, s); else launch_frame_form<2, false>(a, g, count, s); }
-    else if (a.packet_wide) { if (one) launch_frame_form<1, true>(a, g, count, s); else launch_frame_form<1, false>(a, g, count, s); }
-    else { if (one) launch_frame_form<0, true>(a, g, count, s); else launch_frame_form<0, false>(a, g, count, s); }
+    if (a.packet_wide) { if (one) launch_frame_form<true, true>(a, g, count, s); else launch_frame_form<true, false>(a, g, count, s); }
+    else { if (one) launch_frame_form<false, true>(a, g, count, s); else launch_frame_form<false, false>(a, g, count, s); }
     return count;
 }
 void launch_frame_stats(const FrameArgs &a, uint32_t *out, hipStream_t s) { k_frame_stats<<<blocks_for(a.n_local), kBlock, 0, s>>>(a, out); }
@@ -1652,12 +1381,6 @@ void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, fl
     AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
     k_ao_pixels<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, (f.trace_kind[2] == 4 && entry_search) ? f.wide : nullptr, radius, pix); // one point, normal and entry node per pixel for its spp rays
     const uint32_t n_slots = (f.n_local / 16u) * (((spp + 3u) >> 2) * 64u); // ao_slot_decode
-    if (f.trace_kind[2] == 8) { // the packet walk (sixteen neighbouring pixels x one azimuth quadrant per wave, from the root): measured 2x slower than the per-ray walk, before and after the regrouping -- off by default
-        PacketArgs x{}; x.spp = spp; x.ao_radius = radius; x.occl = occl; x.ao_pix = pix; x.ao_tab = tab;
-        if (f.packet_wide) k_packet<PK_AO, true><<<blocks_for(n_slots), kBlock, 0, s>>>(f, x); else k_packet<PK_AO, false><<<blocks_for(n_slots), kBlock, 0, s>>>(f, x);
-        k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
-        return;
-    }
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = n_slots; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;

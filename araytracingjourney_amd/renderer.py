@@ -237,11 +237,11 @@ class Model:
 class Renderer:
     """VulkanTempleRayTracedRenderer (renderer.rs:121-137) on libart: same call order, no window/swapchain."""
 
-    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, device_tree=False, fixed_waves=False, tile_output=False, tuning=None, root_relief=0, dynamic_scene=False):
+    def __init__(self, extent, device=-1, shard=(0, 1), morton_bits=0, keep_debug=False, frames_in_flight=1, fast_build=False, packed_tiles=False, fixed_waves=False, tile_output=False, tuning=None, root_relief=0, dynamic_scene=False):
         self._L = _lib.load()
         w, h = extent
         cfg = ArtConfig(device=device, width=w, height=h, morton_bits=morton_bits, shard_rank=shard[0], shard_count=shard[1],
-                        flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0) | (_lib.ART_FLAG_PACKED_TILES if packed_tiles else 0) | (_lib.ART_FLAG_DEVICE_TREE if device_tree else 0) | (_lib.ART_FLAG_FIXED_WAVES if fixed_waves else 0) | (_lib.ART_FLAG_TILE_OUTPUT if tile_output else 0) | (_lib.ART_FLAG_DYNAMIC_SCENE if dynamic_scene else 0),
+                        flags=(_lib.ART_FLAG_KEEP_DEBUG if keep_debug else 0) | (_lib.ART_FLAG_FAST_BUILD if fast_build else 0) | (_lib.ART_FLAG_PACKED_TILES if packed_tiles else 0) | (_lib.ART_FLAG_FIXED_WAVES if fixed_waves else 0) | (_lib.ART_FLAG_TILE_OUTPUT if tile_output else 0) | (_lib.ART_FLAG_DYNAMIC_SCENE if dynamic_scene else 0),
                         frames_in_flight=frames_in_flight, root_relief=root_relief)
         self._ctx = C.c_void_p()
         check(self._L.art_create(C.byref(cfg), C.byref(self._ctx)))

@@ -165,7 +165,7 @@ def main():
     # is what levels its loop with the others' on the rehearsal (profiles/README.md r1n: 35.7 -> 31 us per frame at N = 8)
     shard = renderer.mgpu_shard(rank, world, dedicated) if world > 1 else (0, 1)
 
-    tuning = {k: (float(v) if k in ("split_alpha", "refit_rebuild_ratio", "beam_fat") else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)} or None
+    tuning = {k: (float(v) if k in ("split_alpha", "refit_rebuild_ratio") else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(",") if kv)} or None
 
     def make_renderer(**kw):
         if glb:   # through the real ingest: art_glb_open + art_scene_add_glb (renderer.rs:346)

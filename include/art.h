@@ -81,8 +81,7 @@ typedef struct ArtConfig {
 #define ART_FLAG_FAST_BUILD 2u /* traversal nodes keep the LBVH topology (PREFER_FAST_BUILD); default: binned-SAH rebuild = PREFER_FAST_TRACE, vk_model.rs:968 */
 #define ART_FLAG_PACKED_TILES 4u /* sharded contexts: the compact tile buffer (the gather's payload) holds B10G11R11_UFLOAT_PACK32 words -- the reference's colour
                                    image format (renderer.rs:268) -- 4 B per pixel instead of RGB32F's 12; art_untile_gathered then assembles the packed colour image */
-#define ART_FLAG_DEVICE_TREE 8u /* build the PREFER_FAST_TRACE tree on the device (parallel locally-ordered clustering over the Morton-ordered leaves)
-                                  instead of the binned SAH (also built on the device, art_sahdev.hip): a somewhat faster build, ~4 % fewer rays/s (profiles/README.md) */
+/* (flag bit 8 was ART_FLAG_DEVICE_TREE until round 4 -- a PLOC-built tree, superseded by the binned SAH on the device: ignored) */
 #define ART_FLAG_FIXED_WAVES 16u /* every 8x8 pixel block of a frame is traced by one wave, always.  Default: adaptive -- now and then a frame counts the packet
                                   * steps of each of its waves, and blocks whose wave outlasts the launch's fair share of the GPU (a packet crossing dense distant
                                   * geometry) are dealt to 4 or 16 waves in the following frames.  The image does not depend on it. */

@@ -24,11 +24,11 @@ extern "C" {
  * nothing from the environment: a host application's environment cannot change which kernels or trees it gets.
  * Synchronises; the scene has to be built again afterwards (art_scene_build). */
 typedef struct ArtTuning {
-    uint32_t frame_form;        /* 0 one fused launch per frame (k_frame) | 1 four staged launches, packet walks | 2 four staged launches, per-ray walks */
-    uint32_t tree_builder;      /* 0 the context's default (binned SAH on the device; ART_FLAG_FAST_BUILD: LBVH topology; ART_FLAG_DEVICE_TREE: PLOC) | 1 binned SAH on the host threads */
-    uint32_t frame_waves;       /* fused frame: occupancy target per SIMD: 0 = 8 | 6 | 7 | 8 */
-    uint32_t packet_wide;       /* packet walks: 0 = default (the 128-byte 4-wide float nodes), 1 = 4-wide, 2 = the 64-byte binary nodes, 3 = 4-wide with beam node steps (4: primary rays only, 5: shadow rays only) */
-    uint32_t primary_walk, shadow_walk, ao_walk; /* override one ray type's walk: 0 default | 8 packet | 2 per-ray binary | 4 per-ray 4-wide quantised */
+    uint32_t frame_form;        /* 0 one fused launch per frame, packet walks (k_frame) | 2 four staged launches, every ray by itself (the persistent per-ray tracer).  (1 -- staged launches of
+                                 * packet walks -- went in round 4 with the other forms that had lost: the packet's beam as node step, PLOC trees, 6- / 7-wave instances) */
+    uint32_t tree_builder;      /* 0 the context's default (binned SAH on the device; ART_FLAG_FAST_BUILD: LBVH topology) | 1 binned SAH on the host threads */
+    uint32_t packet_wide;       /* the fused frame's packet walks: 0 = default (the 128-byte 4-wide float nodes), 1 = 4-wide, 2 = the 64-byte binary nodes */
+    uint32_t primary_walk, shadow_walk, ao_walk; /* frame_form 2 (and the AO rays of any frame): one ray type's per-ray walk: 0 default | 2 binary nodes | 4 quantised 4-wide nodes */
     uint32_t block_order;       /* launch order of the 256-pixel blocks: 0 XCD-aware macro-blocks of 2x2 tiles | 1 identity | n: macro-blocks of n x n tiles */
     uint32_t fixed_waves;       /* 1: no adaptive wave plan (like ART_FLAG_FIXED_WAVES) */
     uint32_t split_fixed_steps; /* wave plan: a fixed packet-step target instead of the adaptive one (0: adaptive) */
@@ -42,7 +42,6 @@ typedef struct ArtTuning {
     uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..8 (0 = 4): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
     float refit_rebuild_ratio;  /* art_trace rebuilds instead of refitting once ArtStats.refit_cost_ratio exceeds this (0 = 2.0; negative: never) */
     uint32_t trace_leaf_batch;  /* persistent per-ray tracer: lanes that must be waiting for a triangle test before the wave runs one, 1..64 (0 = presets: 1, AO rays 8) */
-    float beam_fat;             /* beam node steps: a shadow packet whose ray origins spread further than this along an axis (world units) asks every ray instead (0 = 0.25; negative: never) */
     uint32_t plan_moving_interval; /* wave plan: frames between two looks at the waves while the camera / the lights change every frame (0 = 32) */
     uint32_t refit_streams;     /* moving models: streams of their own the refits run on, beside the frames of the ring slot they precede (0 = min(frames in flight, 4); 0xFFFFFFFF: none -- every refit on its frame's stream, in front of it) */
 } ArtTuning;

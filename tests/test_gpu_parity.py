@@ -50,13 +50,13 @@ def test_ray_queries_match_oracle_bitwise(R, orc, get_scene, name, detail):
     r.close()
 
 
-FORMS = {"fused": (3, {}), "fused-1": (1, {}), "staged": (3, {"frame_form": 1}), "per-ray": (1, {"frame_form": 2}), "fused-binary": (3, {"packet_wide": 2}),
-         "fused-beam": (3, {"packet_wide": 3, "beam_fat": -1.0})}   # ArtTuning (art_set_tuning); fused-beam: node steps on the packet's beam, for every packet of one octant (no fat-beam fallback)
+FORMS = {"fused": (3, {}), "fused-1": (1, {}), "per-ray": (1, {"frame_form": 2}), "per-ray-3": (3, {"frame_form": 2}), "fused-binary": (3, {"packet_wide": 2})}   # ArtTuning (art_set_tuning): the forms libart keeps (round 4
+# removed the staged packet kernels, the packet's beam as node step, PLOC trees and the 6- / 7-wave instances: measured, lost, gone)
 
 
 def _frame_parity(R, orc, sc, w, h, n_lights, form="fused"):
-    # the three forms of the frame: one fused launch (packet walks), four staged launches (packet walks), four staged launches with
-    # the per-ray walks (binary for primary rays, 4-wide for shadow rays)
+    # the forms of the frame: one fused launch (packet walks over the 4-wide or the binary nodes), four staged launches with the per-ray walks (binary for primary rays,
+    # 4-wide for shadow rays)
     fif, tuning = FORMS[form]
     r = R.renderer_for_scene(sc, (w, h), n_lights=n_lights, keep_debug=True, frames_in_flight=fif, tuning=tuning)
     r.render_frame()
@@ -97,13 +97,13 @@ def _check_against_golden(tag, ref, keys=("primary_rays", "shadow_rays", "hit_pi
         assert ref["margin"]["worst_rel_err"] <= 2.0 * fx["gpu_margin"]["worst_rel_err"] + 1e-7, (ref["margin"], fx["gpu_margin"])
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-1", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-1", "per-ray-3", "per-ray"])
 def test_cornell_frame_matches_oracle(R, orc, get_scene, form):
     ref = _frame_parity(R, orc, get_scene("cornell"), 256, 256, None, form)
     assert ref["stats"]["shadow_rays"] > 1000
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-beam", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "per-ray-3", "per-ray"])
 @pytest.mark.parametrize("n_lights", [1, 4])
 def test_sponza_frame_matches_oracle(R, orc, scenes, get_scene, n_lights, form):
     sc = get_scene("sponza_like", 0.12)
@@ -299,7 +299,7 @@ def test_tile_buffer_ring_and_host_side_frame_completion(R, get_scene):
 
 def test_packed_tiles_gather_to_the_packed_colour_image(R, get_scene):
     """ART_FLAG_PACKED_TILES: the gather payload is B10G11R11 (the reference's colour image format, renderer.rs:268), 4 B per pixel;
-    un-tiled on shard 0 it equals the packed colour of the unsharded frame; fused and staged frames"""
+    un-tiled on shard 0 it equals the packed colour of the unsharded frame; several frames in flight and one"""
     import torch
     sc = get_scene("cornell")
     w, h, G = 200, 136, 3
@@ -358,7 +358,7 @@ def test_wide_collapse_on_the_device_equals_the_host_loop(R, get_scene, name, de
     dev.close(); host.close()
 
 
-@pytest.mark.parametrize("walk", [0, 2, 8], ids=["default", "binary", "packet"])
+@pytest.mark.parametrize("walk", [0, 2], ids=["default", "binary"])
 @pytest.mark.parametrize("name,detail,size,spp", [("cornell", 1.0, (256, 256), 16), ("sponza_like", 0.12, (480, 270), 16), ("sponza_like", 0.12, (200, 120), 5)])
 def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp, walk):
     """BASELINE config 5's pass: AO rays from the frame's depth + normal outputs; the 0..255 output is an integer: bit-exact"""
@@ -460,13 +460,13 @@ def test_frame_ring_gives_the_same_frames(R, get_scene):
 
 
 def test_frame_forms_and_trees_give_the_same_frame(R, get_scene):
-    """the fused frame kernel, the four staged packet kernels, the per-ray kernels -- on the SAH tree and on the LBVH topology
+    """the fused frame kernel (4-wide and binary nodes), the per-ray kernels -- on the device's SAH tree, the host's, and on the LBVH topology
     (ART_FLAG_FAST_BUILD): one frame, bit for bit (colour, depth, normal, ray counts); 4 lights so the light loop is covered"""
     from araytracingjourney_amd import scenes
     sc = get_scene("sponza_like", 0.12)
     w, h = 320, 200
-    def frame(frames_in_flight, fast_build=False, tuning=None, device_tree=False):
-        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=frames_in_flight, fast_build=fast_build, device_tree=device_tree, tuning=tuning)
+    def frame(frames_in_flight, fast_build=False, tuning=None):
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=frames_in_flight, fast_build=fast_build, tuning=tuning)
         for d in scenes.sponza_lights(4):
             r.lights_mut().push_dict(d)
         r.render_frame()
@@ -475,18 +475,15 @@ def test_frame_forms_and_trees_give_the_same_frame(R, get_scene):
         return out
     ref = frame(4)                                               # fused, SAH (the default with several frames in flight)
     assert ref[3]["frame_launches"] == 1 and ref[3]["shadow_rays"] > 10000
-    for name, got in (("staged packets", frame(4, tuning={"frame_form": 1})), ("per-ray", frame(1, tuning={"frame_form": 2})), ("fused, one frame in flight", frame(1)),
-                      ("fused on the LBVH topology", frame(4, fast_build=True)), ("fused on the device-built (PLOC) tree", frame(4, device_tree=True)),
-                      ("per-ray on the PLOC tree", frame(1, device_tree=True, tuning={"frame_form": 2})), ("per-ray on the LBVH topology", frame(1, fast_build=True, tuning={"frame_form": 2})),
-                      ("fused on the host-built SAH tree", frame(4, tuning={"tree_builder": 1})), ("fused, 7 waves/SIMD", frame(4, tuning={"frame_waves": 7, "packet_wide": 2})), ("fused, no block reordering", frame(4, tuning={"block_order": 1})),
-                      ("staged, per-ray primary + packet shadow", frame(2, tuning={"frame_form": 1, "primary_walk": 2})), ("fused, binary packet nodes", frame(4, tuning={"packet_wide": 2})),
-                      ("fused, 4-wide collapse on the host", frame(4, tuning={"wide_builder": 1})),
-                      ("fused, beam node steps (fat shadow beams ask every ray)", frame(4, tuning={"packet_wide": 3})), ("fused, beam node steps for every one-octant packet", frame(4, tuning={"packet_wide": 3, "beam_fat": -1.0})),
-                      ("fused, beam node steps for primary rays only", frame(4, tuning={"packet_wide": 4})), ("fused, beam node steps for shadow rays only", frame(2, tuning={"packet_wide": 5, "beam_fat": 0.5}))):
+    for name, got in (("per-ray", frame(1, tuning={"frame_form": 2})), ("per-ray, four frames in flight", frame(4, tuning={"frame_form": 2})), ("fused, one frame in flight", frame(1)),
+                      ("fused on the LBVH topology", frame(4, fast_build=True)), ("per-ray on the LBVH topology", frame(1, fast_build=True, tuning={"frame_form": 2})),
+                      ("fused on the host-built SAH tree", frame(4, tuning={"tree_builder": 1})), ("fused, no block reordering", frame(4, tuning={"block_order": 1})),
+                      ("per-ray, 4-wide nodes for primary rays too", frame(2, tuning={"frame_form": 2, "primary_walk": 4})), ("per-ray, binary nodes for shadow rays too", frame(2, tuning={"frame_form": 2, "shadow_walk": 2})),
+                      ("fused, binary packet nodes", frame(4, tuning={"packet_wide": 2})), ("fused, 4-wide collapse on the host", frame(4, tuning={"wide_builder": 1}))):
         for k in range(3):
             assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (name, k)
         assert got[3]["shadow_rays"] == ref[3]["shadow_rays"] and got[3]["hit_pixels"] == ref[3]["hit_pixels"], name
-    assert frame(4, tuning={"frame_form": 1})[3]["frame_launches"] == 4
+    assert frame(4, tuning={"frame_form": 2})[3]["frame_launches"] == 4
 
 
 def test_wave_plan_changes_the_waves_never_the_image(R, get_scene):
@@ -642,12 +639,12 @@ def _check_traversal_tree(r, same_as_karras_allowed=False):
     return T
 
 
-@pytest.mark.parametrize("builder", ["sah-device", "sah-host", "ploc-device"])
+@pytest.mark.parametrize("builder", ["sah-device", "sah-host"])
 @pytest.mark.parametrize("name,detail", [("cornell", 1.0), ("sponza_like", 0.12), ("sponza_like", 1.0)])
 def test_traversal_tree_is_a_tree_of_exact_boxes(R, get_scene, name, detail, builder):
     """what makes the SAH rebuild invisible: every leaf of the canonical LBVH hangs in the traversal tree exactly once,
     every node box is the exact min/max union of its children's boxes, the root is node 0, the depth stays inside the walks' stacks"""
-    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), device_tree=builder == "ploc-device", tuning={"tree_builder": 1} if builder == "sah-host" else None)   # binned SAH on the device (default) / on the host threads / PLOC
+    r = R.renderer_for_scene(get_scene(name, detail), (64, 64), tuning={"tree_builder": 1} if builder == "sah-host" else None)   # binned SAH on the device (default) / on the host threads
     _check_traversal_tree(r)
     r.close()
 
@@ -719,7 +716,7 @@ def test_single_triangle_known_answers(R):
 @pytest.mark.parametrize("n_tris", [1, 2, 3, 5])
 def test_tiny_scenes_on_every_builder(R, orc, n_tris):
     """one to five triangles (the tree builders' smallest inputs: no internal node, one, two ...): frame and ray queries against the oracle on the
-    default device SAH, the host SAH, PLOC and the LBVH topology"""
+    default device SAH, the host SAH and the LBVH topology"""
     from araytracingjourney_amd import scenes
     mb = scenes.MeshBuilder()
     for k in range(n_tris):
@@ -730,7 +727,7 @@ def test_tiny_scenes_on_every_builder(R, orc, n_tris):
     ref = S.render(oracle_camera(orc, sc, 96, 64), L, nl, 96, 64, threads=2, debug=True)
     rays = random_rays(4000, 11)
     rtuv, rids, _, _ = S.trace_closest(rays)
-    for kw in ({}, {"tuning": {"tree_builder": 1}}, {"device_tree": True}, {"fast_build": True}):
+    for kw in ({}, {"tuning": {"tree_builder": 1}}, {"fast_build": True}):
         r = R.renderer_for_scene(sc, (96, 64), keep_debug=True, **kw)
         r.render_frame()
         assert np.array_equal(r.read_hits()[1], ref["hit_id"]) and np.array_equal(r.read_shadow_bits(), ref["shadow_bits"]), kw
@@ -818,7 +815,7 @@ def test_api_state_and_argument_errors(R, get_scene):
     r.close()
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-binary", "fused-beam", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "per-ray-3", "per-ray"])
 def test_non_finite_cameras_are_errors_and_non_finite_rays_are_misses(R, orc, get_scene, form):
     """A camera looking along the up axis has no side vector (look_at_rh's cross product is zero): an error, like a NaN anywhere in a raw block.
     A finite block can still make non-finite rays (a projection inverse of zeros normalises the zero vector): such a ray accepts no triangle in
@@ -892,7 +889,7 @@ def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
     r.close()
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-binary", "fused-beam", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "per-ray-3", "per-ray"])
 def test_degenerate_geometry_resolves_as_the_oracle_does(R, orc, get_scene, scenes, form):
     """what a driver's traversal leaves undefined and DESIGN.md 1.1 defines: two IDENTICAL triangles (the hit goes to the lower global id), coplanar overlapping
     triangles, zero-area triangles (three collinear points, three equal points: never hit), a sliver a fraction of a pixel wide, and a fan whose shared vertex and
@@ -925,7 +922,7 @@ def test_degenerate_geometry_resolves_as_the_oracle_does(R, orc, get_scene, scen
     assert tris_hit & set(range(6, 14))                  # the fan is
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-beam", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "per-ray-3", "per-ray"])
 def test_directional_lights_along_the_axes_and_unnormalised(R, orc, get_scene, scenes, form):
     """a directional light's L, |nn_L| and the shadow ray's reciprocal direction are made on the host, once (art_api.hip directional_constants), with the
     operations the oracle runs per pixel: axis-aligned directions (zero components: the reciprocal's safe_dir branch, signed zeros), an unnormalised and a
@@ -1232,7 +1229,7 @@ def test_a_model_leaves_and_re_enters_the_structure_without_a_build(R, orc, get_
     r.close()
 
 
-@pytest.mark.parametrize("form", ["fused", "fused-binary", "staged", "per-ray"])
+@pytest.mark.parametrize("form", ["fused", "fused-binary", "per-ray-3", "per-ray"])
 def test_a_moved_model_in_every_form_of_the_frame(R, orc, get_scene, scenes, form):
     """after art_scene_set_model_matrix every form of the frame -- the binary node records and the per-ray walks follow the refit on demand -- gives the oracle's
     frame of the moved scene: hit ids, t, u, v and shadow bits bit for bit; so do ray queries, ray-traced AO, and the trees read back through the parity

@@ -18,11 +18,11 @@ for case in range(n_cases):
     packed = G > 1 and random.random() < 0.5
     B = random.choice((1, 1, 2, 3, 4))
     relief = random.choice((0, 0, 40, 200)) if G > 1 else 0
-    beam = random.choice(({}, {}, {"packet_wide": 3}, {"packet_wide": 3, "beam_fat": -1.0}, {"packet_wide": 4}, {"packet_wide": 5, "beam_fat": 0.5}))   # node steps on the packet's beam (an equivalent form)
+    beam = random.choice(({}, {}, {"packet_wide": 2}))   # the packets walk the 4-wide nodes (default) or the binary ones
     split = random.choice((8, 30, 100000))   # wave-plan target in packet steps (ArtTuning.split_fixed_steps): nearly everything / some / nothing splits
     outs = []
     for form in ("fused", "per-ray"):
-        r = R.renderer_for_scene(sc, (w, h), n_lights=0, shard=(k, G), frames_in_flight=fif, packed_tiles=packed, device_tree=random.random() < 0.3, root_relief=relief,
+        r = R.renderer_for_scene(sc, (w, h), n_lights=0, shard=(k, G), frames_in_flight=fif, packed_tiles=packed, fast_build=random.random() < 0.3, root_relief=relief,
                                  tuning={"frame_form": 2} if form == "per-ray" else dict(beam, split_fixed_steps=split))
         if form == "fused" and B > 1: r.set_frames_per_launch(B)
         for d in (lights16[:nl] if sc is spo else [dict(sc.lights[0], pos=(0.1 * i - 0.3, 0.5, 0.05 * i)) for i in range(nl)]):
@@ -36,6 +36,6 @@ for case in range(n_cases):
         r.close()
     a, b = outs
     ok = all(np.array_equal(a[i].view(np.uint32), b[i].view(np.uint32)) for i in range(3)) and a[4:7] == b[4:7] and (G == 1 or np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)))
-    print(f"case {case}: {sc.name} {w}x{h} lights {nl} F {fif} shard {k}/{G} relief {relief} packed {packed} B {B} split {split} beam {beam} (blocks split: {a[7]}): {'ok' if ok else 'MISMATCH'} rays {a[6]}+{a[4]}", flush=True)
+    print(f"case {case}: {sc.name} {w}x{h} lights {nl} F {fif} shard {k}/{G} relief {relief} packed {packed} B {B} split {split} nodes {beam} (blocks split: {a[7]}): {'ok' if ok else 'MISMATCH'} rays {a[6]}+{a[4]}", flush=True)
     if not ok: sys.exit(1)
 print("FUZZ_OK")

@@ -16,7 +16,7 @@ a = ap.parse_args()
 sc = scenes.bistro_like(1.0) if a.scene == "bistro" else scenes.sponza_like(1.0)
 lights = sc.lights if a.scene == "bistro" else scenes.sponza_lights(a.lights)
 sc = scenes.Scene(sc.name, sc.primitives, sc.camera, lights)
-tuning = {k: (float(v) if k in ("split_alpha", "refit_rebuild_ratio", "beam_fat") else int(v)) for k, v in (kv.split("=") for kv in a.tuning.split(",") if kv)} or None
+tuning = {k: (float(v) if k in ("split_alpha", "refit_rebuild_ratio") else int(v)) for k, v in (kv.split("=") for kv in a.tuning.split(",") if kv)} or None
 r = renderer.renderer_for_scene(sc, (a.width, a.height), fixed_waves=True, tuning=tuning)
 fn = C.CDLL(_lib.LIB_PATH).art_debug_packet_prof
 out = (C.c_ulonglong * 24)()
