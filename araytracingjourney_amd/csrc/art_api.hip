@@ -54,6 +54,10 @@ struct FrameSlot {
     DevBuf<uint8_t> d_occl; DevBuf<uint32_t> d_ao; bool ao_valid = false;
     DevBuf<float4> d_ao_pix;           // per local pixel: the AO rays' origin | start node, world normal | noise index (k_ao_pixels)
     DevBuf<uint32_t> d_wave_cost;      // fused frame: packet steps of each wave of the slot's last launch (feedback for the wave plan)
+    // more than 16 lights: records 16.. in a table of the slot's own (frames in flight on other slots keep theirs), uploaded on the slot's stream when the list changed since the
+    // slot's last upload; the pinned staging copy is rewritten only once the upload that read it has finished
+    DevBuf<ArtLight> d_lights_more; ArtLight *h_lights_more = nullptr; size_t h_lights_cap = 0; hipEvent_t lights_ev = nullptr; bool lights_ev_set = false; uint64_t lights_epoch = 0;
+    DevBuf<uint32_t> d_pix_more;       // fused frame, more than 16 lights: shadow rays of lights 16.. per pixel
     DevBuf<uint32_t> d_pcolor, d_pnormal, d_bgra; DevBuf<uint16_t> d_pdepth; bool presented = false; hipEvent_t ao_ev[2] = {nullptr, nullptr};
     hipEvent_t done_alias = nullptr;   // the latest frame's completion is this ring event (fused frames: one record less per frame) instead of `done`
     float4 *ext_tiles = nullptr; size_t ext_tiles_bytes = 0; // caller-owned gather source (art_bind_color_tiles)
@@ -68,7 +72,9 @@ struct FrameSlot {
     uint32_t as_version = 0;         // which version of the acceleration structure the slot's latest frame read (art_trace_ao and the read-backs follow it)
     void release() {
         d_counters.release(); d_shadow_bits.release(); d_hits.release(); d_contrib.release(); d_shadow_rays.release();
-        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_pix.release(); d_wave_cost.release(); d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
+        d_color.release(); d_normal.release(); d_color_tiles.release(); d_depth.release(); d_occl.release(); d_ao.release(); d_ao_pix.release(); d_wave_cost.release(); d_lights_more.release(); d_pix_more.release();
+        if (h_lights_more) (void)hipHostFree(h_lights_more); h_lights_more = nullptr; h_lights_cap = 0;
+        if (lights_ev) (void)hipEventDestroy(lights_ev); lights_ev = nullptr; lights_ev_set = false; d_pcolor.release(); d_pnormal.release(); d_bgra.release(); d_pdepth.release();
     }
 };
 constexpr uint32_t kMaxFrames = kMaxFrameSlots;
@@ -173,7 +179,7 @@ struct ArtContext {
     ArtCamera camera{};
     uint32_t B = 1, read_b = 0;       // frames per launch of the fused frame (art_set_frames_per_launch); which of them the read / device-pointer calls refer to
     ArtCamera cam_more[kMaxBatch - 1] = {}; // cameras of frames 1.. of a launch (frame 0: camera)
-    std::vector<ArtLight> lights;
+    std::vector<ArtLight> lights; uint64_t lights_epoch = 1;   // (bumped by every art_set_lights that changes the list)
     // frame
     std::vector<uint32_t> tile_list; uint32_t tiles_x = 0, tiles_y = 0, padded_tiles = 0, n_local = 0;
     DevBuf<uint32_t> d_tile_list;
@@ -622,6 +628,7 @@ int32_t setup_frame(ArtContext *c) {
         HIPC(hipMemset(S.d_color.p, 0, npix * B * 16)); HIPC(hipMemset(S.d_normal.p, 0, npix * B * 16)); HIPC(hipMemset(S.d_depth.p, 0, npix * B * 4));
         if (c->tiled()) { HIPC(S.d_color_tiles.ensure((size_t)c->padded_tiles * kTilePixels * B)); HIPC(hipMemset(S.d_color_tiles.p, 0, (size_t)c->padded_tiles * kTilePixels * B * c->tile_px_bytes())); }
         if ((c->cfg.flags & ART_FLAG_KEEP_DEBUG) || c->fused) HIPC(S.d_shadow_bits.ensure(c->n_local * B)); // fused frames always write their per-pixel shadow bits (stats)
+        if (c->fused && c->lights.size() > (size_t)kMaxLights) HIPC(S.d_pix_more.ensure(c->n_local * B));
         if (S.ext_tiles && S.ext_tiles_bytes != (size_t)c->padded_tiles * kTilePixels * c->tile_px_bytes() * B) { S.ext_tiles = nullptr; S.ext_ring_n = 0; S.tiles_of_last = nullptr; S.ext_tiles_bytes = 0; }
     }
     HIPC(hipDeviceSynchronize()); // the clears above ran on the null stream; the slots' streams are non-blocking
@@ -773,7 +780,7 @@ int32_t art_destroy(ArtContext *c) {
 int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     if (!c || !t) return fail(ART_E_INVALID, "art_set_tuning: null argument");
     auto walk_ok = [](uint32_t k) { return k == 0 || k == 2 || k == 4; };
-    if ((t->frame_form != 0 && t->frame_form != 2) || t->tree_builder > 1 || t->packet_wide > 2 || !walk_ok(t->primary_walk) || !walk_ok(t->shadow_walk) || !walk_ok(t->ao_walk))
+    if ((t->frame_form != 0 && t->frame_form != 2) || t->tree_builder > 1 || t->packet_wide > 2 || !walk_ok(t->primary_walk) || !walk_ok(t->shadow_walk) || !(walk_ok(t->ao_walk) || t->ao_walk == 6))
         return fail(ART_E_INVALID, "art_set_tuning: frame_form 0|2, tree_builder 0..1, packet_wide 0..2, walks 0|2|4");
     if (t->frame_form == 0 && (t->primary_walk || t->shadow_walk)) return fail(ART_E_INVALID, "art_set_tuning: the fused frame's rays are packets (primary_walk / shadow_walk choose the per-ray walks of frame_form 2)");
     if (t->as_versions > kMaxAsVersions || !(t->refit_rebuild_ratio == t->refit_rebuild_ratio)) return fail(ART_E_INVALID, "art_set_tuning: as_versions 0..8, refit_rebuild_ratio a number");
@@ -1038,13 +1045,13 @@ int32_t art_camera_from_params(const float pos[3], const float dir[3], float asp
 
 int32_t art_set_lights(ArtContext *c, const ArtLight *lights, uint32_t n) {
     if (!c || (n && !lights)) return fail(ART_E_INVALID, "art_set_lights: null argument");
-    if (n > (uint32_t)kMaxLights) return fail(ART_E_INVALID, "art_set_lights: more than 16 lights");
+    if (n > kMaxLightsTotal) return fail(ART_E_INVALID, "art_set_lights: more than 1024 lights");
     for (uint32_t i = 0; i < n; i++) if (lights[i].type > 3) return fail(ART_E_INVALID, "art_set_lights: unknown light type");
     int32_t r = use_device(c); if (r) return r;
     bool resized = n != c->lights.size();
     bool same = !resized && (n == 0 || std::memcmp(c->lights.data(), lights, (size_t)n * sizeof(ArtLight)) == 0);
     if (same) return ART_OK; // like VkLights' dirty flag (vk_lights.rs:81-139)
-    c->lights.assign(lights, lights + n);
+    c->lights.assign(lights, lights + n); c->lights_epoch++;
     plan_hint_moved(c); // the shadow walks change: look at the waves again
     if (resized) { r = sync_all(c); if (r) return r; } // the per-frame buffers are resized with the light count
     drop_graphs(c); // the records are kernel arguments (FrameArgs::lights): nothing to upload, and frames in flight keep the ones they were launched with
@@ -1100,8 +1107,11 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S, uint32_t version) 
     const AsPtrs as = as_ptrs(c, version); // the version of the acceleration structure this launch reads
     a.nodes = c->bvh.nodes; a.wide = as.wide; a.widef = as.widef; a.packet_wide = c->packet_wide; a.trace_kind[0] = c->kind_primary; a.trace_kind[1] = c->kind_shadow; a.trace_kind[2] = c->kind_ao; a.tune = TraceTune{c->tuning.trace_chunk, c->tuning.trace_refill, c->tuning.trace_blocks, c->tuning.trace_leaf_batch}; a.pipelined = c->F > 1; a.tris = as.tris; a.shade_tris = c->bvh.shade_tris; a.prims = as.prims; a.tex_pool = c->d_tex.p;
     a.n_lights = (uint32_t)c->lights.size();
-    if (a.n_lights) std::memcpy(a.lights, c->lights.data(), (size_t)a.n_lights * sizeof(ArtLight));
-    for (uint32_t i = 0; i < a.n_lights; i++) directional_constants(a.lights[i]);
+    const uint32_t n_arg = std::min(a.n_lights, (uint32_t)kMaxLights);
+    if (n_arg) std::memcpy(a.lights, c->lights.data(), (size_t)n_arg * sizeof(ArtLight));
+    for (uint32_t i = 0; i < n_arg; i++) directional_constants(a.lights[i]);
+    a.lights_more = a.n_lights > (uint32_t)kMaxLights ? S.d_lights_more.p : nullptr;   // (art_trace brings the slot's table up to date: lights_upload)
+    a.pix_more = (a.n_lights > (uint32_t)kMaxLights && c->fused) ? S.d_pix_more.p : nullptr;
     a.hits = S.d_hits.p; a.contrib = S.d_contrib.p; a.shadow_rays = S.d_shadow_rays.p; a.counters = S.d_counters.p;
     a.color = S.d_color.p; a.depth = S.d_depth.p; a.normal = S.d_normal.p;
     a.color_tiles = c->tiled() ? S.last_tiles() : nullptr; a.tiles_packed = c->tiles_packed(); // art_trace picks the frame's buffer (tiles_for)
@@ -1111,6 +1121,27 @@ static FrameArgs make_frame_args(ArtContext *c, FrameSlot &S, uint32_t version) 
     for (uint32_t i = 0; i + 1 < kMaxBatch; i++) std::memcpy(&a.cam_more[i], &c->cam_more[i], sizeof(ArtCamera));
     a.tile_xy = c->d_tile_xy.p; a.wave_items = c->plan.d_items[c->plan.cur].p; a.n_wave_items = c->plan.n_items[c->plan.cur]; a.wave_cost = nullptr; // art_trace sets it for the frames the wave plan samples
     return a;
+}
+
+// more than 16 lights: ring slot S's table of records 16.. as of the current list, on the slot's stream (in front of the frame that reads it)
+static int32_t lights_upload(ArtContext *c, FrameSlot &S, hipStream_t s) {
+    const size_t n = c->lights.size();
+    if (n <= (size_t)kMaxLights || S.lights_epoch == c->lights_epoch) return ART_OK;
+    const size_t m = n - kMaxLights;
+    if (S.lights_ev_set) HIPC(hipEventSynchronize(S.lights_ev));   // the upload that read the staging copy last
+    if (S.h_lights_cap < m) {
+        if (S.h_lights_more) (void)hipHostFree(S.h_lights_more);
+        S.h_lights_more = nullptr; S.h_lights_cap = 0;
+        HIPC(hipHostMalloc((void **)&S.h_lights_more, m * sizeof(ArtLight), hipHostMallocDefault)); S.h_lights_cap = m;
+    }
+    if (S.d_lights_more.n < m) { HIPC(hipStreamSynchronize(s)); HIPC(S.d_lights_more.ensure(m)); }   // (frames of this slot still read the old table)
+    std::memcpy(S.h_lights_more, c->lights.data() + kMaxLights, m * sizeof(ArtLight));
+    for (size_t i = 0; i < m; i++) directional_constants(S.h_lights_more[i]);
+    HIPC(hipMemcpyAsync(S.d_lights_more.p, S.h_lights_more, m * sizeof(ArtLight), hipMemcpyHostToDevice, s));
+    if (!S.lights_ev) HIPC(hipEventCreateWithFlags(&S.lights_ev, hipEventDisableTiming));
+    HIPC(hipEventRecord(S.lights_ev, s)); S.lights_ev_set = true;
+    S.lights_epoch = c->lights_epoch;
+    return ART_OK;
 }
 
 int32_t art_trace(ArtContext *c) {
@@ -1138,6 +1169,7 @@ int32_t art_trace(ArtContext *c) {
         V.used[k] = c->frame_no + 1; V.aux[k] = false;
     }
     S.as_version = ver;
+    r = lights_upload(c, S, s); if (r) return r;
     FrameArgs a = make_frame_args(c, S, ver);
     if (c->tiled()) a.color_tiles = S.tiles_for(c->frame_no, c->F); // alternates when a pair of buffers is bound
     const bool fused = c->fused && c->kind_primary == 8 && c->kind_shadow == 8;
@@ -1231,7 +1263,7 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     if (spp == 0 || spp > 64 || !(radius > 0.0f)) return fail(ART_E_INVALID, "art_trace_ao: spp must be 1..64 and radius > 0");
     if (c->B > 1) return fail(ART_E_STATE, "art_trace_ao: not with several frames per launch");
     int32_t r = use_device(c); if (r) return r;
-    r = ensure_wide(c, c->kind_ao == 4 || (c->kind_ao == 8 && c->packet_wide)); if (r) return r;
+    r = ensure_wide(c, c->kind_ao == 4 || c->kind_ao == 6); if (r) return r;
     FrameSlot &S = c->slot[c->last];
     hipStream_t s = c->stream_of(c->last);
     const size_t n_occl = (size_t)c->n_local * (((spp + 3u) >> 2) * 4u); // one byte per slot of the per-ray tracer: groups of four samples (art_trace.hip ao_slot_decode)
@@ -1249,7 +1281,7 @@ int32_t art_trace_ao(ArtContext *c, uint32_t spp, float radius) {
     }
     uint32_t lut[65] = {0};
     for (uint32_t k = 0; k <= spp; k++) lut[k] = (uint32_t)(std::pow(1.0 - (double)k / (double)spp, 2.2) * 255.0 + 0.5); // XE_GTAO_DEFAULT_FINAL_VALUE_POWER (vk_xe_gtao.rs:22)
-    r = ensure_binary(c, c->kind_ao == 2 || (c->kind_ao == 8 && !c->packet_wide)); if (r) return r;
+    r = ensure_binary(c, c->kind_ao == 2); if (r) return r;
     FrameArgs a = make_frame_args(c, S, S.as_version); // the structure the frame itself was traced in
     if (!c->as.empty()) c->as[S.as_version].aux[c->last] = true;
     HIPC(hipMemsetAsync(S.d_counters.p + 64 + 16 * 32, 0, 8 * 32 * 4, s)); // the AO launch's work cursors

@@ -66,7 +66,8 @@ struct CameraArg { float view[16], view_inv[16], proj[16], proj_inv[16], camera_
 constexpr int kTile = 32;            // shard tile edge (pixels)
 constexpr int kTilePixels = kTile * kTile;
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
-constexpr int kMaxLights = 16;
+constexpr int kMaxLights = 16;        // light records that travel in the kernel arguments
+constexpr uint32_t kMaxLightsTotal = 1024; // art_set_lights' bound (records 16.. live in a device table per ring slot)
 constexpr uint32_t kMaxFrameSlots = 24; // ring slots of a context (more than ~22 streams in use stall the command processor)
 constexpr uint32_t kTileRingMax = 8;    // caller-owned compact tile buffers per ring slot (art_bind_color_tiles_ring)
 int32_t ring_rewind(ArtContext *ctx);   // art_api.hip: waits for every frame in flight, then the next art_trace is launch 0 again (ring slot 0, first tile buffer)
@@ -206,6 +207,8 @@ struct FrameArgs {
     // the light records travel BY VALUE with every launch, like the camera block: a frame in flight can never see a later art_set_lights
     // (a device-side table, however it is double-buffered, is overwritten while launches queued 16 frames ago still hold its address)
     ArtLight lights[kMaxLights]; uint32_t n_lights;
+    const ArtLight *lights_more;   // lights kMaxLights .. n_lights - 1: a table of the frame's ring slot (device), uploaded on the slot's stream when the list changed; null up to kMaxLights
+    uint32_t *pix_more;            // fused frame, more than 16 lights: [n_local] shadow rays traced for lights 16.. per pixel (pix_bits has 16 + 16 bits); else null
     float4 *hits;              // [n_local] t,u,v,gid
     float4 *contrib;           // [n_lights][n_local]
     float4 *shadow_rays;       // [2 * n_lights * n_local] dense per (light, pixel): o.xyz,tmax (<=0: none) | d.xyz,-

@@ -153,7 +153,7 @@ __device__ __forceinline__ bool local_to_xy(uint32_t p, const uint32_t *__restri
 // Moeller-Trumbore block is ~150 instructions and, run whenever any single lane reaches a leaf, it was 60 % of all
 // issued instructions at ~2 % lane utilisation.
 constexpr int kOvfStack4 = 288; // 16 + 288 >= 3 pending siblings per level * 95 levels + 1
-template <bool ANY, int OVF> struct TravBase {
+template <bool ANY, int OVF, int LDSN = kLdsStack> struct TravBase {   // LDSN: entries of the per-lane stack that live in LDS
     Ray r;
     float tbest, bu, bv;
     uint32_t bpos, bgid;
@@ -166,13 +166,13 @@ template <bool ANY, int OVF> struct TravBase {
     __device__ __forceinline__ void push(int ref, int *lds, int *ovf) {
         // the spill accesses are volatile so that the compiler keeps them apart from the LDS ones: merged, they become flat_load
         // / flat_store on a selected pointer, which waits on vmcnt AND lgkmcnt at every pop
-        if (sp < kLdsStack) lds[sp * kTraceBlock] = ref; else if (sp < kLdsStack + OVF) *(volatile int *)&ovf[sp - kLdsStack] = ref;
-        sp = min(sp + 1, kLdsStack + OVF); // the tree cannot need more (see the bounds above); never index past the spill area
+        if (sp < LDSN) lds[sp * kTraceBlock] = ref; else if (sp < LDSN + OVF) *(volatile int *)&ovf[sp - LDSN] = ref;
+        sp = min(sp + 1, LDSN + OVF); // the tree cannot need more (see the bounds above); never index past the spill area
     }
     __device__ __forceinline__ bool pop(int *lds, int *ovf) { // true: stack empty, the ray is finished
         if (sp == 0) return true;
         sp--;
-        if (sp < kLdsStack) cur = lds[sp * kTraceBlock]; else cur = *(volatile int *)&ovf[sp - kLdsStack];
+        if (sp < LDSN) cur = lds[sp * kTraceBlock]; else cur = *(volatile int *)&ovf[sp - LDSN];
         return false;
     }
     // accept() of DESIGN.md 1.1 for the triangle in `cur`: exact triangle-AABB slab, then Moeller-Trumbore
@@ -226,7 +226,7 @@ template <bool ANY> struct Trav : TravBase<ANY, kOvfStack> {
 };
 
 // 64-byte 4-wide quantised nodes (DevNode4)
-template <bool ANY> struct Trav4 : TravBase<ANY, kOvfStack4> {
+template <bool ANY, int LDSN = kLdsStack> struct Trav4 : TravBase<ANY, kOvfStack4 + (kLdsStack - LDSN), LDSN> {
     using Nodes = const DevNode4 *;
     __device__ __forceinline__ bool step_internal(Nodes wide, int *lds, int *ovf) {
         const uint4 *nq = reinterpret_cast<const uint4 *>(wide + this->cur);
@@ -781,6 +781,103 @@ __global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(MOD
     }
 }
 
+// The AO launch's own persistent tracer (round 4): rays are MADE by the whole wave, sixty-four at a time, into a pool in LDS, and a lane that finishes TAKES its next ray from
+// the pool at once (a dozen LDS reads) -- in k_trace a finished lane waits until two dozen lanes are idle, because a refill there is ~80 instructions whoever runs it: 48 of
+// 64 lanes held a ray (profiles/README.md round 3).  Same slots, same rays, same walks (Trav4, any hit): the occlusion bytes cannot change.
+constexpr int kAoLds = 8;           // per-lane stack entries in LDS (AO rays start deep in the tree and are short: the walk rarely holds more; the rest spills)
+constexpr int kAoPoolFields = 11;   // o.xyz d.xyz inv.xyz entry slot
+constexpr uint32_t kAoPoolTake = 8; // idle lanes at which the wave turns to the pool (ArtTuning.trace_refill overrides)
+__global__ __launch_bounds__(kTraceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_trace_ao(TraceArgs a) {
+    __shared__ int stack[kAoLds * kTraceBlock];
+    __shared__ float pool[kAoPoolFields][kTraceBlock];
+    int ovf[kOvfStack4 + (kLdsStack - kAoLds)];
+    const uint32_t leaf_batch = a.leaf_batch;
+    int *lds = &stack[threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_chunks = (a.total + a.chunk - 1) / a.chunk;
+    uint32_t shard = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; // HW_REG_XCC_ID: speed only
+    uint32_t shards_left = 8;
+    uint32_t cur = 0, end = 0;   // wave-uniform: the unread part of this wave's chunk
+    uint32_t pool_n = 0;         // wave-uniform: rays in the pool
+    bool exhausted = false, active = false;
+    Trav4<true, kAoLds> tr;
+    tr.r.tmin = a.ao_radius * 0.01f; tr.r.tmax = a.ao_radius;
+    uint32_t slot = 0;
+    for (;;) {
+        const uint64_t idle = ballot64(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle >= a.refill) {
+            if (pool_n == 0 && !exhausted) {      // the pool is empty: the WHOLE wave makes the next (up to) 64 rays of its chunk
+                if (cur == end) {
+                    uint32_t got = 0xFFFFFFFFu;
+                    if (lane == 0) {
+                        while (shards_left) {
+                            uint32_t lo = (n_chunks * shard) >> 3, hi = (n_chunks * (shard + 1u)) >> 3;
+                            uint32_t c = hi > lo ? atomicAdd(&a.cursors[shard * kCursorStride], 1u) : 0u;
+                            if (hi > lo && c < hi - lo) { got = lo + c; break; }
+                            shard = (shard + 1u) & 7u; shards_left--;
+                        }
+                    }
+                    got = __builtin_amdgcn_readfirstlane(got);
+                    shard = __builtin_amdgcn_readfirstlane(shard);
+                    shards_left = __builtin_amdgcn_readfirstlane(shards_left);
+                    if (got >= n_chunks) exhausted = true;
+                    else { cur = got * a.chunk; end = min(cur + a.chunk, a.total); }
+                }
+                if (!exhausted) {
+                    const uint32_t take = min(64u, end - cur), sidx = cur + lane;
+                    bool has = false;
+                    V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f); int entry = kAoNothingNear;
+                    if (lane < take) {
+                        uint32_t p, smp;
+                        const bool real = ao_slot_decode(sidx, a.spp, p, smp);
+                        float4 po = real ? a.ao_pix[2 * (size_t)p] : make_float4(0.f, 0.f, 0.f, __int_as_float(kAoNothingNear));
+                        float4 pn = real ? a.ao_pix[2 * (size_t)p + 1] : make_float4(0.f, 0.f, 1.f, 0.f);
+                        asm volatile("" : "+v"(pn.x), "+v"(pn.y), "+v"(pn.z), "+v"(pn.w));
+                        entry = __float_as_int(po.w);
+                        if (entry != kAoNothingNear) {
+                            float4 t = a.ao_tab[smp * kAoNoiseTile + __float_as_uint(pn.w)];
+                            o = mk(po.x, po.y, po.z); d = ao_dir(mk(pn.x, pn.y, pn.z), t.x, t.y, t.z);
+                            has = ray_finite(o, d);   // (a non-finite ray accepts nothing: unoccluded, like tr.start's dead ray)
+                        }
+                        if (!has) a.occl[sidx] = 0;    // a padding slot, a miss pixel, no box within the AO radius, a dead ray: nothing to trace
+                    }
+                    const uint64_t hm = ballot64(has);
+                    if (has) {
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+                        const V3 inv = mk(1.0f / safe_dir(d.x), 1.0f / safe_dir(d.y), 1.0f / safe_dir(d.z));   // ray_init's operations
+                        pool[0][at] = o.x; pool[1][at] = o.y; pool[2][at] = o.z; pool[3][at] = d.x; pool[4][at] = d.y; pool[5][at] = d.z;
+                        pool[6][at] = inv.x; pool[7][at] = inv.y; pool[8][at] = inv.z; pool[9][at] = __int_as_float(entry); pool[10][at] = __uint_as_float(sidx);
+                    }
+                    pool_n = (uint32_t)__popcll(hm);
+                    cur += take;
+                }
+            }
+            if (pool_n) {                             // idle lanes take rays from the top of the pool
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!active && rank < pool_n) {
+                    const uint32_t at = pool_n - 1u - rank;
+                    tr.r.o = mk(pool[0][at], pool[1][at], pool[2][at]); tr.r.d = mk(pool[3][at], pool[4][at], pool[5][at]); tr.r.inv = mk(pool[6][at], pool[7][at], pool[8][at]);
+                    tr.r.ood = mk(tr.r.o.x * tr.r.inv.x, tr.r.o.y * tr.r.inv.y, tr.r.o.z * tr.r.inv.z);
+                    tr.tbest = tr.r.tmax; tr.bu = 0.f; tr.bv = 0.f; tr.bpos = kNoHit; tr.bgid = kNoHit; tr.sp = 0;
+                    tr.cur = __float_as_int(pool[9][at]); slot = __float_as_uint(pool[10][at]);
+                    active = true;
+                }
+                pool_n -= min(n_idle, pool_n);
+            } else if (exhausted) { if (n_idle == 64u) break; }
+            if (ballot64(active) == 0ull) continue;   // nothing to trace yet (a chunk of padding / misses): make more
+        }
+        bool done = false;
+#pragma unroll
+        for (int rep_ = 0; rep_ < ART_NODE_REPS; rep_++)
+            if (active && !done && tr.cur >= 0) done = tr.step_internal(a.wide, lds, ovf);
+        const bool on_leaf = active && !done && tr.cur < 0;
+        const uint64_t lm = ballot64(on_leaf);
+        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_batch || ballot64(active && !done && tr.cur >= 0) == 0ull)) { if (on_leaf) done = tr.step_leaf(a.tris, lds, ovf); }
+        if (done) { active = false; a.occl[slot] = tr.bpos != kNoHit ? 1 : 0; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ lights (light.glsl)
 __device__ V3 compute_barycentric(V3 a, V3 b, V3 c, V3 p) { // light.glsl:50-68
     V3 v0 = b - a, v1 = c - a, v2 = p - a;
@@ -953,6 +1050,25 @@ __device__ __forceinline__ bool shade_light(const ArtLight &l, const Surface &S,
     return false;
 }
 
+// Light i of a frame: the first kMaxLights records travel by value in the kernel arguments (FrameArgs::lights), the rest -- the reference's list is a Vec, vk_lights.rs:89-91 --
+// in a table of the frame's ring slot.  Both are read through the constant address space (wave-uniform, read-only: scalar loads, also behind the frame's own stores).
+// (The argument copy is addressed through the kernel-argument segment pointer: FrameArgs is the first -- by-value -- argument of k_frame and k_shade, and taking the address of
+// a.lights[i] itself would make the compiler copy all 2.6 KB of it to scratch.)
+__device__ __forceinline__ ArtLight frame_light(const FrameArgs &a, uint32_t i) {
+    ArtLight L;
+#ifdef __HIP_DEVICE_COMPILE__
+    typedef __attribute__((address_space(4))) const uint32_t *Words;
+    const Words args = (Words)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(FrameArgs, lights));
+    const Words p = i < (uint32_t)kMaxLights ? args + i * (uint32_t)(sizeof(ArtLight) / 4) : (Words)(uintptr_t)(a.lights_more + (i - (uint32_t)kMaxLights));
+    uint32_t w[sizeof(ArtLight) / 4];
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(ArtLight) / 4; k++) w[k] = p[k];
+    __builtin_memcpy(&L, w, sizeof(ArtLight));
+#else
+    L = a.lights[i < (uint32_t)kMaxLights ? i : 0];   // (host pass of the compiler only)
+#endif
+    return L;
+}
 // staged frame, stage 2: emits one shadow ray per (pixel, light) that needs it
 __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
     if (blockIdx.x * kBlock >= a.n_local) return;
@@ -976,7 +1092,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(FrameArgs a) {
         shade_surface(a, a.cam, pos, h.y, h.z, S, out_depth, out_normal);
         for (uint32_t i = 0; i < a.n_lights; i++) {
             float4 c4, ro, rd;
-            bool want = shade_light(a.lights[i], S, c4, ro, rd);
+            const ArtLight L = frame_light(a, i);
+            bool want = shade_light(L, S, c4, ro, rd);
             size_t slot = (size_t)i * a.n_local + p;
             st_nt(&a.contrib[slot], c4);
             if (want) {
@@ -1080,15 +1197,16 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(8, 
     }
     PHASE(2, S.NdotV)
     float rx = 0.f, ry = 0.f, rz = 0.f;
-    uint32_t sbits = 0;
+    uint32_t sbits = 0, more = 0;
     // (until the walks fetched their nodes into SGPRs the multi-light instance parked the surface record in LDS across each shadow walk; it fits now)
     for (uint32_t i = 0; i < (ONE_LIGHT ? 1u : a.n_lights); i++) { // uniform loop: the shadow packet needs the whole wave
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), ro = make_float4(0.f, 0.f, 0.f, 1.0f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
         bool want = false;
-        if (hit) want = shade_light(a.lights[i], S, c4, ro, rd);
-        if (want) sbits |= 1u << (16 + i);
+        const ArtLight L = ONE_LIGHT ? a.lights[0] : frame_light(a, i);
+        if (hit) want = shade_light(L, S, c4, ro, rd);
+        if (want) { if (i < 16u) sbits |= 1u << (16u + i); else more++; }   // (lights 16.. have no bits of their own: their shadow rays are counted)
         Ray sr;
-        if (a.lights[i].type == 2u) ray_init_inv(sr, mk(ro.x, ro.y, ro.z), ld3(a.lights[i].area_pos2), ld3(a.lights[i].area_pos3), 0.01f, a.lights[i].penumbra_angle); // (wave-uniform branch)
+        if (L.type == 2u) ray_init_inv(sr, mk(ro.x, ro.y, ro.z), ld3(L.area_pos2), ld3(L.area_pos3), 0.01f, L.penumbra_angle); // (wave-uniform branch)
         else ray_init(sr, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), 0.01f, ro.w);
         bool son = want && ray_finite(sr.o, sr.d);
         PHASE(3, sr.inv.x)
@@ -1098,7 +1216,7 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(8, 
         PHASE(4, st)
         if (want && spos != kNoHit) { // shadowed: the light keeps 0.05 of its contribution (raytrace.rgen.glsl:179-181)
             c4 = make_float4(c4.x * 0.05f, c4.y * 0.05f, c4.z * 0.05f, c4.w);
-            sbits |= 1u << i;
+            if (i < 16u) sbits |= 1u << i;
         }
         rx += c4.x * c4.w; ry += c4.y * c4.w; rz += c4.z * c4.w; // rgen:185, lights in order
     }
@@ -1114,6 +1232,7 @@ __global__ __launch_bounds__(kFrameBlock) __attribute__((amdgpu_waves_per_eu(8, 
         else st_nt_rgb(a.color_tiles, ti, o);
     }
     if (mine) a.pix_bits[frame_local + p] = sbits;
+    if (!ONE_LIGHT && a.pix_more && mine) a.pix_more[frame_local + p] = more;   // more than 16 lights: shadow rays of lights 16.. (art_get_stats)
     PHASE(5, rx)
 #ifdef ART_PHASE_PROF
     if (__lane_id() == 0 && blockIdx.x < kPhaseWaves) { g_phase[6][blockIdx.x] = 1u; g_phase[7][blockIdx.x] = steps; }
@@ -1211,7 +1330,7 @@ __global__ __launch_bounds__(kBlock) void k_frame_stats(FrameArgs a, uint32_t *o
     if (p < a.n_local) {
         uint32_t x, y;
         bool in = local_to_xy(p, a.tile_list, a.tiles_x, a.W, a.H, x, y);
-        rays = (uint32_t)__popc(a.pix_bits[p] >> 16);
+        rays = (uint32_t)__popc(a.pix_bits[p] >> 16) + (a.pix_more ? a.pix_more[p] : 0u);
         hits = in && a.depth[(size_t)y * a.W + x] < 10000.0f ? 1u : 0u;
     }
     for (int off = 32; off >= 1; off >>= 1) { rays += (uint32_t)__shfl_xor((int)rays, off); hits += (uint32_t)__shfl_xor((int)hits, off); }
@@ -1379,13 +1498,18 @@ __global__ __launch_bounds__(kBlock) void k_ao_resolve(FrameArgs a, const uint8_
 void launch_ao_table(uint32_t spp, float4 *tab, hipStream_t s) { k_ao_table<<<blocks_for(kAoNoiseTile), kBlock, 0, s>>>(spp, tab); }
 void launch_ao(const FrameArgs &f, uint32_t spp, float radius, uint8_t *occl, float4 *pix, const float4 *tab, bool entry_search, uint32_t *ao, const uint32_t *lut, hipStream_t s) {
     AoLut l; for (uint32_t k = 0; k < 65; k++) l.v[k] = lut[k];
-    k_ao_pixels<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, (f.trace_kind[2] == 4 && entry_search) ? f.wide : nullptr, radius, pix); // one point, normal and entry node per pixel for its spp rays
+    k_ao_pixels<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, ((f.trace_kind[2] == 4 || f.trace_kind[2] == 6) && entry_search) ? f.wide : nullptr, radius, pix); // one point, normal and entry node per pixel for its spp rays
     const uint32_t n_slots = (f.n_local / 16u) * (((spp + 3u) >> 2) * 64u); // ao_slot_decode
     TraceArgs a{};
     a.nodes = f.nodes; a.wide = f.wide; a.tris = f.tris; a.total = n_slots; a.cursors = f.counters + 64 + 16 * kCursorStride; a.cam = f.cam; a.W = f.W; a.H = f.H;
     a.tile_list = f.tile_list; a.tiles_x = f.tiles_x; a.depth = f.depth; a.normal = f.normal; a.spp = spp; a.ao_radius = radius; a.occl = occl;
     a.ao_pix = pix; a.ao_tab = tab;
-    launch_trace<MODE_AO>(a, f.trace_kind[2], f.pipelined, f.tune, s);
+    if (f.trace_kind[2] == 4) {   // the default: the AO launch's own tracer (rays made by the whole wave into a pool); 6 = the same walk through the generic tracer (round 3's form), 2 = binary nodes
+        Tune t = tune(f.pipelined, true, f.tune);
+        if (!(f.tune.refill >= 1 && f.tune.refill <= 64)) t.refill = kAoPoolTake;
+        a.chunk = t.chunk; a.refill = t.refill; a.leaf_batch = t.leaf_batch;
+        k_trace_ao<<<persistent_blocks(a.total, t), kTraceBlock, 0, s>>>(a);
+    } else launch_trace<MODE_AO>(a, f.trace_kind[2] == 6 ? 4 : f.trace_kind[2], f.pipelined, f.tune, s);
     k_ao_resolve<<<blocks_for(f.n_local), kBlock, 0, s>>>(f, occl, spp, l, ao);
 }
 void launch_untile(const float4 *gathered, const uint32_t *tile_slot, uint32_t shard_stride, uint32_t n_frames, uint32_t frame_stride, uint32_t W, uint32_t H, float4 *frame, hipStream_t s) {

@@ -175,8 +175,9 @@ int32_t art_set_camera(ArtContext *ctx, const ArtCamera *cam);
 int32_t art_camera_from_params(const float pos[3], const float dir[3], float aspect, float fovy, float znear,
                                float zfar, ArtCamera *out);
 
-/* VkLights::update_host_and_device_buffer (vk_lights.rs:81-139): n 80-byte records; and their producers
- * (lights.rs:144-159, :228-243, :281-296, :383-403) */
+/* VkLights::update_host_and_device_buffer (vk_lights.rs:81-139): n 80-byte records -- at most 1024 (the reference's list is a Vec behind an SSBO of n x 80 bytes, vk_lights.rs:89-91:
+ * no bound but memory; libart carries the first 16 in the kernel arguments of every launch and the rest in a table per ring slot, so a frame in flight never sees a later list);
+ * and their producers (lights.rs:144-159, :228-243, :281-296, :383-403).  art_read_shadow_bits (include/art_parity.h) reports the first 16 lights; ArtStats.shadow_rays counts all. */
 int32_t art_set_lights(ArtContext *ctx, const ArtLight *lights, uint32_t n);
 int32_t art_light_point(const float pos[3], const float color[3], float falloff, int32_t casts_shadows, ArtLight *out);
 int32_t art_light_spot(const float pos[3], const float dir[3], const float color[3], float falloff, float penumbra,

@@ -358,7 +358,7 @@ def test_wide_collapse_on_the_device_equals_the_host_loop(R, get_scene, name, de
     dev.close(); host.close()
 
 
-@pytest.mark.parametrize("walk", [0, 2], ids=["default", "binary"])
+@pytest.mark.parametrize("walk", [0, 2, 6], ids=["default", "binary", "generic-tracer"])
 @pytest.mark.parametrize("name,detail,size,spp", [("cornell", 1.0, (256, 256), 16), ("sponza_like", 0.12, (480, 270), 16), ("sponza_like", 0.12, (200, 120), 5)])
 def test_ray_traced_ao_matches_oracle_exactly(R, orc, get_scene, name, detail, size, spp, walk):
     """BASELINE config 5's pass: AO rays from the frame's depth + normal outputs; the 0..255 output is an integer: bit-exact"""
@@ -867,7 +867,7 @@ def test_non_finite_cameras_are_errors_and_non_finite_rays_are_misses(R, orc, ge
 
 
 def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
-    """the light table's upper bound (16) and a light change between frames (VkLights dirty flag, vk_lights.rs:81-139)"""
+    """sixteen lights -- what the kernel arguments carry -- a light change between frames (VkLights dirty flag, vk_lights.rs:81-139), and the list's upper bound (1024)"""
     import math
     sc = get_scene("cornell")
     lights = [dict(kind="point", pos=(0.3 * math.cos(k), 0.3, 0.3 * math.sin(k)), color=(0.5 + 0.1 * k, 0.6, 0.9 - 0.05 * k), falloff=3.0, casts_shadows=(k % 3 != 0))
@@ -883,7 +883,7 @@ def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
     b = r.read_color()
     assert not np.array_equal(a, b) and b[..., 0].max() == 0 and b[..., 2].max() == 0 and b[..., 1].max() > 0
     with pytest.raises(Exception):
-        for k in range(17):
+        for k in range(1025):
             r.lights_mut().get_point_lights_mut().append(R.PointLight((0, 0.5, 0), (1, 1, 1), 3.0, False))
         r.upload_state()
     r.close()
@@ -968,6 +968,66 @@ def test_lights_change_every_frame_while_sixteen_frames_are_in_flight(R, orc, ge
     for i in range(F):
         ref = S.render(cam, orc.make_lights(lights[i]), 2, w, h, threads=8)
         assert_radiance_close(frames[i], ref["color"], what=f"frame {i}")
+    r.close()
+
+
+@pytest.mark.parametrize("form", ["fused", "per-ray"])
+def test_forty_lights_some_changing_every_frame(R, orc, get_scene, scenes, form):
+    """The reference's light list is a Vec behind an SSBO of n x 80 bytes that the shader loops over (lights.rs:4-67, vk_lights.rs:89-91, raytrace.rgen.glsl:150); libart carries
+    the first 16 records in the kernel arguments and the rest in a table of the frame's ring slot (rounds 1-3 refused more than 16).  Forty lights of all four kinds, two of them
+    -- record 1 and record 29 -- changing every frame with four frames in flight: every frame shows ITS lights against the oracle (depth and normal bit-equal, radiance 1e-4),
+    and the shadow rays counted are the oracle's"""
+    from helpers import device_to_host
+    import math
+    sc = get_scene("sponza_like", 0.12)
+    w, h, F = 480, 270, 4
+    fif, tuning = (F, None) if form == "fused" else (1, {"frame_form": 2})
+    base = []
+    for i in range(40):
+        a = 2.0 * math.pi * i / 40.0
+        if i % 4 == 0: base.append(dict(kind="point", pos=(0.9 * math.cos(a), 0.3 + 0.02 * i, 0.5 * math.sin(a)), color=(0.6 + 0.05 * i, 0.9, 0.4 + 0.03 * i), falloff=2.5, casts_shadows=True))
+        elif i % 4 == 1: base.append(dict(kind="spot", pos=(0.7 * math.cos(a), 1.0, 0.4 * math.sin(a)), dir=(-0.3 * math.cos(a), -1.0, -0.3 * math.sin(a)), color=(1.5, 1.2, 0.5 + 0.04 * i), falloff=4.0, penumbra=0.3, umbra=0.6, casts_shadows=i % 8 == 1))
+        elif i % 4 == 2: base.append(dict(kind="directional", dir=(-0.3 + 0.02 * i, -1.0, -0.2), color=(0.15, 0.12 + 0.004 * i, 0.1), casts_shadows=True))
+        else: base.append(dict(kind="area", pos=(0.3 * math.cos(a), 1.2, 0.3 * math.sin(a)), pos2=(0.3 * math.cos(a) + 0.2, 1.2, 0.3 * math.sin(a)), pos3=(0.3 * math.cos(a) + 0.2, 1.2, 0.3 * math.sin(a) + 0.2), invert_normal=True, color=(0.8, 0.8, 1.0), falloff=3.0, penumbra=0.5, umbra=1.2, casts_shadows=True))
+    def lights_of(frame):   # in the order lights travel in: points, spots, directionals, areas (lights.rs:24-47)
+        L = [dict(d) for kind in ("point", "spot", "directional", "area") for d in base if d["kind"] == kind]
+        assert L[1]["kind"] == "point" and L[29]["kind"] == "directional"
+        L[1]["pos"] = (0.9 * math.cos(0.5 * frame), 0.4, 0.3 * math.sin(0.5 * frame))
+        L[29]["dir"] = (0.4 - 0.2 * frame, -1.0, 0.1 * frame)
+        return L
+    def push(r, L):
+        lm = r.lights_mut()
+        for lst in (lm.get_point_lights_mut(), lm.get_spot_lights_mut(), lm.get_directional_lights_mut(), lm.get_area_lights_mut()):
+            del lst[:]
+        for d in L:
+            lm.push_dict(d)
+    r = R.renderer_for_scene(sc, (w, h), n_lights=0, frames_in_flight=fif, tuning=tuning)
+    push(r, lights_of(0)); r.render_frame()                 # buffers allocated (40 lights), wave plan sampled
+    S = orc.Scene(sc.primitives, morton_bits=30)
+    cam = oracle_camera(orc, sc, w, h)
+    ptrs = []
+    for f in range(F):
+        push(r, lights_of(f + 1)); r.upload_state(); r.trace()
+        if fif == 1:
+            r.sync()
+            ref = S.render(cam, orc.make_lights(lights_of(f + 1)), 40, w, h, threads=8)
+            assert r.stats()["shadow_rays"] == ref["stats"]["shadow_rays"], f
+            assert np.array_equal(r.read_depth().view(np.uint32), ref["depth"].view(np.uint32)), f
+            assert_radiance_close(r.read_color(), ref["color"], what=f"per-ray frame {f}, 40 lights")
+        else:
+            ptrs.append((r.device_color(), r._dev("depth"), r._dev("normal")))   # back to back, no host sync: each slot's table travels on its own stream
+    r.sync()
+    if fif > 1:
+        assert len({t[0][0] for t in ptrs}) == F               # every frame of the trip has its own slot
+        last = None
+        for f, t in enumerate(ptrs):
+            col, dep, nor = (device_to_host(p, n) for p, n in t)
+            ref = S.render(cam, orc.make_lights(lights_of(f + 1)), 40, w, h, threads=8)
+            assert np.array_equal(dep.view(np.uint32).reshape(h, w), ref["depth"].view(np.uint32)), f
+            assert np.array_equal(nor.view(np.uint32).reshape(h, w, 4)[..., :3], ref["normal"].view(np.uint32)[..., :3]), f
+            assert_radiance_close(col.view(np.float32).reshape(h, w, 4), ref["color"], what=f"frame {f} of 40 lights")
+            last = ref
+        assert r.stats()["shadow_rays"] == last["stats"]["shadow_rays"]   # (the latest frame's)
     r.close()
 
 
