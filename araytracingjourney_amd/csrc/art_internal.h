@@ -83,9 +83,10 @@ struct BuildInputs {
 // A phase reserves what it needs (nothing of an earlier phase is live: every phase ends with a stream synchronisation), then takes its pieces.
 struct Arena {
     char *base = nullptr; size_t cap = 0, off = 0;
+    uint64_t generation = 0;   // bumped by every reserve(): a pointer taken in an earlier phase is stale (take_checked in sanitizer / debug builds)
     static size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
     hipError_t reserve(size_t bytes) {
-        off = 0;
+        off = 0; generation++;
         if (bytes <= cap) return hipSuccess;
         if (base) (void)hipFree(base);
         base = nullptr; cap = 0;

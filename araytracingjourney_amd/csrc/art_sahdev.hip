@@ -435,13 +435,14 @@ hipError_t sah_build_device(Lbvh &l, uint32_t T, hipStream_t s) {
         const uint32_t gT = (T + kBlockB - 1) / kBlockB;
         auto blocks = [](size_t items, uint32_t per_block, uint32_t cap) { size_t b = (items + per_block - 1) / per_block; return (uint32_t)(b < 1 ? 1 : (b > cap ? cap : b)); };
         const uint32_t init[16] = {1u, 0u, 0u, 0u, T > kMid ? 1u : 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // [0 / 1] open ranges of this / the next level, [2] small ranges, [4 / 5] ranges of more than kMid leaves
-        HIPQ(hipMemcpyAsync(n_cnt, init, sizeof(init), hipMemcpyHostToDevice, s));
+        HIPQ(hipMemcpy(n_cnt, init, sizeof(init), hipMemcpyHostToDevice));   // (init is a local: a synchronous copy; the stream was synchronised above)
         const bool root_small = T <= kSmall;   // the whole scene is a small range
         k_iota<<<gT, kBlockB, 0, s>>>(T, idx[0], range_of[0], root_small ? kNone : 0u);
-        if (root_small) {
+        if (root_small) {   // (synchronous copies: the sources are locals of this block -- an asynchronous copy of pageable memory happens to be staged before it returns, but nothing says so)
             const SmallRange root{0, T, 0, 0}; const uint32_t one_zero[3] = {0u, 0u, 1u};
-            HIPQ(hipMemcpyAsync(small, &root, sizeof(root), hipMemcpyHostToDevice, s));
-            HIPQ(hipMemcpyAsync(n_cnt, one_zero, sizeof(one_zero), hipMemcpyHostToDevice, s));
+            HIPQ(hipStreamSynchronize(s));
+            HIPQ(hipMemcpy(small, &root, sizeof(root), hipMemcpyHostToDevice));
+            HIPQ(hipMemcpy(n_cnt, one_zero, sizeof(one_zero), hipMemcpyHostToDevice));
         } else {
             k_root_range<<<1, 1, 0, s>>>(T, l.cbounds, ranges[0]);   // the root's domain: the bounds of the centroids, which the Morton keys were made over
         }

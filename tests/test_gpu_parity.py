@@ -1106,6 +1106,41 @@ def test_a_model_moves_every_frame_with_sixteen_frames_in_flight(R, orc, get_sce
     r.close()
 
 
+@pytest.mark.parametrize("F", [1, 2, 4])
+def test_moving_frames_lap_the_ring_of_versions_without_a_sync(R, orc, get_scene, scenes, F):
+    """advisor, round 3: no test reused a ring slot or a version without a host sync in between.  F x 4 + 3 moving frames launched back to back through F ring slots and a
+    ring of 4 versions (every version is rewritten four times, its staging memory with it; the refits run on streams of their own beside the frames): the LAST F frames --
+    the ones whose outputs still exist -- are the oracle's frames of scenes built from scratch, depth and normal bit for bit"""
+    from helpers import device_to_host
+    sc = get_scene("sponza_like", 0.12)
+    w, h, K = 320, 180, 4
+    lights = scenes.sponza_lights(1)
+    movers = [len(sc.primitives) - 1, len(sc.primitives) - 2]
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, frames_in_flight=F, tuning={"as_versions": K, "refit_rebuild_ratio": -1.0})
+    model = r.models_mut()[1]
+    base = moving[0].model
+    r.render_frame()
+    n = F * K + 3
+    ptrs, poses = [], []
+    for i in range(n):
+        m = _pose(base, i + 1)
+        model.set_model_matrix(m)
+        poses.append(m)
+        r.upload_state(); r.trace()
+        ptrs.append((r.device_color(), r._dev("depth"), r._dev("normal")))
+    r.sync()
+    assert r.stats()["refits"] == n
+    cam = oracle_camera(orc, sc, w, h)
+    L = orc.make_lights(lights)
+    for i in range(n - F, n):
+        ref = _oracle_of_moved(orc, scenes, static, moving, poses[i]).render(cam, L, len(lights), w, h, threads=8, debug=True)
+        (pc, nc), (pd, nd), (pn, nn) = ptrs[i]
+        assert np.array_equal(device_to_host(pd, nd).view(np.uint32).reshape(h, w), ref["depth"].view(np.uint32)), f"frame {i}: depth"
+        assert np.array_equal(device_to_host(pn, nn).view(np.uint32).reshape(h, w, 4), ref["normal"].view(np.uint32)), f"frame {i}: normal"
+        assert_radiance_close(device_to_host(pc, nc).view(np.float32).reshape(h, w, 4), ref["color"], what=f"frame {i}")
+    r.close()
+
+
 @pytest.mark.parametrize("config", ["c2", "c4"])
 def test_a_moved_model_at_the_bench_scenes_full_size(R, orc, get_scene, scenes, config):
     """row a3 at the sizes BASELINE names: config 2 (262 816 triangles; the model that moves is its u32-index primitive, 164 k triangles) and config 4 (2.8 M
