@@ -550,7 +550,7 @@ def main():
             if ga and ga["ao_rays"] == st["ao_rays"]:
                 ab = dict(contract=(32 + 1) * ga["ao_rays"] + 64 * ga["n_int_ao"] + 48 * ga["n_tri_ao"])   # SURVEY 8(d) per ray on the canonical LBVH: ray + nodes + triangles + the occlusion byte
             fr = RL.fractions(pmc, us, ab)
-            roof = dict(bound="valu_issue" if "valu_issue_frac" in fr else None, kernel="k_trace<MODE_AO, 4-wide> (the AO launch's persistent per-ray tracer)",
+            roof = dict(bound="valu_issue" if "valu_issue_frac" in fr else None, kernel="k_trace_ao (the AO launch's persistent per-ray tracer: rays made by the whole wave into a pool in LDS)",
                         achieved=pmc["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9 if "SQ_INSTS_VALU" in pmc else None, peak=RL.SIMDS * RL.CLOCK_HZ / RL.VALU_CYCLES / 1e9, unit="G wave-instructions/s",
                         frac=fr.get("valu_issue_frac"), traffic=fr.get("hbm_bytes_per_launch"), hbm_frac=fr.get("hbm_frac"), valu_issue_frac=fr.get("valu_issue_frac"), salu_issue_frac=fr.get("salu_issue_frac"),
                         valu_lane_utilisation=fr.get("valu_lane_utilisation"),

@@ -7,7 +7,7 @@ Inputs (all under profiles/, all produced on the GPU box by tools/profile_round.
     config 2   <tag>_pmc.txt      <tag>_bench_line.json   (+ <tag>_kernel_stats_bench_c2.csv: rocprofv3 --kernel-trace --stats of `bench.py --steps 1000`)
     config 3   <tag>_pmc_c3.txt   <tag>_config3.json
     config 4   <tag>_pmc_c4.txt   <tag>_config4.json
-    config 5   <tag>_pmc_c5.txt   <tag>_config5.json      (dominant kernel: the AO launch's k_trace<4, 4>)
+    config 5   <tag>_pmc_c5.txt   <tag>_config5.json      (dominant kernel: the AO launch's k_trace_ao -- k_trace<4, 4> until round 3)
 (a pmc file: one line per kernel and pass, name {counter: mean} n=launches) and tests/golden/<config>.stats.json (the oracle's visit counters of that frame).
 
 What it prints (and writes to profiles/<tag>_roofline.json; --set-current also writes profiles/current_pmc.json, the file bench.py reads
@@ -116,7 +116,7 @@ CONFIGS = {  # what a profile round covers: name -> (file suffixes under profile
     "c2": dict(pmc="pmc.txt", line="bench_line.json", kernel="k_frame", golden="c2_sponza_like_1080p_1light", lights=1),
     "c3": dict(pmc="pmc_c3.txt", line="config3.json", kernel="k_frame", golden="c3_sponza_like_2160p_4lights", lights=4),
     "c4": dict(pmc="pmc_c4.txt", line="config4.json", kernel="k_frame", golden="c4_bistro_like_1080p_1light", lights=1),
-    "c5": dict(pmc="pmc_c5.txt", line="config5.json", kernel="k_trace<4, 4>", golden="c5_sponza_like_2160p_16spp_ao", lights=1),
+    "c5": dict(pmc="pmc_c5.txt", line="config5.json", kernel=("k_trace_ao", "k_trace<4, 4>"), golden="c5_sponza_like_2160p_16spp_ao", lights=1),   # round 4: the AO launch's own tracer; before: the generic one
 }
 
 
@@ -131,7 +131,12 @@ def main():
         fp, fl = os.path.join(P, f"{a.tag}_{c['pmc']}"), os.path.join(P, f"{a.tag}_{c['line']}")
         if not (os.path.exists(fp) and os.path.exists(fl)):
             continue
-        pmc, launches = parse_pmc_txt(fp, c["kernel"])
+        kernels = c["kernel"] if isinstance(c["kernel"], tuple) else (c["kernel"],)
+        for kname in kernels:
+            pmc, launches = parse_pmc_txt(fp, kname)
+            if launches:
+                break
+        c = dict(c, kernel=kname)
         line = json.load(open(fl))
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", c["golden"] + ".stats.json")))
         if name == "c5":   # the AO launch: its machine time is the step minus the frames without their AO pass (bench.py measures both)
