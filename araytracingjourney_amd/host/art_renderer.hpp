@@ -151,6 +151,7 @@ public:
     Renderer(uint32_t width, uint32_t height, int device = -1, uint32_t frames_in_flight = 1)
         : w_(width), h_(height), camera_({0, 0, 0}, {0, 0, 1}, (float)width / (float)height, 1.57079632679f, 0.1f, 1000.0f) {
         ArtConfig cfg{}; cfg.device = device; cfg.width = width; cfg.height = height; cfg.frames_in_flight = frames_in_flight;
+        cfg.flags = ART_FLAG_DYNAMIC_SCENE;   // this host moves its models (set_model_matrix) and switches them in and out by residency: the ring of structure versions is made by the build, not by the first moved frame
         check(art_create(&cfg, &ctx_));
     }
     Renderer(const Renderer &) = delete;

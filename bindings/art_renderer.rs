@@ -21,7 +21,7 @@ pub struct ArtRayTracedRenderer {
 impl ArtRayTracedRenderer {
     /// VulkanTempleRayTracedRenderer::new (renderer.rs:140): extent + the FrameData ring depth (renderer.rs:135 keeps 3)
     pub fn new(width: u32, height: u32, frames_in_flight: u32) -> Self {
-        let cfg = ArtConfig { device: -1, width, height, morton_bits: 0, shard_rank: 0, shard_count: 1, flags: 0, frames_in_flight, root_relief: 0 };
+        let cfg = ArtConfig { device: -1, width, height, morton_bits: 0, shard_rank: 0, shard_count: 1, flags: ART_FLAG_DYNAMIC_SCENE /* models move: art_scene_build also makes the version ring */, frames_in_flight, root_relief: 0 };
         let mut ctx = std::ptr::null_mut();
         check(unsafe { art_create(&cfg, &mut ctx) });
         let (pos, dir) = ([0.0f32; 3], [0.0f32, 0.0, 1.0]); // defaults of renderer.rs:222-231

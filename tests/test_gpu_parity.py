@@ -1106,6 +1106,42 @@ def test_a_model_moves_every_frame_with_sixteen_frames_in_flight(R, orc, get_sce
     r.close()
 
 
+@pytest.mark.parametrize("dynamic", [False, True], ids=["versions-at-first-move", "versions-at-build"])
+def test_a_small_tree_is_all_crown_and_moves_all_the_same(R, orc, get_scene, scenes, dynamic):
+    """the Cornell box (34 triangles: a tree of a dozen nodes, smaller than one batch of the refit -- everything is the crown's one workgroup) with its last primitive moving
+    before every frame, four frames in flight: every frame is the oracle's frame of a scene built from scratch; and ART_FLAG_DYNAMIC_SCENE makes the ring of versions in
+    art_scene_build (first_move_ms 0, versions_ms > 0) where a scene that did not announce it pays in front of its first moved frame"""
+    from helpers import device_to_host
+    sc = get_scene("cornell")
+    w, h, F = 160, 160, 4
+    movers = [len(sc.primitives) - 1]
+    r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), sc.lights, frames_in_flight=F, dynamic_scene=dynamic)
+    model = r.models_mut()[1]
+    base = moving[0].model
+    r.render_frame()
+    st0 = r.stats()
+    assert (st0["versions_ms"] > 0) == dynamic and st0["first_move_ms"] == 0
+    ptrs, poses = [], []
+    for i in range(F):
+        m = _pose(base, i + 1)
+        m[:, 3] = np.asarray(base, np.float32).reshape(3, 4)[:, 3] + np.float32(0.02 * (i + 1)) * np.array([1.0, 0.5, -1.0], np.float32)   # (small steps: the box stays inside the room)
+        model.set_model_matrix(m); poses.append(m.copy())
+        r.upload_state(); r.trace()
+        ptrs.append((r.device_color(), r._dev("depth"), r._dev("normal")))
+    r.sync()
+    st = r.stats()
+    assert st["refits"] == F and (st["first_move_ms"] == 0) == dynamic and st["versions_ms"] > 0
+    cam = oracle_camera(orc, sc, w, h)
+    L = orc.make_lights(sc.lights)
+    for i in range(F):
+        ref = _oracle_of_moved(orc, scenes, static, moving, poses[i]).render(cam, L, len(sc.lights), w, h, threads=4, debug=True)
+        (pc, nc), (pd, nd), (pn, nn) = ptrs[i]
+        assert np.array_equal(device_to_host(pd, nd).view(np.uint32).reshape(h, w), ref["depth"].view(np.uint32)), f"frame {i}: depth"
+        assert np.array_equal(device_to_host(pn, nn).view(np.uint32).reshape(h, w, 4), ref["normal"].view(np.uint32)), f"frame {i}: normal"
+        assert_radiance_close(device_to_host(pc, nc).view(np.float32).reshape(h, w, 4), ref["color"], what=f"frame {i}")
+    r.close()
+
+
 @pytest.mark.parametrize("F", [1, 2, 4])
 def test_moving_frames_lap_the_ring_of_versions_without_a_sync(R, orc, get_scene, scenes, F):
     """advisor, round 3: no test reused a ring slot or a version without a host sync in between.  F x 4 + 3 moving frames launched back to back through F ring slots and a
