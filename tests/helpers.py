@@ -44,3 +44,22 @@ def device_to_host(ptr, nbytes):
     rc = hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), nbytes, 2)   # hipMemcpyDeviceToHost
     assert rc == 0, f"hipMemcpy failed: {rc}"
     return out
+
+
+def seam_scene(scenes):
+    """one quad whose uv run from -1.25 to 2.25 (and -0.75 to 1.75) under a 4 x 5 texture of unrelated texels: nearly every pixel's bilinear footprint sits on a texel boundary,
+    a fifth of them on the REPEAT wrap (tests/test_oracle.py: against numpy in fp64; tests/test_gpu_parity.py: the GPU against the oracle)"""
+    import math
+    rng = np.random.default_rng(7)
+    tw, th = 4, 5
+    tex = np.zeros((3, th, tw, 4), np.uint8)
+    tex[0] = rng.integers(20, 256, (th, tw, 4))                                     # albedo: unrelated texels
+    tex[1, ..., 0] = 255; tex[1, ..., 1] = rng.integers(80, 230, (th, tw)); tex[1, ..., 2] = rng.integers(0, 2, (th, tw)) * 255   # occlusion, roughness, metallic
+    nm = rng.normal(0, 0.35, (th, tw, 3)); nm[..., 2] = 1.0; nm /= np.linalg.norm(nm, axis=-1, keepdims=True)
+    tex[2, ..., :3] = np.round((nm * 0.5 + 0.5) * 255); tex[2, ..., 3] = 255
+    mb = scenes.MeshBuilder()
+    mb.add([(-0.8, -0.6, 0.5), (0.8, -0.6, 0.5), (0.8, 0.6, 0.7), (-0.8, 0.6, 0.7)], [(-1.25, -0.75), (2.25, -0.75), (2.25, 1.75), (-1.25, 1.75)],
+           [(0, 0, -1)] * 4, [(1, 0, 0, 1)] * 4, [0, 1, 2, 0, 2, 3])
+    prim = mb.finish(tex)
+    return scenes.Scene("seams", [prim], dict(pos=(0.0, 0.0, -0.6), dir=(0.0, 0.0, 1.0), fovy=math.pi / 2, znear=0.1, zfar=1000.0),
+                        [dict(kind="point", pos=(0.3, -0.2, -0.3), color=(6.0, 5.0, 4.0), falloff=4.0, casts_shadows=False)])

@@ -866,6 +866,21 @@ def test_non_finite_cameras_are_errors_and_non_finite_rays_are_misses(R, orc, ge
     r.close()
 
 
+@pytest.mark.parametrize("form", ["fused", "per-ray"])
+def test_texture_seams_match_the_oracle(R, orc, scenes, form):
+    """bilinear REPEAT where the 2x2 footprint wraps (uv below 0, at 1, past 1) on a 4 x 5 texture of unrelated texels -- the scene tests/test_oracle.py holds against numpy in
+    fp64: depth and normal bit for bit (the normal map goes through the sampler), radiance 1e-4"""
+    from helpers import seam_scene
+    sc = seam_scene(scenes)
+    ref = _frame_parity(R, orc, sc, 96, 96, None, form=form)
+    fif, tuning = FORMS[form]
+    r = R.renderer_for_scene(sc, (96, 96), frames_in_flight=fif, tuning=tuning)
+    r.render_frame()
+    assert np.array_equal(r.read_depth().view(np.uint32), ref["depth"].view(np.uint32)) and np.array_equal(r.read_normal().view(np.uint32), ref["normal"].view(np.uint32))
+    assert ref["stats"]["hit_pixels"] > 3000
+    r.close()
+
+
 def test_sixteen_lights_and_light_updates(R, orc, get_scene, scenes):
     """sixteen lights -- what the kernel arguments carry -- a light change between frames (VkLights dirty flag, vk_lights.rs:81-139), and the list's upper bound (1024)"""
     import math

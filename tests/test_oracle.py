@@ -316,6 +316,40 @@ def test_all_light_types_against_numpy_in_fp64(orc64, scenes):
     assert checked > 1000 and (lit > 20).all(), (checked, lit)
 
 
+def test_repeat_sampler_at_the_texture_seams_against_numpy_in_fp64(orc64, scenes):
+    """the last piece of the shading both hands wrote alike: bilinear filtering with REPEAT where the 2x2 footprint wraps -- uv below 0, at 1, past 1; the
+    texel before column 0 is the last column.  One quad whose uv run from -1.25 to 2.25 (and -0.75 to 1.75) under a 4 x 5 texture of unrelated texels, so nearly every pixel's
+    footprint sits on a texel boundary and a fifth of them on the wrap: the fp64 oracle against the numpy sampler (Python's floor-mod, no shared helper) through the whole shading
+    of every pixel -- albedo, roughness / metallic and the normal map all go through it -- at 5e-6 (normal: 1e-6)"""
+    from helpers import seam_scene
+    sc = seam_scene(scenes)
+    prim = sc.primitives[0]
+    th, tw = prim.tex.shape[1:3]
+    w = h = 96
+    S, cam, recs, out = _f64_frame(orc64, sc, sc.lights, w, h)
+    view = np.array(cam.view, np.float64).reshape(4, 4).T
+    view_inv = np.array(cam.view_inv, np.float64).reshape(4, 4).T
+    nl = [NP.light_from_record(recs[0])]
+    V = prim.verts.astype(np.float64)
+    checked = wrapped = negative = 0
+    for y in range(h):
+        for x in range(w):
+            pi, ti = out["hit_id"][y, x]
+            if pi < 0:
+                continue
+            _, u, v, _ = out["hit_tuv"][y, x]
+            i0, i1, i2 = [int(k) for k in prim.indices[3 * ti:3 * ti + 3]]
+            uv = V[i0, 3:5] * (1 - u - v) + V[i1, 3:5] * u + V[i2, 3:5] * v
+            x0, y0 = math.floor(uv[0] * tw - 0.5), math.floor(uv[1] * th - 0.5)
+            wrapped += (x0 % tw == tw - 1) or (y0 % th == th - 1)                     # the footprint's second column / row is the first one again
+            negative += x0 < 0 or y0 < 0
+            rho, depth, on, mask = NP.shade_pixel(prim, int(ti), float(u), float(v), view, view_inv, np.array(cam.camera_pos, np.float64), nl, 0)
+            assert np.allclose(out["color"][y, x, :3], rho, rtol=5e-6, atol=2e-7), (x, y, uv, out["color"][y, x], rho)   # (a wrong texel shows at 1e-2; the C source's float-rounded constants at 1e-6 under this bright a light)
+            assert np.allclose(out["normal"][y, x, :3], on, rtol=1e-6, atol=2e-7), (x, y, uv)
+            checked += 1
+    assert checked > 3000 and wrapped > checked // 6 and negative > checked // 8, (checked, wrapped, negative)
+
+
 @pytest.mark.parametrize("config,n_pixels", [("c2", 2000), ("c4", 200)])
 def test_bench_scenes_against_a_brute_force_witness_in_fp64(orc, orc64, scenes, config, n_pixels):
     """The scenes the bench runs, at FULL detail -- config 2 (262 816 triangles, a primitive with u32 indices) and config 4 (2.8 M triangles, 63-bit Morton keys on
