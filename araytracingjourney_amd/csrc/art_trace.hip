@@ -361,6 +361,10 @@ __device__ __forceinline__ void packet_walk(const FrameArgs &a, const Ray &r, bo
             float te;
             const uint64_t m0 = ballot64(slab_oct<OCT>(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, tbest, te));
             const uint64_t m1 = ballot64(slab_oct<OCT>(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, tbest, te));
+            // (Round 4 also skipped the third and fourth box where a node has no such child -- its valid mask is a scalar, and a node of the collapse has three children on
+            // average, so a quarter of the 52 box-test instructions of a step test a point box at 3e38: configs 2 / 3 / 4 19 450 / 30 990 / 17 080 Mray/s against 19 270-19 530 /
+            // 31 450 / 17 170 -- nothing: the launch is not short of vector issue slots the way its 0.68 suggests; a step's chain of dependent scalar loads, ballots and the LDS
+            // pop is what the waves take turns waiting for.  profiles/README.md round 4.)
             const uint64_t m2 = ballot64(slab_oct<OCT>(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, tbest, te));
             const uint64_t m3 = ballot64(slab_oct<OCT>(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, tbest, te));
 #ifdef ART_PACKET_PROF
