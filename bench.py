@@ -386,18 +386,28 @@ def main():
             known = [x for x in rays_pose if x is not None]
             rays_pose = [x if x is not None else sum(known) / len(known) for x in rays_pose]   # (poses in between: the mean of the counted ones -- they differ by a thousandth)
 
+            at = [0]                            # the motion goes on across the settle, warm-up and timed parts (no jump back to pose 0 in between)
+
             def moving(n):
-                for i in range(n):
-                    r._camera = cams[i % len(cams)]
+                for _ in range(n):
+                    r._camera = cams[at[0] % len(cams)]
+                    at[0] += 1
                     r.upload_state()
                     r.trace()
-            moving(2 * F)
+            t_settle = time.perf_counter()      # the leg settles like the timed region itself: its own frames for --settle-seconds (the legs in front of it left the GPU idling between
+            while True:                         # single fenced frames: twenty frames on idle clocks measure the clocks), then W warm-up frames and a fence
+                moving(3 * F)
+                if time.perf_counter() - t_settle >= args.settle_seconds:
+                    break
             fence()
+            moving(args.warmup)
+            fence()
+            first = at[0]
             c0 = time.perf_counter()
             moving(args.steps)
             fence()
             cwall = time.perf_counter() - c0
-            rays_moved = sum(rays_pose[i % len(cams)] for i in range(args.steps))
+            rays_moved = sum(rays_pose[(first + i) % len(cams)] for i in range(args.steps))
             return dict(poses=len(cams), value=rays_moved / cwall / 1e6, unit="Mray/s", ms_per_step=cwall * 1e3 / args.steps, rays_per_frame_min=min(rays_pose), rays_per_frame_max=max(rays_pose),
                         ray_counts_checked_against_oracle=checked, protocol=protocol)
 
@@ -408,13 +418,13 @@ def main():
         if extras and not args.ao and args.camera_walk > 0:
             # camera_path: the reference's own camera motion (main.rs:69-131) -- a key held down and a hand on the mouse, at the frame rate this library renders at
             campath = camera_leg(scenes.camera_walk(sc, args.camera_walk), gold_of(f"camera_walk_{args.camera_walk}"), 8,
-                                 "art_set_camera before every frame, fenced on both sides like `value`; the camera moves as the reference's does (main.rs:80-124: 0.002 units per ms of frame time along the view "
+                                 "art_set_camera before every frame; settled, warmed up and fenced on both sides like `value`; the camera moves as the reference's does (main.rs:80-124: 0.002 units per ms of frame time along the view "
                                  "direction, 0.002 rad per mouse count at 1 000 counts / s) at 6 000 frames / s -- 0.00033 units and 0.00033 rad a frame, a closed loop out and back")
         if extras and not args.ao and args.camera_path > 0:
             # camera_jumps: a pose 0.2 units and 15 degrees from the last one EVERY frame (round 1-3's camera_path): no frame in flight shares its heavy blocks with its neighbours -- a stress
             # test of what depends on frame-to-frame coherence (the wave plan), not something a render loop does
             camjumps = camera_leg(scenes.camera_path(sc, args.camera_path), gold_of(f"camera_path_{args.camera_path}"), 1,
-                                  "art_set_camera before every frame with a pose 0.2 units / 15 degrees away from the last (a closed path of 8 poses), fenced on both sides like `value`: a stress leg -- "
+                                  "art_set_camera before every frame with a pose 0.2 units / 15 degrees away from the last (a closed path of 8 poses); settled, warmed up and fenced on both sides like `value`: a stress leg -- "
                                   "nothing a frame learns about its heavy blocks holds for the next")
         if campath or camjumps:
             r._camera = renderer.Camera(sc.camera["pos"], sc.camera["dir"], W / H, sc.camera["fovy"], sc.camera["znear"], sc.camera["zfar"])
@@ -450,11 +460,21 @@ def main():
                 ps = mv.stats()
                 rays_pose.append(ps["primary_rays"] + ps["shadow_rays"]); refit_alone.append(ps["refit_ms"])
 
+            mat = [0]
+
             def moved(n):
-                for i in range(n):
-                    model.set_model_matrix(poses[i % len(poses)])
+                for _ in range(n):
+                    model.set_model_matrix(poses[mat[0] % len(poses)])
+                    mat[0] += 1
                     mv.trace()
-            moved(2 * F); mv.sync()
+            t_settle = time.perf_counter()      # (settled like the timed region: see the camera legs)
+            while True:
+                moved(3 * F)
+                if time.perf_counter() - t_settle >= args.settle_seconds:
+                    break
+            mv.sync()
+            moved(args.warmup); mv.sync()
+            mfirst = mat[0]
             m0 = time.perf_counter()
             moved(args.steps); mv.sync()
             mwall = time.perf_counter() - m0
@@ -469,11 +489,11 @@ def main():
                 mv.trace(); mv.sync()
                 residency.append(mv.stats()["refit_ms"])
             assert not mv.needs_build() and mv.stats()["rebuilds"] == ms_["rebuilds"]
-            moving_model = dict(poses=len(poses), value=sum(rays_pose[i % len(poses)] for i in range(args.steps)) / mwall / 1e6, unit="Mray/s", ms_per_step=mwall * 1e3 / args.steps,
+            moving_model = dict(poses=len(poses), value=sum(rays_pose[(mfirst + i) % len(poses)] for i in range(args.steps)) / mwall / 1e6, unit="Mray/s", ms_per_step=mwall * 1e3 / args.steps,
                                 refit_ms=refit_alone[len(refit_alone) // 2], refit_ms_max=refit_alone[-1], refits=ms_["refits"], rebuilds=ms_["rebuilds"], refit_cost_ratio=ms_["refit_cost_ratio"],
                                 moving_triangles=sc.primitives[-1].n_tris, build_ms=ms_["build_ms"], residency_change_ms=sorted(residency)[len(residency) // 2],
                                 first_move_ms=ms_["first_move_ms"], versions_ms=ms_["versions_ms"],
-                                protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, 62 % of its triangles, carried and turned at 2 units / s and 2 rad / s -- 0.00033 a frame -- out and back), fenced on both sides like `value`; "
+                                protocol="art_scene_set_model_matrix before every frame (one model = the scene's last primitive, 62 % of its triangles, carried and turned at 2 units / s and 2 rad / s -- 0.00033 a frame -- out and back); settled, warmed up and fenced on both sides like `value`; "
                                          "versions_ms = host time of making the ring of structure versions (inside art_scene_build: ART_FLAG_DYNAMIC_SCENE; first_move_ms = what the first moved frame paid, 0 then); "
                                          "refit_ms = device time of one refit (all triangle records + every 4-wide node) with nothing else on the GPU, median over the poses; "
                                          "residency_change_ms = the same for the model leaving / re-entering the structure (art_scene_set_primitive_enabled: no build)")
