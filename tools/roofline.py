@@ -147,7 +147,20 @@ def main():
             us = line["ms_per_step"] * 1e3
             ab = algorithmic_bytes(gold, c["lights"])
         fr = fractions(pmc, us, ab)
-        cands = [k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac") if k in fr]
+        fta = os.path.join(P, f"{a.tag}_pmc_ta_{name}.txt")   # tools/pmc_ta.sh: the vector-memory path's own counters
+        if os.path.exists(fta):
+            ta, n_ta = parse_pmc_txt(fta, kname)
+            if n_ta and ta.get("GRBM_GUI_ACTIVE"):
+                # TA_TA_BUSY_sum: over the 256 addressers (one a CU); GRBM_GUI_ACTIVE: over the 8 XCDs -- both of the kernel's own launches under the profiler
+                fr["ta_busy_frac"] = (ta["TA_TA_BUSY_sum"] / CUS) / (ta["GRBM_GUI_ACTIVE"] / 8)
+                if ta.get("TA_FLAT_READ_WAVEFRONTS_sum"):
+                    fr["ta_cycles_per_load_instruction"] = ta["TA_TA_BUSY_sum"] / ta["TA_FLAT_READ_WAVEFRONTS_sum"]
+                    if "TCP_TOTAL_CACHE_ACCESSES_sum" in ta:
+                        fr["l1_accesses_per_load_instruction"] = ta["TCP_TOTAL_CACHE_ACCESSES_sum"] / ta["TA_FLAT_READ_WAVEFRONTS_sum"]
+                if "TA_ADDR_STALLED_BY_TC_CYCLES_sum" in ta:
+                    fr["ta_stalled_by_l1_frac"] = (ta["TA_ADDR_STALLED_BY_TC_CYCLES_sum"] / CUS) / (ta["GRBM_GUI_ACTIVE"] / 8)
+                pmc = dict(pmc, **ta)
+        cands = [k for k in ("valu_issue_frac", "salu_issue_frac", "hbm_frac", "ta_busy_frac") if k in fr]
         bound = max(cands, key=lambda k: fr[k]).replace("_frac", "") if cands else None
         out = dict(tag=a.tag, config=name, workload=line["config"]["workload"], kernel=c["kernel"], us_per_launch_machine=us, ms_per_step=line["ms_per_step"], mray_per_s=line["value"],
                    pmc_launches_averaged=launches, pmc=pmc, algorithmic_bytes_per_frame=ab, binding_roof=bound, **fr)
