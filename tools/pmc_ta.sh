@@ -11,6 +11,8 @@ SETS=("GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"
       "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
       "TCP_TCP_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"
       "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum")
+# PMC_SETS="A B;C D": other counter sets, one pass each (e.g. the scalar / instruction caches: "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES;SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES")
+if [ -n "$PMC_SETS" ]; then IFS=";" read -ra SETS <<< "$PMC_SETS"; fi
 i=0
 for C in "${SETS[@]}"; do
   i=$((i+1))
