@@ -121,7 +121,7 @@ struct WavePlan {
 // One version of what a frame reads of the acceleration structure.  A static scene has none (the build's arrays are read directly); the first
 // art_scene_set_model_matrix makes a small ring of them: a refit writes the NEXT version while frames in flight still read the older ones, like the
 // reference's per-frame TLAS (one VkTlasBuilder per FrameData, renderer.rs:300-318, :637-651).  Version 0 is the build's own arrays.
-constexpr uint32_t kMaxAsVersions = 8;
+constexpr uint32_t kMaxAsVersions = 24;
 struct AsVersion {
     DevTri *tris = nullptr; DevNodeW *widef = nullptr; DevNode4 *wide = nullptr; DevPrim *prims = nullptr;
     bool owned = false;                  // version 0 aliases c->bvh.* and c->d_prims
@@ -300,8 +300,12 @@ int32_t as_create(ArtContext *c) {
     int32_t r = ensure_wide(c, true); if (r) return r;
     r = sync_all(c); if (r) return r;
     const auto t_begin = std::chrono::steady_clock::now();
-    // (default: one more than the frames in flight, 4 at least and 8 at most -- with fewer versions than ring slots the host stands waiting for frame n - K in front of every refit)
-    const uint32_t K = c->tuning.as_versions ? std::min(c->tuning.as_versions, kMaxAsVersions) : std::min(std::max(c->F + 1u, 4u), kMaxAsVersions);
+    // (default: twice the frames in flight, 4 at least and 24 at most.  The host may issue the refit of frame n once the frames that read that version -- frame n - K -- are
+    //  over, so K sets how far it runs ahead of the GPU: with K = F + 1 a refit is issued when its ring slot's previous frame has all but finished and its latency -- 0.5 ms
+    //  among eight frames in flight -- stands in front of the slot's next frame; with K = 2 F it is a ring trip ahead.  Config 2, F = 8, a model of 164 k triangles moving
+    //  every frame: 0.252 / 0.229 / 0.213 / 0.210 / 0.205 / 0.205 ms a frame with 4 / 8 / 10 / 12 / 16 / 24 versions (profiles/README.md round 4d); a version is the tree's
+    //  arrays once more: 42 MB for config 2, 450 MB for config 4.)
+    const uint32_t K = c->tuning.as_versions ? std::min(c->tuning.as_versions, kMaxAsVersions) : std::min(std::max(2u * c->F, 4u), kMaxAsVersions);
     const size_t np = c->h_dev_prims.size(), T = c->T, NW = c->bvh.n_wide;
     c->as.assign(K, AsVersion{});
     hipStream_t s = c->main_stream();
@@ -783,7 +787,7 @@ int32_t art_set_tuning(ArtContext *c, const ArtTuning *t) {
     if ((t->frame_form != 0 && t->frame_form != 2) || t->tree_builder > 1 || t->packet_wide > 2 || !walk_ok(t->primary_walk) || !walk_ok(t->shadow_walk) || !(walk_ok(t->ao_walk) || t->ao_walk == 6))
         return fail(ART_E_INVALID, "art_set_tuning: frame_form 0|2, tree_builder 0..1, packet_wide 0..2, walks 0|2|4");
     if (t->frame_form == 0 && (t->primary_walk || t->shadow_walk)) return fail(ART_E_INVALID, "art_set_tuning: the fused frame's rays are packets (primary_walk / shadow_walk choose the per-ray walks of frame_form 2)");
-    if (t->as_versions > kMaxAsVersions || !(t->refit_rebuild_ratio == t->refit_rebuild_ratio)) return fail(ART_E_INVALID, "art_set_tuning: as_versions 0..8, refit_rebuild_ratio a number");
+    if (t->as_versions > kMaxAsVersions || !(t->refit_rebuild_ratio == t->refit_rebuild_ratio)) return fail(ART_E_INVALID, "art_set_tuning: as_versions 0..24, refit_rebuild_ratio a number");
     int32_t r = use_device(c); if (r) return r;
     r = sync_all(c); if (r) return r;
     drop_graphs(c);

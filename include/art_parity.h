@@ -39,7 +39,7 @@ typedef struct ArtTuning {
     uint32_t hw_queues;         /* hardware queues the HOST gave the process (GPU_MAX_HW_QUEUES; 0 = HIP's default of 4): the wave plan counts min(frames in flight, this) launches in flight */
     uint32_t log;               /* to stderr: 1 build phase times, 2 wave-plan decisions, 4 every wave-plan poll */
     uint32_t wide_builder;      /* the 4-wide collapse of the binary tree: 0 level by level on the device | 1 one host thread (the form the device one is tested against) */
-    uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..8 (0 = 4): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
+    uint32_t as_versions;       /* moving models: versions of the acceleration structure a context cycles through, 1..24 (0 = twice the frames in flight, 4 at least): a refit may run while as_versions - 1 older frames are in flight; 1 = refit in place, nothing in flight */
     float refit_rebuild_ratio;  /* art_trace rebuilds instead of refitting once ArtStats.refit_cost_ratio exceeds this (0 = 2.0; negative: never) */
     uint32_t trace_leaf_batch;  /* persistent per-ray tracer: lanes that must be waiting for a triangle test before the wave runs one, 1..64 (0 = presets: 1, AO rays 8) */
     uint32_t plan_moving_interval; /* wave plan: frames between two looks at the waves while the camera / the lights change every frame (0 = 32) */
