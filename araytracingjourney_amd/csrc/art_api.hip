@@ -167,6 +167,8 @@ struct ArtContext {
     uint32_t T = 0;
     // moving models (art_scene_set_model_matrix): versions of the structure, the primitive table as the next refit will upload it
     std::vector<AsVersion> as; uint32_t as_cur = 0; bool xform_dirty = false;
+    void *as_block = nullptr, *as_pinned = nullptr;   // ONE device allocation and ONE pinned one behind all the versions (six + three per version before).  versions_ms is something else: the refit streams' creation (a
+                                                      // high-priority hardware queue each: 4-10 ms apiece) and the refit's work lists (host, 9 ms for config 2) -- ArtTuning.log bit 0 prints the parts
     // Refits run on streams of their own, one per ring slot (up to four): the refit in front of frame n of slot k then overlaps frame n - F, which still runs on that slot's
     // stream, instead of queueing behind it -- the slot's chain is frame, frame, frame with the refits beside it, and the frame waits for its refit's event.  (On the frame's
     // own stream a slot's cycle was refit + frame: a model moving every frame cost the ring a third of its depth, profiles/README.md round 4.)
@@ -284,13 +286,10 @@ uint64_t as_epoch_of(const ArtContext *c, uint32_t v) { return c->as.empty() ? 0
 // everything that reads them has finished (the caller synchronised)
 void as_release(ArtContext *c) {
     for (AsVersion &V : c->as) {
-        if (V.owned) { (void)hipFree(V.tris); (void)hipFree(V.widef); (void)hipFree(V.wide); (void)hipFree(V.prims); }
-        if (V.h_prims) (void)hipHostFree(V.h_prims);
-        if (V.h_touched) (void)hipHostFree(V.h_touched);
-        if (V.h_result) (void)hipHostFree(V.h_result);
-        (void)hipFree(V.mark); (void)hipFree(V.acc);
         if (V.ready) (void)hipEventDestroy(V.ready);
     }
+    (void)hipFree(c->as_block); c->as_block = nullptr;                         // every version's device arrays
+    if (c->as_pinned) (void)hipHostFree(c->as_pinned); c->as_pinned = nullptr; // every version's staging memory
     c->as.clear(); c->as_cur = 0;
 }
 // the first move of a built scene: the ring of versions (ArtTuning.as_versions; default 4: one more than the reference's frames in flight, renderer.rs:135 -- measured on
@@ -309,6 +308,8 @@ int32_t as_create(ArtContext *c) {
     const size_t np = c->h_dev_prims.size(), T = c->T, NW = c->bvh.n_wide;
     c->as.assign(K, AsVersion{});
     hipStream_t s = c->main_stream();
+    double t_sec[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&, last = std::chrono::steady_clock::now()](int i) mutable { const auto n = std::chrono::steady_clock::now(); t_sec[i] += std::chrono::duration<double, std::milli>(n - last).count(); last = n; };
     auto body = [&]() -> int32_t {
         const uint32_t want = c->tuning.refit_streams == 0xFFFFFFFFu ? 0u : (c->tuning.refit_streams ? std::min(c->tuning.refit_streams, 4u) : std::min(c->F, 4u));
         while (c->n_refit_streams < want) {   // (kept for the life of the context)
@@ -316,6 +317,7 @@ int32_t as_create(ArtContext *c) {
             HIPC(hipStreamCreateWithPriority(&c->refit_stream[c->n_refit_streams], hipStreamNonBlocking, hi)); c->n_refit_streams++;
         }
         while (c->n_refit_streams > want) { c->n_refit_streams--; (void)hipStreamSynchronize(c->refit_stream[c->n_refit_streams]); (void)hipStreamDestroy(c->refit_stream[c->n_refit_streams]); c->refit_stream[c->n_refit_streams] = nullptr; }
+        lap(0);
         if (!c->bvh.leaf_parent) { // who holds whom in the 4-wide tree: the marks of a refit go up along it
             HIPC(hipMalloc(&c->bvh.leaf_parent, T * 4)); HIPC(hipMalloc(&c->bvh.node_parent, NW * 4));
             launch_wide_parents(c->bvh.n_wide, c->bvh.widef, c->bvh.leaf_parent, c->bvh.node_parent, s);
@@ -323,24 +325,40 @@ int32_t as_create(ArtContext *c) {
             hipError_t e = refit_lists_build(c->bvh, c->T, s);   // the refit's work lists (a workgroup per batch of subtrees)
             if (e != hipSuccess) return hipfail(e, "refit_lists_build");
         }
+        lap(1);
+        // one device block and one pinned block, carved per version (256-byte steps)
+        auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
+        const size_t dev_owned = pad(T * sizeof(DevTri)) + pad(NW * sizeof(DevNodeW)) + pad(NW * sizeof(DevNode4)) + pad(np * sizeof(DevPrim)), dev_every = pad(NW * 4) + pad(32);
+        const size_t pin_every = pad(np * sizeof(DevPrim)) + pad(np) + pad(32);
+        HIPC(hipMalloc(&c->as_block, (K - 1) * dev_owned + K * dev_every));
+        HIPC(hipHostMalloc(&c->as_pinned, K * pin_every, hipHostMallocDefault));
+        lap(2);
+        char *dp = (char *)c->as_block, *hp = (char *)c->as_pinned, *dhp = nullptr;
+        HIPC(hipHostGetDevicePointer((void **)&dhp, c->as_pinned, 0));
+        auto carve = [&](char *&p, size_t n) { char *q = p; p += pad(n); return q; };
         for (uint32_t v = 0; v < K; v++) { // (everything on the context's first stream, asynchronously: one wait at the end)
             AsVersion &V = c->as[v];
             if (v == 0) { V.tris = c->bvh.tris; V.widef = c->bvh.widef; V.wide = c->bvh.wide; V.prims = c->d_prims.p; }
             else {
                 V.owned = true;
-                HIPC(hipMalloc(&V.tris, T * sizeof(DevTri))); HIPC(hipMalloc(&V.widef, NW * sizeof(DevNodeW))); HIPC(hipMalloc(&V.wide, NW * sizeof(DevNode4))); HIPC(hipMalloc(&V.prims, np * sizeof(DevPrim)));
+                V.tris = (DevTri *)carve(dp, T * sizeof(DevTri)); V.widef = (DevNodeW *)carve(dp, NW * sizeof(DevNodeW)); V.wide = (DevNode4 *)carve(dp, NW * sizeof(DevNode4)); V.prims = (DevPrim *)carve(dp, np * sizeof(DevPrim));
                 HIPC(hipMemcpyAsync(V.tris, c->bvh.tris, T * sizeof(DevTri), hipMemcpyDeviceToDevice, s)); HIPC(hipMemcpyAsync(V.widef, c->bvh.widef, NW * sizeof(DevNodeW), hipMemcpyDeviceToDevice, s));
                 HIPC(hipMemcpyAsync(V.wide, c->bvh.wide, NW * sizeof(DevNode4), hipMemcpyDeviceToDevice, s)); HIPC(hipMemcpyAsync(V.prims, c->d_prims.p, np * sizeof(DevPrim), hipMemcpyDeviceToDevice, s));
             }
-            HIPC(hipHostMalloc((void **)&V.h_prims, np * sizeof(DevPrim), hipHostMallocDefault)); HIPC(hipHostMalloc((void **)&V.h_touched, np, hipHostMallocDefault)); HIPC(hipHostMalloc((void **)&V.h_result, 32, hipHostMallocDefault));
-            HIPC(hipHostGetDevicePointer((void **)&V.dh_prims, V.h_prims, 0)); HIPC(hipHostGetDevicePointer((void **)&V.dh_touched, V.h_touched, 0)); HIPC(hipHostGetDevicePointer((void **)&V.dh_result, V.h_result, 0));
-            HIPC(hipMalloc(&V.mark, NW * 4)); HIPC(hipMemsetAsync(V.mark, 0, NW * 4, s)); HIPC(hipMalloc(&V.acc, 32)); HIPC(hipMemsetAsync(V.acc, 0, 32, s));
+            V.mark = (uint32_t *)carve(dp, NW * 4); V.acc = (double *)carve(dp, 32);
+            HIPC(hipMemsetAsync(V.mark, 0, NW * 4, s)); HIPC(hipMemsetAsync(V.acc, 0, 32, s));
+            const size_t off = (size_t)(hp - (char *)c->as_pinned);
+            V.h_prims = (DevPrim *)carve(hp, np * sizeof(DevPrim)); V.h_touched = (uint8_t *)carve(hp, np); V.h_result = (double *)carve(hp, 32);
+            V.dh_prims = (DevPrim *)(dhp + off); V.dh_touched = (uint8_t *)(dhp + off + pad(np * sizeof(DevPrim))); V.dh_result = (double *)(dhp + off + pad(np * sizeof(DevPrim)) + pad(np));
             HIPC(hipEventCreateWithFlags(&V.ready, hipEventDisableTiming));
         }
+        lap(3);
         AsVersion &V0 = c->as[0];
         launch_wide_cost(c->bvh.n_wide, V0.widef, nullptr, V0.acc, V0.dh_result, s);   // the cost of the tree as built
         HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(s));
         c->as_cost0 = V0.h_result[0]; c->refit_cost_ratio = 1.0f;
+        lap(4);
+        if (c->tuning.log & 1u) std::fprintf(stderr, "[art] versions: %u of them; refit streams %.2f ms, parents + work lists %.2f, the two allocations %.2f, copies issued + events %.2f, the wait for them + the cost of the tree as built %.2f\n", K, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4]);
         return ART_OK;
     };
     r = body();
