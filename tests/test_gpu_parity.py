@@ -1157,17 +1157,19 @@ def test_a_small_tree_is_all_crown_and_moves_all_the_same(R, orc, get_scene, sce
     r.close()
 
 
-@pytest.mark.parametrize("F", [1, 2, 4])
-def test_moving_frames_lap_the_ring_of_versions_without_a_sync(R, orc, get_scene, scenes, F):
+@pytest.mark.parametrize("F,K", [(1, 4), (2, 4), (4, 4), (8, 0), (3, 24)], ids=["1-slot-4-versions", "2-slots-4-versions", "4-slots-4-versions", "8-slots-default-16-versions", "3-slots-24-versions"])
+def test_moving_frames_lap_the_ring_of_versions_without_a_sync(R, orc, get_scene, scenes, F, K):
     """advisor, round 3: no test reused a ring slot or a version without a host sync in between.  F x 4 + 3 moving frames launched back to back through F ring slots and a
-    ring of 4 versions (every version is rewritten four times, its staging memory with it; the refits run on streams of their own beside the frames): the LAST F frames --
-    the ones whose outputs still exist -- are the oracle's frames of scenes built from scratch, depth and normal bit for bit"""
+    ring of K versions (every version is rewritten F times or more, its staging memory with it; the refits run on streams of their own beside the frames): the LAST F frames
+    -- the ones whose outputs still exist -- are the oracle's frames of scenes built from scratch, depth and normal bit for bit.  K = 0: the default, twice the ring of
+    frames (round 4d); 24: the most art_set_tuning takes"""
     from helpers import device_to_host
     sc = get_scene("sponza_like", 0.12)
-    w, h, K = 320, 180, 4
+    w, h = 320, 180
     lights = scenes.sponza_lights(1)
     movers = [len(sc.primitives) - 1, len(sc.primitives) - 2]
     r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, frames_in_flight=F, tuning={"as_versions": K, "refit_rebuild_ratio": -1.0})
+    K = K or max(2 * F, 4)
     model = r.models_mut()[1]
     base = moving[0].model
     r.render_frame()
