@@ -264,3 +264,25 @@ def test_bench_started_plainly_spawns_its_ranks():
     assert out.returncode != 0 and "starting the ranks as a child process" in out.stderr
     assert out.stderr.count("bench.py needs an MI355X") >= 2, out.stderr[-3000:]
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_roofline_is_rederived_from_the_committed_counter_files(tmp_path):
+    """tools/roofline.py --tag round4 on the files under profiles/ (rocprofv3 counter passes of configs 2-5, the bench lines they belong to): every fraction the docs quote
+    comes out of it again -- the frame kernel bound by vector-instruction issue, the AO launch by the texture addresser (tools/pmc_ta.sh's counters, round 4b)"""
+    import json
+    import shutil
+    work = tmp_path / "repo"
+    for d in ("profiles", "tools", os.path.join("tests", "golden")):
+        shutil.copytree(os.path.join(ROOT, d), work / d, ignore=shutil.ignore_patterns("__pycache__", "*.glb", "*.npz", "*.npy"))
+    shutil.copytree(os.path.join(ROOT, "araytracingjourney_amd", "csrc"), work / "araytracingjourney_amd" / "csrc", ignore=shutil.ignore_patterns("*.o", "*.so"))
+    out = subprocess.run([sys.executable, str(work / "tools" / "roofline.py"), "--tag", "round4"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout)
+    assert set(r) == {"c2", "c3", "c4", "c5"}
+    for k in ("c2", "c3", "c4"):
+        assert r[k]["binding_roof"] == "valu_issue" and 0.6 < r[k]["valu_issue_frac"] < 0.8 and r[k]["hbm_frac"] < 0.25
+    assert 0.05 < r["c2"]["ta_busy_frac"] < 0.12                      # the packets' nodes come through the scalar cache
+    assert r["c5"]["binding_roof"] == "ta_busy" and 0.8 < r["c5"]["ta_busy_frac"] < 0.92 and 20 < r["c5"]["ta_cycles_per_load_instruction"] < 30
+    committed = json.load(open(os.path.join(ROOT, "profiles", "round4_roofline.json")))
+    for k in r:
+        assert abs(committed[k]["valu_issue_frac"] - r[k]["valu_issue_frac"]) < 1e-9, k      # the committed summary is this output
