@@ -856,12 +856,15 @@ static void render_pixel(Job *J, OrcStats *st, uint32_t x, uint32_t y) {
 static void *worker(void *arg) {
     Job *J = (Job *)arg;
     OrcStats st; memset(&st, 0, sizeof(st));
+    /* work items: 32 x 32-pixel tiles of the rows [y0, y1), dealt by an atomic cursor ("all host cores over 32x32-pixel tiles") */
+    const uint32_t tiles_x = (J->w + 31u) / 32u, tiles_y = (J->y1 > J->y0 ? J->y1 - J->y0 + 31u : 0u) / 32u;
     for (;;) {
-        uint32_t y = __sync_fetch_and_add(J->next_row, 1u);
-        if (y >= J->y1) break;
-        uint32_t ye = y + 1;
-        for (uint32_t yy = y; yy < ye; yy++)
-            for (uint32_t x = 0; x < J->w; x++) render_pixel(J, &st, x, yy);
+        uint32_t t = __sync_fetch_and_add(J->next_row, 1u);
+        if (t >= tiles_x * tiles_y) break;
+        const uint32_t xa = (t % tiles_x) * 32u, ya = J->y0 + (t / tiles_x) * 32u;
+        const uint32_t xe = xa + 32u < J->w ? xa + 32u : J->w, ye = ya + 32u < J->y1 ? ya + 32u : J->y1;
+        for (uint32_t yy = ya; yy < ye; yy++)
+            for (uint32_t x = xa; x < xe; x++) render_pixel(J, &st, x, yy);
     }
     pthread_mutex_lock(J->mu);
     uint64_t *a = (uint64_t *)&J->stats, *b = (uint64_t *)&st;
@@ -875,7 +878,7 @@ void orc_render(const OrcScene *s, const OrcCamera *cam, const OrcLight *lights,
                 uint32_t *shadow_bits, OrcStats *stats, int n_threads) {
     Job J; memset(&J, 0, sizeof(J));
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-    volatile uint32_t next = y0;
+    volatile uint32_t next = 0;   /* the tile cursor (next_row of the packet statistics: a row of blocks) */
     J.s = s; J.cam = cam; J.lights = lights; J.nl = n_lights; J.w = w; J.h = h; J.y0 = y0; J.y1 = y1 < h ? y1 : h;
     J.color = color; J.depth = depth; J.normal = normal; J.hit_tuv = hit_tuv; J.hit_id = hit_id; J.shadow_bits = shadow_bits;
     J.mu = &mu; J.next_row = &next;
