@@ -289,3 +289,55 @@ class BruteForce:
             return False, 1.0
         i, t, u, v, m = closest_hit(o, d, self.tris[cand], tmin, tmax, eps)
         return i >= 0, m
+
+
+# ---- ray-traced ambient occlusion (libart's own definition behind XeGTAO's I/O contract: DESIGN.md 6 f2), restated in float64 ----------------------------
+def hilbert_index_64(x, y):
+    """XeGTAO.h:120-142 at XE_HILBERT_LEVEL 6: position of (x, y) on the Hilbert curve over a 64 x 64 tile"""
+    index, lvl = 0, 32
+    while lvl > 0:
+        rx, ry = int((x & lvl) > 0), int((y & lvl) > 0)
+        index += lvl * lvl * ((3 * rx) ^ ry)
+        if ry == 0:
+            if rx == 1:
+                x, y = 63 - x, 63 - y
+            x, y = y, x
+        lvl //= 2
+    return index
+
+
+# the R2 sequence's two constants AS THE DEFINITION HAS THEM: rounded to float (the index reaches 8 400: the double constants would move a sample by 4e-4)
+R2_A, R2_B = float(np.float32(0.75487766624669276)), float(np.float32(0.56984029099805327))
+
+
+def ao_pixel(x, y, w, h, depth, normal_out, view_inv, proj_inv, tris, spp, radius, tol=1e-6):
+    """the AO value (0..255) of one pixel from the frame's depth and view-space normal outputs: the position is the primary ray scaled to the view depth, the
+    normal the normal output taken back to world space, the spp directions a cosine-weighted hemisphere about it -- the R2 sequence on the pixel's Hilbert index
+    (index + 288 sample) through the concentric square-root map, in the frame of Duff et al. (2017) -- each an any-hit segment (0.01 r, r) against EVERY triangle;
+    the count of blocked segments goes through (1 - k / spp) ^ 2.2 (XeGTAO's final power, vk_xe_gtao.rs:22)"""
+    if not depth < 10000.0:
+        return 255, 255, 255
+    o, d = primary_ray(x, y, w, h, view_inv, proj_inv)
+    pc = np.array([x + 0.5, y + 0.5]) / np.array([w, h], np.float64) * 2.0 - 1.0
+    tn = normalize((proj_inv @ np.array([pc[0], pc[1], 1.0, 1.0]))[:3])
+    wp = o + d * (depth / -tn[2])
+    n = np.array([normal_out[0] * 2.0 - 1.0, -(normal_out[1] * 2.0 - 1.0), -(normal_out[2] * 2.0 - 1.0)])
+    N = normalize(view_inv[:3, :3] @ n)
+    sg = math.copysign(1.0, N[2])
+    a = -1.0 / (sg + N[2]); b = N[0] * N[1] * a
+    T = np.array([1.0 + sg * N[0] * N[0] * a, sg * b, -sg * N[0]])
+    B = np.array([b, sg + N[1] * N[1] * a, -N[1]])
+    hidx = hilbert_index_64(x & 63, y & 63)
+    blocked, sure, maybe = 0, 0, 0
+    for s in range(spp):
+        fi = float(hidx + 288 * s)
+        u1, u2 = math.modf(0.5 + fi * R2_A)[0], math.modf(0.5 + fi * R2_B)[0]
+        r, cz, phi = math.sqrt(u1), math.sqrt(1.0 - u1), 2.0 * math.pi * u2
+        dvec = T * (r * math.cos(phi)) + B * (r * math.sin(phi)) + N * cz
+        blocked += closest_hit(wp, dvec, tris, radius * 0.01, radius)[0] >= 0
+        # the same segment a hair shorter at both ends against triangles a hair smaller, and a hair longer against triangles a hair larger: a segment that ends ON a
+        # surface or passes through an edge is blocked in one arithmetic and free in another
+        sure += closest_hit(wp, dvec, tris, radius * 0.01 * (1 + tol), radius * (1 - tol), -tol)[0] >= 0
+        maybe += closest_hit(wp, dvec, tris, radius * 0.01 * (1 - tol), radius * (1 + tol), tol)[0] >= 0
+    val = lambda k: int(math.floor((1.0 - k / spp) ** 2.2 * 255.0 + 0.5))
+    return val(blocked), val(maybe), val(sure)     # the value, and the interval it may lie in (fewest .. most blocked segments)

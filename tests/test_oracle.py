@@ -570,3 +570,28 @@ print("SANITIZER_RUN_OK")
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", ORC_SO="liborc_asan.so")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "SANITIZER_RUN_OK" in out.stdout and "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_ray_traced_ao_against_numpy_in_fp64(orc64, scenes):
+    """the AO pass is libart's own definition (no reference parity possible: it stands in for XeGTAO behind the same inputs and output), so until round 4 its oracle
+    was checked by the kernel written from it and nothing else.  The independent leg: the fp64 build of the oracle against tests/np_shading.py ao_pixel -- Hilbert
+    index, R2 samples (with the two constants rounded to float, as the definition has them: with the double constants five pixels of 1 600 differed by one sample --
+    the index reaches 8 400 and moves a direction by 4e-4), the hemisphere frame, numpy's own cos / sin instead of the C source's polynomial, every segment against
+    EVERY triangle, no tree -- on the Cornell box's depth and normal outputs, every pixel of a 40 x 40 frame at 16 and at 5 samples: the integers are equal (all
+    1 600; the test would let a pixel whose answer hangs on 1e-6 of a segment's length or of a triangle's edge lie between numpy's two answers: there is none)"""
+    sc = scenes.cornell()
+    w = h = 40
+    S, cam, recs, out = _f64_frame(orc64, sc, sc.lights, w, h)
+    view_inv = np.array(cam.view_inv, np.float64).reshape(4, 4).T
+    proj_inv = np.array(cam.proj_inv, np.float64).reshape(4, 4).T
+    tris, _, _ = NP.world_triangles(sc.primitives)
+    radius = 0.2 * 1.457
+    for spp in (16, 5):
+        got, st = orc64.render_ao(S, cam, out["depth"], out["normal"], spp, radius, threads=4)
+        res = np.array([[NP.ao_pixel(x, y, w, h, float(out["depth"][y, x]), out["normal"][y, x], view_inv, proj_inv, tris, spp, radius) for x in range(w)] for y in range(h)], np.uint32)
+        want, lo, hi = res[..., 0], res[..., 1], res[..., 2]
+        assert np.all((got >= lo) & (got <= hi)), np.argwhere((got < lo) | (got > hi))[:5]      # every pixel inside what numpy allows it ...
+        undecided = lo != hi
+        assert np.array_equal(got[~undecided], want[~undecided]) and undecided.mean() < 0.02    # ... which is ONE value for all but a few pixels with a segment ending on a surface
+        assert st["ao_rays"] == int((out["depth"] < 10000.0).sum()) * spp
+        assert want.min() < 200 and want.max() == 255 and len(np.unique(want)) > spp // 2      # corners and walls: a spread of values, not a constant
