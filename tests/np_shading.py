@@ -341,3 +341,72 @@ def ao_pixel(x, y, w, h, depth, normal_out, view_inv, proj_inv, tris, spp, radiu
         maybe += closest_hit(wp, dvec, tris, radius * 0.01 * (1 - tol), radius * (1 + tol), tol)[0] >= 0
     val = lambda k: int(math.floor((1.0 - k / spp) ** 2.2 * 255.0 + 0.5))
     return val(blocked), val(maybe), val(sure)     # the value, and the interval it may lie in (fewest .. most blocked segments)
+
+
+# ---- presentation: the B10G11R11 read-back, AO, AMD's LPM tone mapper as the reference configures it, display gamma -- restated in float64 ----------------
+def unpack_ufloat(v, mantissa_bits):
+    """an unsigned small float (5 exponent bits, bias 15) as the B10G11R11_UFLOAT_PACK32 format defines it"""
+    e, m = v >> mantissa_bits, v & ((1 << mantissa_bits) - 1)
+    if e == 31:
+        return math.inf if m == 0 else math.nan
+    if e == 0:
+        return m * 2.0 ** (-14 - mantissa_bits)
+    return (1.0 + m * 2.0 ** -mantissa_bits) * 2.0 ** (e - 15)
+
+
+def lpm_setup_709():
+    """LpmData::new(false, 0.0, 256.0, 8.0, 0.25, 1.0, zeros, (1, 1/2, 1/32)) with LPM_CONFIG_709_709 / LPM_COLORS_709_709 (vk_tonemap.rs:60-120, :417-426),
+    get_control_block (:122-230) and its own LpmColXyToZ / LpmColRgbToXyz (:12-47, z = 1 - x + y as written there) -- the numbers LpmMap reads"""
+    hdr_max, exposure, contrast, shoulder_contrast = 256.0, 8.0, 0.25 + 1.0, 1.0
+    saturation = np.zeros(3) + contrast
+    crosstalk = np.array([1.0, 1.0 / 2.0, 1.0 / 32.0])
+    mid_in, mid_out = hdr_max * 0.18 * 2.0 ** -exposure, 0.18
+    cs = contrast * shoulder_contrast
+    z0 = -mid_in ** contrast
+    z1 = hdr_max ** cs * mid_in ** contrast
+    z2 = hdr_max ** contrast * mid_in ** cs * mid_out
+    z3 = hdr_max ** cs * mid_out
+    z4 = mid_in ** cs * mid_out
+    tone = np.array([-((z0 + (mid_out * (z1 - z2)) / (z3 - z4)) / z4), (z1 - z2) / (z3 - z4)])
+
+    def xy_to_z(s):
+        return np.array([s[0], s[1], 1.0 - s[0] + s[1]])
+
+    def rgb_to_xyz(r, g, b, w):
+        rgb3 = np.stack([xy_to_z(r), xy_to_z(g), xy_to_z(b)], axis=1)       # columns r g b
+        w3 = xy_to_z(w) / w[1]
+        s = np.linalg.inv(rgb3) @ w3
+        return rgb3 * s[None, :]                                             # every row scaled component-wise
+
+    m = rgb_to_xyz((0.64, 0.33), (0.30, 0.60), (0.15, 0.06), (0.3127, 0.3290))
+    luma_w = m[1] / m[1].sum()
+    luma_t = m[1] / m[1].sum()                                               # soft = false: the working space's Y row
+    return dict(saturation=saturation, contrast=contrast, tone=tone, luma_w=luma_w, luma_t=luma_t, rcp_luma_t=1.0 / luma_t, crosstalk=crosstalk)
+
+
+def lpm_map_709(c, P):
+    """LpmMap (ffx_lpm.h:727-832) with shoulder, con, soft, con2, clip and scaleOnly all false"""
+    sat = lambda x: min(max(x, 0.0), 1.0)
+    R, G, B = c
+    rcp_max = 1.0 / max(R, G, B)
+    ratio = np.array([R * rcp_max, G * rcp_max, B * rcp_max]) ** P["saturation"]
+    lt = P["luma_t"]
+    luma = G * lt[1] + (R * lt[0] + B * lt[2])
+    luma = luma ** P["contrast"]
+    luma = luma / (luma * P["tone"][0] + P["tone"][1])
+    scale = sat(luma / float(ratio @ lt))
+    col = np.array([sat(x * scale) for x in ratio])
+    cap = -P["crosstalk"] * col + P["crosstalk"]
+    add = sat(luma - float(col @ lt))
+    t = add / float(cap @ lt)
+    col = np.array([sat(t * cap[k] + col[k]) for k in range(3)])
+    add = sat(luma - float(col @ lt))
+    return np.array([sat(add * P["rcp_luma_t"][k] + col[k]) for k in range(3)])
+
+
+def present_pixel(packed, ao, P):
+    """tonemap.comp.glsl:32-38 on one stored pixel: the packed colour read back, times ao / 255, LpmFilter(..., LPM_CONFIG_709_709), pow(1 / 2.2) -> B, G, R as 8-bit UNORM"""
+    c = np.array([unpack_ufloat(packed & 0x7FF, 6), unpack_ufloat((packed >> 11) & 0x7FF, 6), unpack_ufloat(packed >> 22, 5)]) * (ao / 255.0)
+    c = lpm_map_709(c, P) if c.max() > 0.0 else np.zeros(3)
+    c = np.clip(c ** (1.0 / 2.2), 0.0, 1.0) * 255.0
+    return c[::-1]                                                               # B G R, before rounding

@@ -595,3 +595,39 @@ def test_ray_traced_ao_against_numpy_in_fp64(orc64, scenes):
         assert np.array_equal(got[~undecided], want[~undecided]) and undecided.mean() < 0.02    # ... which is ONE value for all but a few pixels with a segment ending on a surface
         assert st["ao_rays"] == int((out["depth"] < 10000.0).sum()) * spp
         assert want.min() < 200 and want.max() == 255 and len(np.unique(want)) > spp // 2      # corners and walls: a spread of values, not a constant
+
+
+def test_presentation_against_numpy_in_fp64(orc):
+    """the last leg both hands wrote alike: AMD's LPM tone mapper, restated twice from ffx_lpm.h by the same hand (oracle and art_present.hip).
+    tests/np_shading.py restates the presentation a third time, in float64 and from the other side: the control block from the reference's own Rust
+    (vk_tonemap.rs:12-47, :122-230, with its z = 1 - x + y), LpmMap from ffx_lpm.h:727-832, the small-float read-back from the format's definition.  4 000 colours
+    from black over mid grey to 300 (saturated primaries, near-equal channels, every AO value): the oracle's 8-bit output is numpy's value rounded, or -- where
+    numpy's value lies within 0.02 of a rounding boundary and float arithmetic may fall the other way -- its neighbour"""
+    rng = np.random.default_rng(7)
+    n = 4000
+    col = np.zeros((1, n, 4), np.float32)
+    mag = 10.0 ** rng.uniform(-4, 2.48, n)
+    col[0, :, :3] = (rng.random((n, 3)) ** rng.choice([0.2, 1.0, 4.0], (n, 1))) * mag[:, None]
+    col[0, :50, :3] = 0.0                                           # black stays black
+    col[0, 50:100, :3] = mag[50:100, None]                          # greys
+    col[0, 100:150, 1:3] = 0.0                                      # saturated red
+    ao = rng.integers(0, 256, (1, n)).astype(np.uint32); ao[0, :200] = 255
+    packed, bgra = orc.present(col, ao)
+    P = NP.lpm_setup_709()
+    ctl = orc.lpm_control_block(False, 0.0, 256.0, 8.0, 0.25, 1.0, (0, 0, 0), (1.0, 0.5, 1.0 / 32.0)).view(np.float32)
+    assert np.allclose(ctl[0:3], P["saturation"], rtol=1e-6) and np.isclose(ctl[3], P["contrast"]) and np.allclose(ctl[4:6], P["tone"], rtol=2e-5)
+    assert np.allclose(ctl[6:9], P["luma_t"], rtol=1e-5) and np.allclose(ctl[12:15], P["rcp_luma_t"], rtol=1e-5) and np.allclose(ctl[25:28], P["luma_w"], rtol=1e-5)
+    near = exact = 0
+    for i in range(n):
+        want = NP.present_pixel(int(packed[0, i]), int(ao[0, i]), P)
+        got = bgra[0, i, :3].astype(np.float64)
+        for k in range(3):
+            r = math.floor(want[k] + 0.5)
+            if got[k] == r:
+                exact += 1
+            else:
+                assert abs(got[k] - r) == 1 and abs((want[k] + 0.5) - round(want[k] + 0.5)) < 0.02, (i, k, col[0, i], ao[0, i], want, got)
+                near += 1
+        assert bgra[0, i, 3] == 255
+    assert near < 0.01 * 3 * n, (near, exact)
+    assert len(np.unique(bgra[0, :, :3])) > 200                      # the whole output range is in the sample
