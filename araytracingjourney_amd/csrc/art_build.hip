@@ -571,6 +571,32 @@ __device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const D
     float *o = widef[w].box[i];
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
 }
+// one node of the pass behind the boxes: its quantised record (the per-ray walks' DevNode4) from its float one if asked, and what it adds to the tree's surface-area cost
+// (the half-areas of its child boxes); the root also leaves the half-area of its union in acc[1]
+__device__ __forceinline__ double wide_requant_node(uint32_t w, const DevNodeW *__restrict__ widef, DevNode4 *__restrict__ wide, bool requant, double *acc) {
+    const float4 *q = reinterpret_cast<const float4 *>(widef + w);
+    const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
+    const int4 ch = *reinterpret_cast<const int4 *>(&widef[w].child[0]);
+    const float lo[4][3] = {{a0.x, a0.y, a0.z}, {a1.z, a1.w, a2.x}, {a3.x, a3.y, a3.z}, {a4.z, a4.w, a5.x}}, hi[4][3] = {{a0.w, a1.x, a1.y}, {a2.y, a2.z, a2.w}, {a3.w, a4.x, a4.y}, {a5.y, a5.z, a5.w}};
+    const int nc = (ch.x != kAbsentChild) + (ch.y != kAbsentChild) + (ch.z != kAbsentChild) + (ch.w != kAbsentChild); // the valid children are slots 0 .. nc-1
+    if (requant) {
+        const float *plo[4] = {lo[0], lo[1], lo[2], lo[3]}, *phi[4] = {hi[0], hi[1], hi[2], hi[3]};
+        DevNode4 d;
+        wide_quantise(plo, phi, nc, d);
+        d.child[0] = ch.x; d.child[1] = ch.y; d.child[2] = ch.z; d.child[3] = ch.w;
+        wide[w] = d;
+    }
+    double a = 0.0;
+    float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = 0; j < nc; j++) {
+        if (box_nowhere(lo[j][0])) continue;
+        double dx = (double)hi[j][0] - lo[j][0], dy = (double)hi[j][1] - lo[j][1], dz = (double)hi[j][2] - lo[j][2];
+        a += dx * dy + dy * dz + dz * dx;
+        for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], lo[j][k]); rhi[k] = fmaxf(rhi[k], hi[j][k]); }
+    }
+    if (w == 0) { double dx = (double)rhi[0] - rlo[0], dy = (double)rhi[1] - rlo[1], dz = (double)rhi[2] - rlo[2]; acc[1] = dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
+    return a;
+}
 // The tree cut into BATCHES of whole subtrees of about kBatchNodes nodes (refit_lists_build) and the crown above them: ONE workgroup rewrites a batch's triangles and then refits
 // its nodes level by level, deepest first, with a workgroup barrier between levels -- everything a node of the batch depends on is the batch's own, written through the one L1
 // of the CU the workgroup runs on; a second launch of one large workgroup does the same for the crown (the few hundred nodes whose subtrees are larger than a batch).
@@ -580,9 +606,10 @@ __device__ __forceinline__ void wide_union_child(uint32_t w, uint32_t i, const D
 // it, per node and level, where a workgroup barrier costs nothing of the kind.  profiles/README.md round 4.
 // sub_off: [0, nb + 1] node offsets of batches 0 .. nb (batch nb = the crown) | [nb + 2, 2 nb + 3] leaf offsets | then nb + 1 rows of (n_levels + 1) offsets into the batch's
 // node list, deepest level of the tree first.
-__global__ void k_refit_sub(uint32_t batch0, uint32_t nb1 /*batches + the crown*/, uint32_t n_levels, const uint32_t *__restrict__ sub_nodes, const uint32_t *__restrict__ sub_leaves, const uint32_t *__restrict__ sub_off,
+template <bool FOLD> __global__ void k_refit_sub(uint32_t batch0, uint32_t nb1 /*batches + the crown*/, uint32_t n_levels, const uint32_t *__restrict__ sub_nodes, const uint32_t *__restrict__ sub_leaves, const uint32_t *__restrict__ sub_off,
                             const DevShadeTri *__restrict__ shade, const DevPrim *prims_host, DevPrim *prims_dev, uint32_t n_prim_words, const uint8_t *touched,
-                            const uint32_t *__restrict__ leaf_parent, const uint32_t *__restrict__ node_parent, uint32_t *mark, DevTri *tris, DevNodeW *widef, unsigned long long *stamp, bool first_launch) {
+                            const uint32_t *__restrict__ leaf_parent, const uint32_t *__restrict__ node_parent, uint32_t *mark, DevTri *tris, DevNodeW *widef, unsigned long long *stamp, bool first_launch,
+                            DevNode4 *wide, double *acc, double *out /*null: not the refit's last launch*/) {
     const uint32_t b = batch0 + blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     if (first_launch) {
         if (blockIdx.x == 0 && tid == 0) stamp[0] = wall_clock64();   // the refit's start (100 MHz): its device time travels to the host with its cost, no events
@@ -599,6 +626,32 @@ __global__ void k_refit_sub(uint32_t batch0, uint32_t nb1 /*batches + the crown*
         __threadfence_block();
         __syncthreads();   // the level above reads these records
     }
+    // Round 4g: what k_wide_requant did in a launch of its own behind the crown -- 514 workgroups finding their slots among the frames' packets, 0.2-0.3 ms of the refit's
+    // 0.5-0.7 -- each workgroup now does for ITS nodes while they are warm: the quantised records of the marked ones (marks cleared), its share of the tree's cost.  The
+    // crown's workgroup runs behind all the batches (stream order) and hands the result to the host.
+    if (!FOLD) return;   // (a small tree: k_wide_requant does this behind the crown, a node a thread -- see launch_refit; the instance without this tail keeps 40 registers
+                         //  and eight waves a SIMD -- with it 122, and a crown of 1 024 threads would need a CU all to itself)
+    __shared__ double s_cost[16];
+    double a = 0.0;
+    for (uint32_t i = sub_off[b] + tid; i < sub_off[b + 1]; i += nt) {
+        const uint32_t w = sub_nodes[i];
+        const bool m = mark[w] != 0u;
+        if (m) mark[w] = 0u;
+        a += wide_requant_node(w, widef, wide, m && wide, acc);
+    }
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+    if ((tid & 63u) == 0) s_cost[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (uint32_t i = 0; i < (nt + 63u) / 64u; i++) t += s_cost[i];
+        if (out) {   // the crown: every batch's sum is in acc[0] (they ran before this launch)
+            __threadfence();
+            out[0] = atomicAdd(&acc[0], t) + t; out[1] = *(volatile double *)&acc[1];
+            reinterpret_cast<unsigned long long *>(out)[2] = *(volatile unsigned long long *)&acc[2]; reinterpret_cast<unsigned long long *>(out)[3] = wall_clock64();
+            acc[0] = 0.0; acc[1] = 0.0;
+        } else if (t != 0.0) atomicAdd(&acc[0], t);
+    }
 }
 // after the boxes: every node's quantised record (the per-ray walks', DevNode4) from its float one, and the tree's surface-area cost while the boxes are at hand:
 // cost[0] += the half-areas of all child boxes (the measure of the rays that cross each box: what a walk pays for), cost[1] = half-area of the root's union.  A refit
@@ -614,26 +667,7 @@ __global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const Dev
     if (w < n_wide) {
         const bool requant = wide && (!mark || mark[w]);      // the double-precision quantisation only where a box changed; the cost sums every node
         if (mark && mark[w]) mark[w] = 0;                      // (the marks are this version's: cleared for its next refit)
-        const float4 *q = reinterpret_cast<const float4 *>(widef + w);
-        const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
-        const int4 ch = *reinterpret_cast<const int4 *>(&widef[w].child[0]);
-        const float lo[4][3] = {{a0.x, a0.y, a0.z}, {a1.z, a1.w, a2.x}, {a3.x, a3.y, a3.z}, {a4.z, a4.w, a5.x}}, hi[4][3] = {{a0.w, a1.x, a1.y}, {a2.y, a2.z, a2.w}, {a3.w, a4.x, a4.y}, {a5.y, a5.z, a5.w}};
-        const int nc = (ch.x != kAbsentChild) + (ch.y != kAbsentChild) + (ch.z != kAbsentChild) + (ch.w != kAbsentChild); // the valid children are slots 0 .. nc-1
-        if (requant) {
-            const float *plo[4] = {lo[0], lo[1], lo[2], lo[3]}, *phi[4] = {hi[0], hi[1], hi[2], hi[3]};
-            DevNode4 d;
-            wide_quantise(plo, phi, nc, d);
-            d.child[0] = ch.x; d.child[1] = ch.y; d.child[2] = ch.z; d.child[3] = ch.w;
-            wide[w] = d;
-        }
-        float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int j = 0; j < nc; j++) {
-            if (box_nowhere(lo[j][0])) continue;
-            double dx = (double)hi[j][0] - lo[j][0], dy = (double)hi[j][1] - lo[j][1], dz = (double)hi[j][2] - lo[j][2];
-            a += dx * dy + dy * dz + dz * dx;
-            for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], lo[j][k]); rhi[k] = fmaxf(rhi[k], hi[j][k]); }
-        }
-        if (w == 0) { double dx = (double)rhi[0] - rlo[0], dy = (double)rhi[1] - rlo[1], dz = (double)rhi[2] - rlo[2]; acc[1] = dx < 0 ? 0.0 : dx * dy + dy * dz + dz * dx; }
+        a = wide_requant_node(w, widef, wide, requant, acc);
     }
     for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
     if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = a;
@@ -655,13 +689,22 @@ __global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const Dev
 void launch_wide_parents(uint32_t n_wide, const DevNodeW *widef, uint32_t *leaf_parent, uint32_t *node_parent, hipStream_t s) {
     k_wide_parents<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, leaf_parent, node_parent);
 }
-// a refit in three launches whatever the tree's depth: the batches (their triangles + their nodes), the crown (its triangles + its levels), the quantised records of the marked
-// nodes + the tree's cost -> result[0..3] = cost sum, root half-area, start and end stamps (wall_clock64: 100 MHz)
+constexpr uint32_t kFoldRequantNodes = 400000;
+// a refit in two or three launches whatever the tree's depth: the batches (their triangles, their nodes' boxes), the crown (the same for the nodes above the batches), and the
+// quantised records + cost either inside those (a large tree) or in a launch behind them -> result[0..3] = cost sum, root half-area, start and end stamps (wall_clock64: 100 MHz)
 void launch_refit(const RefitArgs &r, hipStream_t s) {
     unsigned long long *stamp = reinterpret_cast<unsigned long long *>(r.acc) + 2;
     const uint32_t npw = r.n_prims * (uint32_t)(sizeof(DevPrim) / 4), nb1 = r.sub_batches + 1;
-    if (r.sub_batches) k_refit_sub<<<r.sub_batches, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true);
-    k_refit_sub<<<1, 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, r.sub_batches == 0);
+    // The quantised records and the cost: in the refit's own workgroups for a large tree (config 4's 1.4 M nodes: a refit alone 0.57 -> 0.28 ms, a frame of a moving model
+    // 0.67 -> 0.44), in a launch of their own -- a node a thread -- for a small one (config 2's 131 k nodes: folded, a refit alone 0.13 -> 0.19 ms: three nodes' double-precision
+    // quantisation in a row per thread of 143 workgroups against one each in 514; among frames the two forms cost the same).  profiles/README.md round 4g
+    if (r.n_wide >= kFoldRequantNodes) {
+        if (r.sub_batches) k_refit_sub<true><<<r.sub_batches, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true, r.wide, r.acc, nullptr);
+        k_refit_sub<true><<<1, r.sub_batches ? 256 : 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, r.sub_batches == 0, r.wide, r.acc, r.result);
+        return;
+    }
+    if (r.sub_batches) k_refit_sub<false><<<r.sub_batches, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true, nullptr, nullptr, nullptr);
+    k_refit_sub<false><<<1, 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, r.sub_batches == 0, nullptr, nullptr, nullptr);
     k_wide_requant<<<(r.n_wide + 255) / 256, 256, 0, s>>>(r.n_wide, r.widef, r.wide, r.mark, r.acc, r.result);
 }
 // The refit's work lists, once per tree (host work on the parents read back: the topology never changes).  A node whose subtree has at most kBatchNodes nodes while its parent's
