@@ -1198,7 +1198,7 @@ def test_moving_frames_lap_the_ring_of_versions_without_a_sync(R, orc, get_scene
 def test_a_moved_model_at_the_bench_scenes_full_size(R, orc, get_scene, scenes, config):
     """row a3 at the sizes BASELINE names: config 2 (262 816 triangles; the model that moves is its u32-index primitive, 164 k triangles) and config 4 (2.8 M
     triangles, 63-bit keys) at 1920x1080 -- two poses in a row, each frame against the oracle built from scratch where the model is: hit ids, t, u, v, shadow
-    bits, ray counts bit for bit, radiance within 1e-4; and ray-traced AO in the refitted structure on config 2"""
+    bits, ray counts bit for bit, radiance within 1e-4; and ray-traced AO in the refitted structure (16 samples on config 2, 4 on config 4)"""
     sc = get_scene("sponza_like" if config == "c2" else "bistro_like", 1.0)
     lights = scenes.sponza_lights(1) if config == "c2" else sc.lights
     w, h = 1920, 1080
@@ -1222,10 +1222,13 @@ def test_a_moved_model_at_the_bench_scenes_full_size(R, orc, get_scene, scenes, 
         assert st["shadow_rays"] == ref["stats"]["shadow_rays"] and st["hit_pixels"] == ref["stats"]["hit_pixels"] and st["rebuilds"] == 0
         assert_radiance_close(r.read_color(), ref["color"])
     assert r.stats()["refits"] == 2 and 0 < r.stats()["refit_ms"] < 2.0                    # (the review's bar: a refresh within 2 ms on config 2)
-    if config == "c2":
-        r.trace_ao(16)
-        want_ao, _ = orc.render_ao(S, cam, ref["depth"], ref["normal"], 16, 0.2 * 1.457, threads=8)
-        assert np.array_equal(r.read_ao(), want_ao)
+    # ray-traced AO in the refitted structure: the per-ray walk over the QUANTISED records the refit made (for config 4's 1.4 M nodes inside the refit's own workgroups since
+    # round 4g, for config 2 in the launch behind them) -- and the cost that travelled to the host with them
+    spp = 16 if config == "c2" else 4
+    r.trace_ao(spp)
+    want_ao, _ = orc.render_ao(S, cam, ref["depth"], ref["normal"], spp, 0.2 * 1.457, threads=8)
+    assert np.array_equal(r.read_ao(), want_ao)
+    assert 0.95 < r.stats()["refit_cost_ratio"] < 2.0
     r.close()
 
 
