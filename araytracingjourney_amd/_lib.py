@@ -63,7 +63,7 @@ class ArtGlbCopyInfo(C.Structure):
 class ArtTuning(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("frame_form", "tree_builder", "packet_wide", "primary_walk", "shadow_walk", "ao_walk", "block_order", "fixed_waves",
                                           "split_fixed_steps", "split_min_steps")] + [("split_alpha", C.c_float)] + \
-               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder", "as_versions")] + [("refit_rebuild_ratio", C.c_float), ("trace_leaf_batch", C.c_uint32), ("plan_moving_interval", C.c_uint32), ("refit_streams", C.c_uint32)]
+               [(n, C.c_uint32) for n in ("ao_entry_off", "trace_chunk", "trace_refill", "trace_blocks", "hw_queues", "log", "wide_builder", "as_versions")] + [("refit_rebuild_ratio", C.c_float), ("trace_leaf_batch", C.c_uint32), ("plan_moving_interval", C.c_uint32), ("refit_streams", C.c_uint32), ("refit_fold_nodes", C.c_uint32)]
 
 
 class ArtLayout(C.Structure):

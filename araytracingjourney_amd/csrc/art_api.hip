@@ -129,6 +129,8 @@ struct AsVersion {
     // primitive (moved since this version was written), and the refit's result (cost sum, root half-area, start / end device stamps).  d*: the device's addresses of the same.
     DevPrim *h_prims = nullptr, *dh_prims = nullptr; uint8_t *h_touched = nullptr, *dh_touched = nullptr; double *h_result = nullptr, *dh_result = nullptr;
     uint32_t *mark = nullptr;            // per 4-wide node (art_build.hip k_retri): all zero between refits
+    uint32_t *h_dirty = nullptr, *dh_dirty = nullptr;   // pinned: the batches this refit runs (those that hold a primitive that moved since the version was written)
+    double *batch_cost = nullptr; bool cost_cached = false;   // device: every batch's share of this version's cost (large trees); valid once a refit has run all batches
     double *acc = nullptr;               // 4 doubles of device scratch of the refit's last launch: zero between refits
     uint64_t used[kMaxFrameSlots] = {};  // frame number + 1 of the newest launch on each ring slot that read this version (0: none)
     bool aux[kMaxFrameSlots] = {};       // art_trace_ao / art_present ran behind that frame on the slot's stream
@@ -328,8 +330,9 @@ int32_t as_create(ArtContext *c) {
         lap(1);
         // one device block and one pinned block, carved per version (256-byte steps)
         auto pad = [](size_t n) { return (n + 255) & ~(size_t)255; };
-        const size_t dev_owned = pad(T * sizeof(DevTri)) + pad(NW * sizeof(DevNodeW)) + pad(NW * sizeof(DevNode4)) + pad(np * sizeof(DevPrim)), dev_every = pad(NW * 4) + pad(32);
-        const size_t pin_every = pad(np * sizeof(DevPrim)) + pad(np) + pad(32);
+        const size_t nbat = c->bvh.sub_batches ? c->bvh.sub_batches : 1;
+        const size_t dev_owned = pad(T * sizeof(DevTri)) + pad(NW * sizeof(DevNodeW)) + pad(NW * sizeof(DevNode4)) + pad(np * sizeof(DevPrim)), dev_every = pad(NW * 4) + pad(32) + pad(nbat * 8);
+        const size_t pin_every = pad(np * sizeof(DevPrim)) + pad(np) + pad(32) + pad(nbat * 4);
         HIPC(hipMalloc(&c->as_block, (K - 1) * dev_owned + K * dev_every));
         HIPC(hipHostMalloc(&c->as_pinned, K * pin_every, hipHostMallocDefault));
         lap(2);
@@ -345,11 +348,12 @@ int32_t as_create(ArtContext *c) {
                 HIPC(hipMemcpyAsync(V.tris, c->bvh.tris, T * sizeof(DevTri), hipMemcpyDeviceToDevice, s)); HIPC(hipMemcpyAsync(V.widef, c->bvh.widef, NW * sizeof(DevNodeW), hipMemcpyDeviceToDevice, s));
                 HIPC(hipMemcpyAsync(V.wide, c->bvh.wide, NW * sizeof(DevNode4), hipMemcpyDeviceToDevice, s)); HIPC(hipMemcpyAsync(V.prims, c->d_prims.p, np * sizeof(DevPrim), hipMemcpyDeviceToDevice, s));
             }
-            V.mark = (uint32_t *)carve(dp, NW * 4); V.acc = (double *)carve(dp, 32);
+            V.mark = (uint32_t *)carve(dp, NW * 4); V.acc = (double *)carve(dp, 32); V.batch_cost = (double *)carve(dp, nbat * 8);
             HIPC(hipMemsetAsync(V.mark, 0, NW * 4, s)); HIPC(hipMemsetAsync(V.acc, 0, 32, s));
             const size_t off = (size_t)(hp - (char *)c->as_pinned);
             V.h_prims = (DevPrim *)carve(hp, np * sizeof(DevPrim)); V.h_touched = (uint8_t *)carve(hp, np); V.h_result = (double *)carve(hp, 32);
             V.dh_prims = (DevPrim *)(dhp + off); V.dh_touched = (uint8_t *)(dhp + off + pad(np * sizeof(DevPrim))); V.dh_result = (double *)(dhp + off + pad(np * sizeof(DevPrim)) + pad(np));
+            V.h_dirty = (uint32_t *)carve(hp, nbat * 4); V.dh_dirty = (uint32_t *)(dhp + off + pad(np * sizeof(DevPrim)) + pad(np) + pad(32));
             HIPC(hipEventCreateWithFlags(&V.ready, hipEventDisableTiming));
         }
         lap(3);
@@ -425,6 +429,20 @@ int32_t scene_refresh(ArtContext *c, uint32_t k, hipStream_t s) {
     ra.T = c->T; ra.n_wide = c->bvh.n_wide; ra.n_prims = (uint32_t)np; ra.shade = c->bvh.shade_tris; ra.prims_host = V.dh_prims; ra.prims_dev = V.prims; ra.touched = V.dh_touched;
     ra.sub_nodes = c->bvh.sub_nodes; ra.sub_leaves = c->bvh.sub_leaves; ra.sub_off = c->bvh.sub_off; ra.sub_batches = c->bvh.sub_batches; ra.sub_levels = c->bvh.sub_levels;
     ra.leaf_parent = c->bvh.leaf_parent; ra.node_parent = c->bvh.node_parent; ra.mark = V.mark; ra.tris = V.tris; ra.wide = V.wide; ra.widef = V.widef; ra.acc = V.acc; ra.result = V.dh_result;
+    {   // the batches that hold a primitive that moved (since this version was written); the others keep their triangles, their boxes and -- in a large tree -- their
+        // cached share of the cost, which a version's first refit makes for all of them
+        const std::vector<uint32_t> &po = c->bvh.batch_prim_off, &pi = c->bvh.batch_prim_ids;
+        ra.fold = c->bvh.n_wide >= (c->tuning.refit_fold_nodes ? c->tuning.refit_fold_nodes : kFoldRequantNodes);
+        const bool all = po.size() != (size_t)c->bvh.sub_batches + 1 || (ra.fold && !V.cost_cached);
+        uint32_t nd = 0;
+        if (!all) for (uint32_t b = 0; b < c->bvh.sub_batches; b++) {
+            bool hit = false;
+            for (uint32_t i = po[b]; i < po[b + 1] && !hit; i++) hit = pi[i] < np && V.h_touched[pi[i]] != 0;
+            if (hit) V.h_dirty[nd++] = b;
+        }
+        ra.dirty = all ? nullptr : V.dh_dirty; ra.n_dirty = nd; ra.batch_cost = V.batch_cost;
+        if (all) V.cost_cached = true;
+    }
     launch_refit(ra, s);
     HIPC(hipEventRecord(V.ready, s)); V.ready_known = false; V.ready_slot = beside ? ~0u : k; V.result_pending = true;   // (~0: no frame stream is behind it by itself)
     HIPC(hipGetLastError());

@@ -9,6 +9,7 @@
 // 64-byte traversal nodes + 64-byte leaf-ordered triangle records; the 4-wide collapse of the traversal tree, level by level (wide_build).
 #include "art_internal.h"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -609,8 +610,8 @@ __device__ __forceinline__ double wide_requant_node(uint32_t w, const DevNodeW *
 template <bool FOLD> __global__ void k_refit_sub(uint32_t batch0, uint32_t nb1 /*batches + the crown*/, uint32_t n_levels, const uint32_t *__restrict__ sub_nodes, const uint32_t *__restrict__ sub_leaves, const uint32_t *__restrict__ sub_off,
                             const DevShadeTri *__restrict__ shade, const DevPrim *prims_host, DevPrim *prims_dev, uint32_t n_prim_words, const uint8_t *touched,
                             const uint32_t *__restrict__ leaf_parent, const uint32_t *__restrict__ node_parent, uint32_t *mark, DevTri *tris, DevNodeW *widef, unsigned long long *stamp, bool first_launch,
-                            DevNode4 *wide, double *acc, double *out /*null: not the refit's last launch*/) {
-    const uint32_t b = batch0 + blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+                            DevNode4 *wide, double *acc, double *out /*null: not the refit's last launch*/, const uint32_t *__restrict__ dirty /*null: batch batch0 + blockIdx.x*/, double *batch_cost) {
+    const uint32_t b = dirty ? dirty[blockIdx.x] : batch0 + blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     if (first_launch) {
         if (blockIdx.x == 0 && tid == 0) stamp[0] = wall_clock64();   // the refit's start (100 MHz): its device time travels to the host with its cost, no events
         for (uint32_t i = blockIdx.x * nt + tid; i < n_prim_words; i += gridDim.x * nt) reinterpret_cast<uint32_t *>(prims_dev)[i] = reinterpret_cast<const uint32_t *>(prims_host)[i];   // the table's device copy, for the frames
@@ -639,18 +640,18 @@ template <bool FOLD> __global__ void k_refit_sub(uint32_t batch0, uint32_t nb1 /
         if (m) mark[w] = 0u;
         a += wide_requant_node(w, widef, wide, m && wide, acc);
     }
+    if (out) for (uint32_t i = tid; i + 1u < nb1; i += nt) a += batch_cost[i];   // the crown: every batch's share, made by this refit or kept from an earlier one of this version
     for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
     if ((tid & 63u) == 0) s_cost[tid >> 6] = a;
     __syncthreads();
     if (tid == 0) {
         double t = 0.0;
         for (uint32_t i = 0; i < (nt + 63u) / 64u; i++) t += s_cost[i];
-        if (out) {   // the crown: every batch's sum is in acc[0] (they ran before this launch)
-            __threadfence();
-            out[0] = atomicAdd(&acc[0], t) + t; out[1] = *(volatile double *)&acc[1];
+        if (out) {
+            out[0] = t; out[1] = *(volatile double *)&acc[1];
             reinterpret_cast<unsigned long long *>(out)[2] = *(volatile unsigned long long *)&acc[2]; reinterpret_cast<unsigned long long *>(out)[3] = wall_clock64();
             acc[0] = 0.0; acc[1] = 0.0;
-        } else if (t != 0.0) atomicAdd(&acc[0], t);
+        } else batch_cost[b] = t;
     }
 }
 // after the boxes: every node's quantised record (the per-ray walks', DevNode4) from its float one, and the tree's surface-area cost while the boxes are at hand:
@@ -689,7 +690,6 @@ __global__ __launch_bounds__(256) void k_wide_requant(uint32_t n_wide, const Dev
 void launch_wide_parents(uint32_t n_wide, const DevNodeW *widef, uint32_t *leaf_parent, uint32_t *node_parent, hipStream_t s) {
     k_wide_parents<<<(n_wide + 255) / 256, 256, 0, s>>>(n_wide, widef, leaf_parent, node_parent);
 }
-constexpr uint32_t kFoldRequantNodes = 400000;
 // a refit in two or three launches whatever the tree's depth: the batches (their triangles, their nodes' boxes), the crown (the same for the nodes above the batches), and the
 // quantised records + cost either inside those (a large tree) or in a launch behind them -> result[0..3] = cost sum, root half-area, start and end stamps (wall_clock64: 100 MHz)
 void launch_refit(const RefitArgs &r, hipStream_t s) {
@@ -698,18 +698,23 @@ void launch_refit(const RefitArgs &r, hipStream_t s) {
     // The quantised records and the cost: in the refit's own workgroups for a large tree (config 4's 1.4 M nodes: a refit alone 0.57 -> 0.28 ms, a frame of a moving model
     // 0.67 -> 0.44), in a launch of their own -- a node a thread -- for a small one (config 2's 131 k nodes: folded, a refit alone 0.13 -> 0.19 ms: three nodes' double-precision
     // quantisation in a row per thread of 143 workgroups against one each in 514; among frames the two forms cost the same).  profiles/README.md round 4g
-    if (r.n_wide >= kFoldRequantNodes) {
-        if (r.sub_batches) k_refit_sub<true><<<r.sub_batches, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true, r.wide, r.acc, nullptr);
-        k_refit_sub<true><<<1, r.sub_batches ? 256 : 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, r.sub_batches == 0, r.wide, r.acc, r.result);
+    const uint32_t grid = r.dirty ? r.n_dirty : r.sub_batches;   // (a refit runs the batches that hold a primitive that moved; the crown always)
+    if (r.fold) {
+        if (grid) k_refit_sub<true><<<grid, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true, r.wide, r.acc, nullptr, r.dirty, r.batch_cost);
+        k_refit_sub<true><<<1, r.sub_batches ? 256 : 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, grid == 0, r.wide, r.acc, r.result, nullptr, r.batch_cost);
         return;
     }
-    if (r.sub_batches) k_refit_sub<false><<<r.sub_batches, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true, nullptr, nullptr, nullptr);
-    k_refit_sub<false><<<1, 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, r.sub_batches == 0, nullptr, nullptr, nullptr);
+    if (grid) k_refit_sub<false><<<grid, 256, 0, s>>>(0u, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, true, nullptr, nullptr, nullptr, r.dirty, nullptr);
+    k_refit_sub<false><<<1, 1024, 0, s>>>(r.sub_batches, nb1, r.sub_levels, r.sub_nodes, r.sub_leaves, r.sub_off, r.shade, r.prims_host, r.prims_dev, npw, r.touched, r.leaf_parent, r.node_parent, r.mark, r.tris, r.widef, stamp, grid == 0, nullptr, nullptr, nullptr, nullptr, nullptr);
     k_wide_requant<<<(r.n_wide + 255) / 256, 256, 0, s>>>(r.n_wide, r.widef, r.wide, r.mark, r.acc, r.result);
 }
 // The refit's work lists, once per tree (host work on the parents read back: the topology never changes).  A node whose subtree has at most kBatchNodes nodes while its parent's
 // has more roots a batch subtree; runs of such roots (in index order) are dealt to batches of about kBatchNodes nodes; the nodes above them -- the crown: a few hundred for the
 // bench scenes -- are batch `nb`.  The numbering is breadth-first, so a larger index is never above a smaller one: a batch's nodes in descending order are deepest level first.
+__global__ __launch_bounds__(256) void k_leaf_prims(uint32_t T, const uint32_t *__restrict__ leaf_gid, const uint32_t *__restrict__ tri_prim, uint32_t *__restrict__ out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < T) out[p] = tri_prim[leaf_gid[p]];
+}
 hipError_t refit_lists_build(Lbvh &l, uint32_t T, hipStream_t s) {
     constexpr uint32_t kBatchNodes = 768;
     const std::vector<uint32_t> &levels = l.wide_levels;
@@ -753,6 +758,27 @@ hipError_t refit_lists_build(Lbvh &l, uint32_t T, hipStream_t s) {
         for (uint32_t b = 0; b <= nb1; b++) off[nb1 + 1 + b] = cnt[b];
         std::vector<uint32_t> at(cnt.begin(), cnt.end() - 1);
         for (uint32_t p = 0; p < T; p++) sub_leaves[at[slot(leaf_parent[p])]++] = p;
+    }
+    {   // which primitives have triangles in which batch (the crown always runs): the leaf's primitive is tri_prim[leaf_gid[p]], gathered on the device
+        std::vector<uint32_t> tp(T);
+        uint32_t *d_lp = nullptr;
+        HIPQ(hipMalloc(&d_lp, (size_t)T * 4));
+        k_leaf_prims<<<(T + 255) / 256, 256, 0, s>>>(T, l.leaf_gid, l.tri_prim, d_lp);
+        hipError_t ec = hipMemcpyAsync(tp.data(), d_lp, (size_t)T * 4, hipMemcpyDeviceToHost, s);   // (on the kernel's own stream: the context's streams do not wait for the null stream or it for them)
+        if (ec == hipSuccess) ec = hipStreamSynchronize(s);
+        hipFree(d_lp);
+        HIPQ(ec);
+        uint32_t n_prims = 0;
+        for (uint32_t g = 0; g < T; g++) n_prims = std::max(n_prims, tp[g] + 1u);
+        std::vector<uint32_t> seen(n_prims, 0u);   // seen[primitive] = batch + 1 of the last batch it was listed for (the leaf lists are batch by batch: one pass)
+        l.batch_prim_off.assign(1, 0u); l.batch_prim_ids.clear();
+        for (uint32_t b = 0; b < nb; b++) {
+            for (uint32_t i = off[nb1 + 1 + b]; i < off[nb1 + 2 + b]; i++) {
+                const uint32_t pr = tp[sub_leaves[i]];
+                if (seen[pr] != b + 1u) { seen[pr] = b + 1u; l.batch_prim_ids.push_back(pr); }
+            }
+            l.batch_prim_off.push_back((uint32_t)l.batch_prim_ids.size());
+        }
     }
     hipFree(l.sub_nodes); hipFree(l.sub_leaves); hipFree(l.sub_off); l.sub_nodes = l.sub_leaves = l.sub_off = nullptr;
     HIPQ(hipMalloc(&l.sub_nodes, (size_t)NW * 4)); HIPQ(hipMalloc(&l.sub_leaves, (size_t)T * 4)); HIPQ(hipMalloc(&l.sub_off, off.size() * 4));

@@ -119,6 +119,7 @@ struct Lbvh {               // canonical binary LBVH, device arrays
     // the refit's work lists (refit_lists_build, made with the parents): the tree below its top levels is cut into batches of neighbouring subtrees, one workgroup each
     uint32_t *sub_nodes = nullptr, *sub_leaves = nullptr, *sub_off = nullptr;   // device: batch b's nodes (deepest level first) / leaves; batch nb = the crown above the batches; sub_off: see k_refit_sub
     uint32_t sub_batches = 0, sub_levels = 0;                                     // host: batches (without the crown); levels of the tree
+    std::vector<uint32_t> batch_prim_off, batch_prim_ids;                         // host: the primitives whose triangles lie in batch b: ids [off[b], off[b + 1]) -- a refit launches the batches that hold a primitive that moved
     int32_t *trav_child;    // [2*(T-1)] topology of the traversal nodes when it is not the canonical one (sah_build), else null
     float *trav_lo, *trav_hi; // [(T-1)*3]
     char *block = nullptr;  // host: ONE allocation behind the arrays lbvh_build makes (leaf_gid .. shade_tris, cbounds) and room for the traversal tree's three (res_trav_*): two dozen
@@ -153,7 +154,11 @@ struct RefitArgs {
     const DevShadeTri *shade; const DevPrim *prims_host; DevPrim *prims_dev; const uint8_t *touched;
     const uint32_t *leaf_parent, *node_parent; uint32_t *mark;
     DevTri *tris; DevNode4 *wide; DevNodeW *widef; double *acc, *result;
+    const uint32_t *dirty; uint32_t n_dirty;   // the batches to run (device-visible list; null: all of them)
+    double *batch_cost;                        // [sub_batches] this version's cost share of every batch (large trees: a batch that does not run keeps its share)
+    bool fold;                                 // the quantised records and the cost in the refit's own workgroups (large trees: kFoldRequantNodes / ArtTuning.refit_fold_nodes)
 };
+constexpr uint32_t kFoldRequantNodes = 400000;   // trees of this many 4-wide nodes and more: the refit's workgroups make the quantised records and the cost themselves (art_build.hip launch_refit)
 void launch_refit(const RefitArgs &r, hipStream_t s);
 void launch_wide_parents(uint32_t n_wide, const DevNodeW *widef, uint32_t *leaf_parent, uint32_t *node_parent, hipStream_t s);
 hipError_t refit_lists_build(Lbvh &l, uint32_t T, hipStream_t s);   // after launch_wide_parents (synchronises: a one-off of the scene's first version ring)

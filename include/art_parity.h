@@ -44,6 +44,7 @@ typedef struct ArtTuning {
     uint32_t trace_leaf_batch;  /* persistent per-ray tracer: lanes that must be waiting for a triangle test before the wave runs one, 1..64 (0 = presets: 1, AO rays 8) */
     uint32_t plan_moving_interval; /* wave plan: frames between two looks at the waves while the camera / the lights change every frame (0 = 32) */
     uint32_t refit_streams;     /* moving models: streams of their own the refits run on, beside the frames of the ring slot they precede (0 = min(frames in flight, 4); 0xFFFFFFFF: none -- every refit on its frame's stream, in front of it) */
+    uint32_t refit_fold_nodes;  /* moving models: trees of this many 4-wide nodes and more make the quantised records and the cost inside the refit's own workgroups, with a cached share of the cost per batch (0 = 400 000; 1 = every tree: the tests' way to that form on small scenes) */
 } ArtTuning;
 int32_t art_set_tuning(ArtContext *ctx, const ArtTuning *tuning);
 /* per-pixel primary hit record, row-major: tuv[4*i] = t,u,v,0 ; ids[2*i] = primitive index (-1 miss), triangle id */

@@ -1194,6 +1194,49 @@ def test_moving_frames_lap_the_ring_of_versions_without_a_sync(R, orc, get_scene
     r.close()
 
 
+def test_a_small_model_moves_among_batches_that_stay(R, orc, get_scene, scenes):
+    """round 4g / 4h: a refit launches only the batches of subtrees that hold a primitive that moved, and a large tree makes its quantised records and its cost in the
+    refit's own workgroups with every batch's share of the cost cached per version (ArtTuning.refit_fold_nodes = 1: that form on this small tree; 0: the launch of its
+    own behind the crown).  One 3 920-triangle primitive of a 66 k-triangle scene moves through eight poses and back to where it was built, two versions, so every
+    version is rewritten four times -- the first time all batches run, afterwards the few that hold the mover: every frame is the oracle's frame of a scene built
+    from scratch (depth, normal bit for bit), AO walks the refitted quantised records, and the two forms report the same cost, equal to the build's once the model is back"""
+    sc = get_scene("sponza_like", 0.5)
+    w, h = 256, 144
+    lights = scenes.sponza_lights(1)
+    movers = [6]
+    cam = oracle_camera(orc, sc, w, h)
+    L = orc.make_lights(lights)
+    poses, refs = [], []
+    ratios = {}
+    for fold in (1, 0):
+        r, static, moving = _moving_scene(R, scenes, sc, movers, (w, h), lights, frames_in_flight=1, tuning={"as_versions": 2, "refit_rebuild_ratio": -1.0, "refit_fold_nodes": fold})
+        model = r.models_mut()[1]
+        base = moving[0].model
+        if not poses:
+            poses = [_pose(base, i) for i in range(1, 8)] + [np.ascontiguousarray(np.asarray(base, np.float32).reshape(3, 4))]
+            refs = [_oracle_of_moved(orc, scenes, static, moving, m) for m in poses]
+        r.render_frame()
+        ratios[fold] = []
+        for m, S in zip(poses, refs):
+            model.set_model_matrix(m)
+            r.render_frame()
+            ref = S.render(cam, L, len(lights), w, h, threads=8, debug=True)
+            assert np.array_equal(r.read_depth().view(np.uint32), ref["depth"].view(np.uint32))
+            assert np.array_equal(r.read_normal().view(np.uint32), ref["normal"].view(np.uint32))
+            assert_radiance_close(r.read_color(), ref["color"])
+            r.sync()
+            ratios[fold].append(r.stats()["refit_cost_ratio"])
+        r.trace_ao(8)
+        want_ao, _ = orc.render_ao(refs[-1], cam, ref["depth"], ref["normal"], 8, 0.2 * 1.457, threads=8)
+        assert np.array_equal(r.read_ao(), want_ao)
+        st = r.stats()
+        assert st["refits"] == len(poses) and st["rebuilds"] == 0
+        r.close()
+    # (the cost a frame reports is that of the latest refit whose result has arrived: each frame above was waited for, so it is its own)
+    assert np.allclose(ratios[1], ratios[0], rtol=1e-9), (ratios[1], ratios[0])
+    assert abs(ratios[1][-1] - 1.0) < 1e-6 and max(ratios[1]) > 1.0005, ratios[1]     # back where it was built: the build's cost again; in between the tree was looser
+
+
 @pytest.mark.parametrize("config", ["c2", "c4"])
 def test_a_moved_model_at_the_bench_scenes_full_size(R, orc, get_scene, scenes, config):
     """row a3 at the sizes BASELINE names: config 2 (262 816 triangles; the model that moves is its u32-index primitive, 164 k triangles) and config 4 (2.8 M
